@@ -1,0 +1,186 @@
+"""Synthetic index builder (Tier A "structured" data of SURVEY.md 8(d)).
+
+The reference ships no dataset (sift10kfiles.tar.gz is absent) and relies on external DiskANN
+tools (``build_disk_index``, ``compute_groundtruth``; BANG_Base/ReadMe.pdf p.1-2) to produce the
+files ``bang_load`` reads.  This module produces the same files from a seed:
+
+* base vectors  = mixture of Gaussian clusters, clipped/rounded for uint8 / int8;
+* graph         = R/2 exact nearest neighbours + R/2 uniformly random long links per node,
+                  de-duplicated, adjacency sorted ascending (bang_preprocess.py:102-104), ragged
+                  degree allowed;
+* medoid        = point nearest the dataset mean;
+* PQ            = DiskANN-style: centroid = mean, D split into m chunks of near-equal size,
+                  256-means per chunk on centred data, codes = nearest pivot;
+* queries       = base points + Gaussian noise; ground truth by brute force.
+
+Everything runs through torch so the same code builds 10K-point fixtures on the CPU and the
+1M-point benchmark index on the GPU in seconds.  (Index *construction* is outside the search
+hot path -- SURVEY 8 f-3.)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .formats import Index, NP_DTYPE, pack_graph
+
+SEED = 20240711
+
+
+def _gen(seed: int, device) -> torch.Generator:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, sigma: float = 12.0,
+                 seed: int = SEED, device="cpu") -> torch.Tensor:
+    """float32 tensor [N, D] already rounded/clipped to the value range of ``dtype``."""
+    g = _gen(seed, device)
+    centres = torch.rand(n_clusters, D, generator=g, device=device) * 175.0 + 40.0
+    assign = torch.randint(0, n_clusters, (N,), generator=g, device=device)
+    x = centres[assign] + torch.randn(N, D, generator=g, device=device) * sigma
+    if dtype == "uint8":
+        x = x.round().clamp_(0, 255)
+    elif dtype == "int8":
+        x = (x - 128.0).round().clamp_(-128, 127)
+    else:
+        x = x / 128.0
+    return x
+
+
+def _sq_norms(x: torch.Tensor) -> torch.Tensor:
+    return (x * x).sum(dim=1)
+
+
+def knn(base: torch.Tensor, queries: torch.Tensor, k: int, exclude_self: bool = False,
+        row_block: int = 4096, col_block: int = 262144):
+    """Exact k nearest neighbours (squared L2) of every query row among ``base`` rows.
+    Returns (ids int64 [Q,k], dists float32 [Q,k]) sorted ascending by (dist, id)."""
+    Nb = base.shape[0]
+    bn = _sq_norms(base)
+    out_i, out_d = [], []
+    for r0 in range(0, queries.shape[0], row_block):
+        q = queries[r0:r0 + row_block]
+        qn = _sq_norms(q)
+        cand_d, cand_i = [], []
+        for c0 in range(0, Nb, col_block):
+            b = base[c0:c0 + col_block]
+            d = qn[:, None] + bn[None, c0:c0 + col_block] - 2.0 * (q @ b.T)
+            if exclude_self:
+                rows = torch.arange(r0, r0 + q.shape[0], device=base.device)
+                inside = (rows >= c0) & (rows < c0 + b.shape[0])
+                d[inside.nonzero().squeeze(1), rows[inside] - c0] = float("inf")
+            kk = min(k, b.shape[0])
+            dd, ii = torch.topk(d, kk, dim=1, largest=False)
+            cand_d.append(dd)
+            cand_i.append(ii + c0)
+        cd = torch.cat(cand_d, dim=1)
+        ci = torch.cat(cand_i, dim=1)
+        # exact re-evaluation of the shortlisted candidates (removes matmul round-off), then a
+        # lexicographic (dist, id) order so ties are deterministic
+        diff = q[:, None, :] - base[ci]
+        cd = (diff * diff).sum(dim=2)
+        order = torch.argsort(ci, dim=1, stable=True)
+        cd, ci = torch.gather(cd, 1, order), torch.gather(ci, 1, order)
+        order = torch.argsort(cd, dim=1, stable=True)[:, :k]
+        out_d.append(torch.gather(cd, 1, order))
+        out_i.append(torch.gather(ci, 1, order))
+    return torch.cat(out_i), torch.cat(out_d)
+
+
+def build_graph(x: torch.Tensor, R: int, seed: int = SEED, n_knn: int | None = None):
+    """kNN + random-long-link graph.  Returns (degrees int64 [N], adjacency int64 [N,R]) with each
+    row's first ``degree`` entries distinct, != self and sorted ascending; the tail is 0."""
+    N = x.shape[0]
+    dev = x.device
+    n_knn = min(R // 2 if n_knn is None else n_knn, N - 1)
+    nn_ids, _ = knn(x, x, n_knn, exclude_self=True)
+    g = _gen(seed + 1, dev)
+    rnd = torch.randint(0, N, (N, R - n_knn), generator=g, device=dev)
+    adj = torch.cat([nn_ids, rnd], dim=1)
+    adj, _ = torch.sort(adj, dim=1)
+    self_id = torch.arange(N, device=dev)[:, None]
+    keep = torch.ones_like(adj, dtype=torch.bool)
+    keep[:, 1:] = adj[:, 1:] != adj[:, :-1]
+    keep &= adj != self_id
+    deg = keep.sum(dim=1)
+    pos = torch.cumsum(keep.to(torch.int64), dim=1) - 1
+    out = torch.zeros_like(adj)
+    rows = torch.arange(N, device=dev)[:, None].expand_as(adj)
+    out[rows[keep], pos[keep]] = adj[keep]
+    return deg, out
+
+
+def chunk_offsets(D: int, m: int) -> np.ndarray:
+    """DiskANN's split: the first D % m chunks get ceil(D/m) dims, the rest floor(D/m)."""
+    lo, rem = divmod(D, m)
+    sizes = [lo + 1 if c < rem else lo for c in range(m)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+
+
+def train_pq(x: torch.Tensor, m: int, iters: int = 8, sample: int = 65536, seed: int = SEED):
+    """Returns (pivots [256,D] f32, centroid [D] f32, chunk_off [m+1] u32, codes [N,m] u8) as torch/np."""
+    N, D = x.shape
+    dev = x.device
+    g = _gen(seed + 2, dev)
+    centroid = x.mean(dim=0)
+    xc = x - centroid
+    off = chunk_offsets(D, m)
+    pivots = torch.zeros(256, D, device=dev)
+    codes = torch.empty(N, m, dtype=torch.uint8, device=dev)
+    sidx = torch.randperm(N, generator=g, device=dev)[: min(sample, N)]
+    for c in range(m):
+        a, b = int(off[c]), int(off[c + 1])
+        sub = xc[sidx, a:b]
+        if sub.shape[0] >= 256:
+            init = torch.randperm(sub.shape[0], generator=g, device=dev)[:256]
+        else:
+            init = torch.randint(0, sub.shape[0], (256,), generator=g, device=dev)
+        cen = sub[init].clone()
+        for _ in range(iters):
+            d = torch.cdist(sub, cen)
+            lab = d.argmin(dim=1)
+            sums = torch.zeros_like(cen).index_add_(0, lab, sub)
+            cnt = torch.zeros(256, device=dev).index_add_(0, lab, torch.ones_like(lab, dtype=torch.float32))
+            nz = cnt > 0
+            cen[nz] = sums[nz] / cnt[nz, None]
+        pivots[:, a:b] = cen
+        full = xc[:, a:b]
+        for r0 in range(0, N, 1 << 20):
+            codes[r0:r0 + (1 << 20), c] = torch.cdist(full[r0:r0 + (1 << 20)], cen).argmin(dim=1).to(torch.uint8)
+    return pivots, centroid, off, codes
+
+
+def make_queries(x: torch.Tensor, Q: int, dtype: str, noise: float = 6.0, seed: int = SEED) -> torch.Tensor:
+    g = _gen(seed + 3, x.device)
+    pick = torch.randint(0, x.shape[0], (Q,), generator=g, device=x.device)
+    scale = noise if dtype != "float" else noise / 128.0
+    q = x[pick] + torch.randn(Q, x.shape[1], generator=g, device=x.device) * scale
+    if dtype == "uint8":
+        q = q.round().clamp_(0, 255)
+    elif dtype == "int8":
+        q = q.round().clamp_(-128, 127)
+    return q
+
+
+def to_numpy(x: torch.Tensor, dtype: str) -> np.ndarray:
+    return x.detach().cpu().numpy().astype(NP_DTYPE[dtype])
+
+
+def make_index(N: int, D: int, dtype: str, R: int, m: int, Q: int, K: int = 10, n_clusters: int = 256,
+               seed: int = SEED, device="cpu", pq_iters: int = 8):
+    """Build a complete structured test case.  Returns (Index, queries np [Q,D], gt_ids np u32 [Q,K],
+    gt_dists np f32 [Q,K])."""
+    x = make_vectors(N, D, dtype, n_clusters=n_clusters, seed=seed, device=device)
+    deg, adj = build_graph(x, R, seed=seed)
+    medoid = int(_sq_norms(x - x.mean(dim=0)).argmin())
+    pivots, centroid, off, codes = train_pq(x, m, iters=pq_iters, seed=seed)
+    q = make_queries(x, Q, dtype, seed=seed)
+    gt_i, gt_d = knn(x, q, K)
+    vec_np = to_numpy(x, dtype)
+    graph = pack_graph(vec_np, deg.cpu().numpy().astype(np.uint32), adj.cpu().numpy().astype(np.uint32))
+    ix = Index(dtype=dtype, N=N, D=D, R=R, m=m, medoid=medoid, graph=graph,
+               codes=codes.cpu().numpy(), pivots=pivots.cpu().numpy().astype(np.float32),
+               centroid=centroid.cpu().numpy().astype(np.float32), chunk_off=off)
+    return ix, to_numpy(q, dtype), gt_i.cpu().numpy().astype(np.uint32), gt_d.cpu().numpy().astype(np.float32)
