@@ -1,0 +1,848 @@
+// bang_engine.cpp -- host side of the MI355X-native BANG_Base search engine.
+//
+// Mirrors the reference's BANGSearchInner<T> (BANG_Base/bang_search.cuh:341-370; implementation
+// bang_search.cu:138-1068): bang_load / bang_set_searchparams / bang_alloc / bang_init /
+// bang_query / bang_free / bang_unload, behind the C-ABI of include/bang_c.h.
+//
+// What is different from the reference, on purpose:
+//  * the batch is split into LANES (contiguous query ranges).  Each lane owns a HIP stream, pinned
+//    staging buffers and a host walker thread, and runs its own iteration loop, so one lane's
+//    PCIe / CPU latency hides behind another lane's kernels (the reference advances all 10K
+//    queries in lock-step and pays every round trip serially, bang_search.cu:701-958).
+//  * per iteration a lane issues 2 kernels (front = filter+distance+parent, back = sort+merge)
+//    instead of 6 kernels + 2 memsets; parents are written by the kernel straight into mapped
+//    pinned host memory (no D2H copy), adjacency rows travel in one H2D copy.
+//  * graph placement is a run-time option: host RAM + C++ walker (BANG_Base) or HBM-resident
+//    (BANG_Inmemory placement) with the identical search semantics, hence identical results.
+//  * there is NO CPU fallback: without a HIP device every call fails with BANG_ERR_NOGPU.
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bang_c.h"
+#include "bang_internal.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+extern "C" void bang_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* bang_last_error(void) { return g_err; }
+
+#define HIP_TRY(x)                                                                                \
+  do {                                                                                            \
+    hipError_t _e = (x);                                                                          \
+    if (_e != hipSuccess) {                                                                       \
+      bang_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__);     \
+      return BANG_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+#define BANG_TRY(x)            \
+  do {                         \
+    int _r = (x);              \
+    if (_r != BANG_OK) return _r; \
+  } while (0)
+
+extern "C" int bang_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------ device helpers
+extern "C" int bang_dev_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return BANG_ERR_ARG;
+  if (bang_device_count() == 0) { bang_set_error("no HIP device"); return BANG_ERR_NOGPU; }
+  HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 4));
+  return BANG_OK;
+}
+extern "C" int bang_dev_free(void* d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return BANG_OK; }
+extern "C" int bang_dev_memset(void* d_ptr, int value, size_t bytes) { HIP_TRY(hipMemset(d_ptr, value, bytes)); return BANG_OK; }
+extern "C" int bang_dev_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return BANG_OK;
+}
+extern "C" int bang_dev_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return BANG_OK;
+}
+extern "C" int bang_dev_sync(void) { HIP_TRY(hipDeviceSynchronize()); return BANG_OK; }
+
+// ------------------------------------------------------------------ engine state
+namespace {
+
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+
+struct Lane {
+  uint32_t q0 = 0, nq = 0;
+  hipStream_t s_main = nullptr, s_fp = nullptr;
+  hipEvent_t ev_front = nullptr, ev_fp = nullptr;
+  std::vector<hipEvent_t> tev;      // timing events (pairs), "timing"=1
+  size_t tev_used = 0;
+  std::vector<int> tev_kind;        // 0 front, 1 back, 2 rerank
+  // results of the last run
+  int rc = BANG_OK;
+  std::string err;
+  uint32_t iterations = 0;
+  uint64_t front_launches = 0;
+  double walker_ms = 0, front_ms = 0, back_ms = 0, rerank_ms = 0;
+};
+
+}  // namespace
+
+struct bang_engine {
+  int dtype = BANG_U8;
+  size_t tsize = 1;
+  // options
+  int graph_mode = BANG_GRAPH_HOST;
+  int lanes_opt = 0;      // 0 = auto
+  int threads_opt = 1;
+  int device = 0;
+  int pq_mode = 0;        // 0 auto (pivot-stationary if possible), 1 force LUT path
+  int timing = 0;
+  int check_every = 4;    // device-graph mode: poll the active counter every N iterations
+  // index
+  bool loaded = false;
+  uint64_t medoid = 0, entry_len = 0;
+  uint32_t D = 0, R = 0, N = 0, m = 0;
+  const uint8_t* graph = nullptr;   // host
+  uint8_t* graph_owned = nullptr;
+  uint8_t* d_graph = nullptr;       // BANG_GRAPH_DEVICE
+  uint8_t* d_codes = nullptr;
+  bool codes_owned = false;
+  float* d_pivots_T = nullptr;      // [D][256]
+  float* d_pivots_packed = nullptr; // [mp][256][psz]
+  float* d_centroid = nullptr;
+  uint32_t* d_chunk_off = nullptr;
+  uint32_t* d_seed = nullptr;       // {count, MEDOID, adj(MEDOID)...}
+  uint8_t* d_medoid_vec = nullptr;
+  uint32_t psz = 0, mp = 0;
+  // search params
+  int k = 0, L = 0, distfn = BANG_DIST_L2;
+  bool params_set = false;
+  // per-alloc state
+  bool allocated = false;
+  bool inited = false;
+  int Qcap = 0;
+  int Qcur = 0;          // batch size of the running / last query (row stride of the vector log)
+  uint32_t cand_stride = 0;
+  void* d_queries = nullptr;
+  float* d_qc = nullptr;
+  float* d_lut = nullptr;
+  uint32_t* d_bloom = nullptr;
+  uint32_t* d_stage = nullptr;
+  uint32_t* d_nbrs = nullptr;
+  float* d_dist = nullptr;
+  uint32_t* d_cnt = nullptr;
+  uint32_t* d_wl_ids = nullptr;
+  float* d_wl_dist = nullptr;
+  uint8_t* d_wl_vis = nullptr;
+  uint32_t* d_wl_cnt = nullptr;
+  uint32_t* d_mark = nullptr;
+  uint32_t* d_parents_dev = nullptr;   // device-graph mode
+  uint32_t* h_parents = nullptr;       // mapped pinned (host-graph mode)
+  uint32_t* d_parents_map = nullptr;   // device alias of h_parents
+  uint32_t* d_cand_ids = nullptr;
+  uint32_t* d_cand_row = nullptr;
+  uint32_t* d_cand_cnt = nullptr;
+  uint32_t* d_active = nullptr;        // [L+50 + 2] per-iteration active counters (device-graph mode)
+  unsigned long long* d_evals = nullptr;
+  uint8_t* d_fp = nullptr;             // [(L+50)][Q][vec_bytes] vector log (host-graph mode)
+  uint8_t* h_fp = nullptr;             // pinned mirror
+  uint32_t* h_stage = nullptr;         // pinned [Q][65]
+  uint64_t* d_ids_out = nullptr;
+  float* d_dists_out = nullptr;
+  std::vector<Lane> lanes;
+  bang_stats stats{};
+};
+
+namespace {
+
+size_t vec_bytes(const bang_engine* e) { return (size_t)e->D * e->tsize; }
+
+int ensure_device(bang_engine* e) {
+  if (bang_device_count() == 0) {
+    bang_set_error("no HIP device visible: libbang has no CPU fallback");
+    return BANG_ERR_NOGPU;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  return BANG_OK;
+}
+
+template <typename T>
+int dmalloc(T** p, size_t count) {
+  HIP_TRY(hipMalloc((void**)p, std::max<size_t>(count * sizeof(T), 16)));
+  return BANG_OK;
+}
+template <typename T>
+void dfree(T*& p) {
+  if (p) (void)hipFree((void*)p);
+  p = nullptr;
+}
+
+int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext, const float* pivots,
+                 const float* centroid, const uint32_t* chunk_off) {
+  const uint32_t D = e->D, m = e->m;
+  if (e->R == 0 || e->R > BANG_MAX_R) {             // assert(R == MAX_R), bang_search.cu:190 (relaxed to R <= 64)
+    bang_set_error("graph degree bound R=%u unsupported (max %d)", e->R, BANG_MAX_R);
+    return BANG_ERR_UNSUPPORTED;
+  }
+  if (e->entry_len < (uint64_t)D * e->tsize + 4 + 4ull * e->R) {
+    bang_set_error("index entry length %llu too small for D=%u R=%u", (unsigned long long)e->entry_len, D, e->R);
+    return BANG_ERR_IO;
+  }
+  if (e->medoid >= e->N) { bang_set_error("medoid out of range"); return BANG_ERR_IO; }
+  // PQ codes (+256 B slack: the distance kernel over-reads up to 19 B past a row)
+  const size_t code_bytes = (size_t)e->N * m;
+  if (d_codes_ext) {
+    e->d_codes = (uint8_t*)d_codes_ext;
+    e->codes_owned = false;
+  } else {
+    HIP_TRY(hipMalloc((void**)&e->d_codes, code_bytes + 256));
+    e->codes_owned = true;
+    HIP_TRY(hipMemset(e->d_codes + code_bytes, 0, 256));
+    const size_t step = (size_t)1 << 30;
+    for (size_t off = 0; off < code_bytes; off += step)
+      HIP_TRY(hipMemcpy(e->d_codes + off, h_codes + off, std::min(step, code_bytes - off), hipMemcpyHostToDevice));
+  }
+  // pivots: transposed [D][256] for K1 (bang_search.cu:281-285) and chunk-packed for the LDS kernel
+  std::vector<float> pt((size_t)D * 256);
+  for (uint32_t row = 0; row < 256; ++row)
+    for (uint32_t col = 0; col < D; ++col) pt[(size_t)col * 256 + row] = pivots[(size_t)row * D + col];
+  BANG_TRY(dmalloc(&e->d_pivots_T, pt.size()));
+  HIP_TRY(hipMemcpy(e->d_pivots_T, pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
+  BANG_TRY(dmalloc(&e->d_centroid, D));
+  HIP_TRY(hipMemcpy(e->d_centroid, centroid, (size_t)D * 4, hipMemcpyHostToDevice));
+  BANG_TRY(dmalloc(&e->d_chunk_off, m + 1));
+  HIP_TRY(hipMemcpy(e->d_chunk_off, chunk_off, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
+  uint32_t psz = 0, mp = m;
+  BANG_TRY(bang_pq_layout(chunk_off, D, m, &psz, &mp));
+  if (e->pq_mode == 1) { psz = 0; mp = m; }
+  e->psz = psz;
+  e->mp = mp;
+  if (psz) {
+    std::vector<float> packed((size_t)mp * 256 * psz);
+    BANG_TRY(bang_pack_pivots(pivots, chunk_off, D, m, psz, mp, packed.data()));
+    BANG_TRY(dmalloc(&e->d_pivots_packed, packed.size()));
+    HIP_TRY(hipMemcpy(e->d_pivots_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  }
+  // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501)
+  const uint8_t* me = e->graph + e->medoid * e->entry_len;
+  uint32_t deg;
+  memcpy(&deg, me + vec_bytes(e), 4);
+  if (deg > e->R) deg = e->R;
+  std::vector<uint32_t> seed(2 + BANG_MAX_R + 1, 0);
+  seed[0] = deg + 1;
+  seed[1] = (uint32_t)e->medoid;
+  memcpy(&seed[2], me + vec_bytes(e) + 4, (size_t)deg * 4);
+  BANG_TRY(dmalloc(&e->d_seed, seed.size()));
+  HIP_TRY(hipMemcpy(e->d_seed, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&e->d_medoid_vec, (vec_bytes(e) + 15) & ~(size_t)15));
+  HIP_TRY(hipMemcpy(e->d_medoid_vec, me, vec_bytes(e), hipMemcpyHostToDevice));
+  if (e->graph_mode == BANG_GRAPH_DEVICE) {
+    const size_t gbytes = (size_t)e->N * e->entry_len;
+    HIP_TRY(hipMalloc((void**)&e->d_graph, gbytes + 256));
+    const size_t step = (size_t)1 << 30;
+    for (size_t off = 0; off < gbytes; off += step)
+      HIP_TRY(hipMemcpy(e->d_graph + off, e->graph + off, std::min(step, gbytes - off), hipMemcpyHostToDevice));
+  }
+  e->loaded = true;
+  return BANG_OK;
+}
+
+void unload_index(bang_engine* e) {
+  if (e->codes_owned) dfree(e->d_codes);
+  e->d_codes = nullptr;
+  dfree(e->d_pivots_T);
+  dfree(e->d_pivots_packed);
+  dfree(e->d_centroid);
+  dfree(e->d_chunk_off);
+  dfree(e->d_seed);
+  dfree(e->d_medoid_vec);
+  dfree(e->d_graph);
+  free(e->graph_owned);
+  e->graph_owned = nullptr;
+  e->graph = nullptr;
+  e->loaded = false;
+}
+
+void free_batch(bang_engine* e) {
+  for (Lane& ln : e->lanes) {
+    if (ln.s_main) (void)hipStreamDestroy(ln.s_main);
+    if (ln.s_fp) (void)hipStreamDestroy(ln.s_fp);
+    if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
+    if (ln.ev_fp) (void)hipEventDestroy(ln.ev_fp);
+    for (hipEvent_t ev : ln.tev) if (ev) (void)hipEventDestroy(ev);
+  }
+  e->lanes.clear();
+  dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_stage); dfree(e->d_nbrs);
+  dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
+  dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
+  dfree(e->d_active); dfree(e->d_evals); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
+  if (e->h_parents) (void)hipHostFree(e->h_parents);
+  if (e->h_fp) (void)hipHostFree(e->h_fp);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  e->h_parents = nullptr; e->d_parents_map = nullptr; e->h_fp = nullptr; e->h_stage = nullptr;
+  e->allocated = false;
+  e->inited = false;
+}
+
+// ---- file loading (bang_search.cu:138-362) ----
+bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+
+int load_files(bang_engine* e, const char* prefix) {
+  const std::string p(prefix);
+  const std::string f_piv = p + "_pq_pivots.bin", f_cmp = p + "_pq_compressed.bin", f_graph = p + "_disk.bin",
+                    f_meta = p + "_disk_metadata.bin";                       // suffixes :39-45
+  FILE* fp = fopen(f_piv.c_str(), "rb");
+  if (!fp) { printf("Error.. Could not open the PQ Pivots File: %s\n", f_piv.c_str()); bang_set_error("cannot open %s", f_piv.c_str()); return BANG_ERR_IO; }
+  FILE* fc = fopen(f_cmp.c_str(), "rb");
+  if (!fc) { fclose(fp); printf("Error.. Could not open the PQ Compressed Vectors File: %s\n", f_cmp.c_str()); bang_set_error("cannot open %s", f_cmp.c_str()); return BANG_ERR_IO; }
+  FILE* fg = fopen(f_graph.c_str(), "rb");
+  if (!fg) { fclose(fp); fclose(fc); printf("Error.. Could not open the Graph Index File: %s\n", f_graph.c_str()); bang_set_error("cannot open %s", f_graph.c_str()); return BANG_ERR_IO; }
+  FILE* fm = fopen(f_meta.c_str(), "rb");
+  if (!fm) { fclose(fp); fclose(fc); fclose(fg); printf("Error.. Could not open the Metadata File: %s\n", f_meta.c_str()); bang_set_error("cannot open %s", f_meta.c_str()); return BANG_ERR_IO; }
+  int rc = BANG_OK;
+  std::vector<uint8_t> codes;
+  std::vector<float> pivots, centroid;
+  std::vector<uint32_t> chunk_off;
+  do {
+    // 32-byte packed metadata {u64 medoid, u64 entryLen, i32 dtype, u32 D, u32 R, u32 N} (bang_search.cuh:42-50)
+    uint8_t md[32];
+    if (!read_exact(fm, md, 32)) { bang_set_error("short metadata file"); rc = BANG_ERR_IO; break; }
+    memcpy(&e->medoid, md, 8);
+    memcpy(&e->entry_len, md + 8, 8);
+    memcpy(&e->D, md + 20, 4);
+    memcpy(&e->R, md + 24, 4);
+    memcpy(&e->N, md + 28, 4);
+    // compressed vectors {i32 N, i32 m, u8[N][m]} (:218-234)
+    int32_t n_pts = 0, n_chunks = 0;
+    if (!read_exact(fc, &n_pts, 4) || !read_exact(fc, &n_chunks, 4) || n_pts <= 0 || n_chunks <= 0) {
+      bang_set_error("bad compressed-vector header"); rc = BANG_ERR_IO; break;
+    }
+    if ((uint32_t)n_pts != e->N) { bang_set_error("N mismatch: metadata %u vs compressed %d", e->N, n_pts); rc = BANG_ERR_IO; break; }
+    e->m = (uint32_t)n_chunks;
+    codes.resize((size_t)n_pts * n_chunks);
+    if (!read_exact(fc, codes.data(), codes.size())) { bang_set_error("short compressed-vector file"); rc = BANG_ERR_IO; break; }
+    // pivots file: section table then {rows, cols} + data at every offset (:246-296)
+    uint32_t nsec = 0;
+    if (!read_exact(fp, &nsec, 4) || nsec != 4) {
+      printf("Error.. PQ Pivots File does not contain the required # of sub-sections:\n");
+      bang_set_error("pivots file: bad section count"); rc = BANG_ERR_IO; break;
+    }
+    uint64_t offs[4];
+    fseek(fp, 8, SEEK_SET);
+    if (!read_exact(fp, offs, 32)) { bang_set_error("pivots file: short header"); rc = BANG_ERR_IO; break; }
+    pivots.resize((size_t)256 * e->D);
+    centroid.resize(e->D);
+    chunk_off.resize(e->m + 1);
+    fseek(fp, (long)offs[0] + 8, SEEK_SET);
+    bool ok = read_exact(fp, pivots.data(), pivots.size() * 4);
+    fseek(fp, (long)offs[1] + 8, SEEK_SET);
+    ok = ok && read_exact(fp, centroid.data(), centroid.size() * 4);
+    fseek(fp, (long)offs[2] + 8, SEEK_SET);
+    ok = ok && read_exact(fp, chunk_off.data(), chunk_off.size() * 4);
+    if (!ok) { bang_set_error("pivots file: short section"); rc = BANG_ERR_IO; break; }
+    // graph + full-precision vectors into host RAM (:312-328)
+    fseek(fg, 0, SEEK_END);
+    const size_t gsize = (size_t)ftell(fg);
+    fseek(fg, 0, SEEK_SET);
+    if (gsize < (size_t)e->N * e->entry_len) { bang_set_error("graph file too small"); rc = BANG_ERR_IO; break; }
+    e->graph_owned = (uint8_t*)malloc(gsize);
+    if (!e->graph_owned) { printf("Error.. Malloc failed for Graph Index.\n"); bang_set_error("malloc(%zu) failed", gsize); rc = BANG_ERR_NOMEM; break; }
+    if (!read_exact(fg, e->graph_owned, gsize)) { bang_set_error("short graph file"); rc = BANG_ERR_IO; break; }
+    e->graph = e->graph_owned;
+  } while (0);
+  fclose(fp); fclose(fc); fclose(fg); fclose(fm);
+  if (rc != BANG_OK) { free(e->graph_owned); e->graph_owned = nullptr; e->graph = nullptr; return rc; }
+  rc = upload_index(e, codes.data(), nullptr, pivots.data(), centroid.data(), chunk_off.data());
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+// ------------------------------------------------------------------ the search loop of one lane
+struct LaneCtx {
+  bang_engine* e;
+  Lane* ln;
+  bang_iter_params p;   // pointers already offset to the lane's first query
+};
+
+void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
+  const size_t q0 = ln.q0;
+  memset(&p, 0, sizeof(p));
+  p.Q = ln.nq; p.R = e->R; p.m = e->m; p.L = (uint32_t)e->L; p.medoid = (uint32_t)e->medoid;
+  p.psz = e->psz; p.mp = e->mp;
+  p.d_stage = e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr;
+  p.d_seed = e->d_seed;
+  p.d_codes = e->d_codes;
+  p.d_pivots_packed = e->d_pivots_packed;
+  p.d_qc = e->d_qc ? e->d_qc + q0 * e->mp * e->psz : nullptr;
+  p.d_lut = e->d_lut ? e->d_lut + q0 * e->m * 256 : nullptr;
+  p.d_graph = (e->graph_mode == BANG_GRAPH_DEVICE) ? e->d_graph : nullptr;
+  p.entry_len = e->entry_len;
+  p.vec_bytes = (uint32_t)vec_bytes(e);
+  p.d_bloom = e->d_bloom + q0 * BANG_BF_WORDS;
+  p.d_nbrs = e->d_nbrs + q0 * BANG_NBR_STRIDE;
+  p.d_dist = e->d_dist + q0 * BANG_NBR_STRIDE;
+  p.d_cnt = e->d_cnt + q0;
+  p.d_wl_ids = e->d_wl_ids + q0 * e->L;
+  p.d_wl_dist = e->d_wl_dist + q0 * e->L;
+  p.d_wl_vis = e->d_wl_vis + q0 * e->L;
+  p.d_wl_cnt = e->d_wl_cnt + q0;
+  p.d_mark = e->d_mark + q0;
+  p.d_parents = (e->graph_mode == BANG_GRAPH_DEVICE ? e->d_parents_dev : e->d_parents_map) + q0;
+  p.d_cand_ids = e->d_cand_ids + q0 * e->cand_stride;
+  p.d_cand_row = e->d_cand_row ? e->d_cand_row + q0 * e->cand_stride : nullptr;
+  p.d_cand_cnt = e->d_cand_cnt + q0;
+  p.d_active = nullptr;
+  p.d_evals = e->d_evals;
+}
+
+hipEvent_t timing_begin(bang_engine* e, Lane& ln, int kind) {
+  if (!e->timing || ln.tev_used + 2 > ln.tev.size()) return nullptr;
+  hipEvent_t a = ln.tev[ln.tev_used];
+  ln.tev_kind[ln.tev_used / 2] = kind;
+  (void)hipEventRecord(a, ln.s_main);
+  return a;
+}
+void timing_end(bang_engine* e, Lane& ln, hipEvent_t a) {
+  if (!a) return;
+  (void)hipEventRecord(ln.tev[ln.tev_used + 1], ln.s_main);
+  ln.tev_used += 2;
+  (void)e;
+}
+
+// Host graph walker for one lane and one iteration (bang_search.cu:771-813): for every query with a
+// parent copy the parent's full-precision vector into the vector log row `row` and its adjacency
+// list into the staging row.  Returns the number of queries that are still active.
+uint32_t walk(bang_engine* e, const Lane& ln, uint32_t row, bool adjacency, uint32_t* n_parents) {
+  const size_t vb = vec_bytes(e);
+  const uint64_t elen = e->entry_len;
+  const uint8_t* graph = e->graph;
+  const uint32_t* parents = e->h_parents + ln.q0;
+  uint32_t* stage = e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE;
+  uint8_t* fp_row = e->h_fp + ((size_t)row * e->Qcur + ln.q0) * vb;
+  const uint32_t R = e->R;
+  uint32_t active = 0, np = 0;
+  const uint32_t PF = 8;
+  for (uint32_t i = 0; i < ln.nq && i < PF; ++i) {
+    const uint32_t par = parents[i];
+    if (par < BANG_IDLE_PARENT) {
+      const uint8_t* ent = graph + (uint64_t)par * elen;
+      for (uint64_t o = 0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+    }
+  }
+  for (uint32_t i = 0; i < ln.nq; ++i) {
+    if (i + PF < ln.nq) {
+      const uint32_t par = parents[i + PF];
+      if (par < BANG_IDLE_PARENT) {
+        const uint8_t* ent = graph + (uint64_t)par * elen;
+        for (uint64_t o = 0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+      }
+    }
+    const uint32_t par = parents[i];
+    uint32_t* srow = stage + (size_t)i * BANG_STAGE_STRIDE;
+    if (par < BANG_IDLE_PARENT) {
+      const uint8_t* ent = graph + (uint64_t)par * elen;
+      memcpy(fp_row + (size_t)i * vb, ent, vb);                       // :796-798
+      if (adjacency) {
+        uint32_t deg;
+        memcpy(&deg, ent + vb, 4);                                    // :801
+        if (deg > R) deg = R;
+        srow[0] = deg;
+        memcpy(srow + 1, ent + vb + 4, (size_t)deg * 4);              // :809-810
+      }
+      ++active;
+      ++np;
+    } else {
+      if (adjacency) srow[0] = 0;                                     // memset(numNeighbors_query) :761
+      if (par == BANG_IDLE_PARENT) ++active;
+    }
+  }
+  *n_parents = np;
+  return active;
+}
+
+#define LANE_HIP(x)                                                                               \
+  do {                                                                                            \
+    hipError_t _e = (x);                                                                          \
+    if (_e != hipSuccess) {                                                                       \
+      bang_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__);     \
+      return BANG_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, float* h_dists, int Q) {
+  LANE_HIP(hipSetDevice(e->device));
+  const bool dev_graph = (e->graph_mode == BANG_GRAPH_DEVICE);
+  const uint32_t dim_adjust = (e->distfn == BANG_DIST_MIPS) ? 1u : 0u;      // :631
+  const size_t qdim = e->D - dim_adjust;
+  const size_t qbytes = qdim * e->tsize;
+  const size_t vb = vec_bytes(e);
+  const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
+  ln.tev_used = 0;
+  ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0;
+  bang_iter_params p;
+  fill_params(e, ln, p);
+
+  // queries H2D (:612) + K1 (:623)
+  uint8_t* dq = (uint8_t*)e->d_queries + (size_t)ln.q0 * qbytes;
+  LANE_HIP(hipMemcpyAsync(dq, (const uint8_t*)h_queries + (size_t)ln.q0 * qbytes, (size_t)ln.nq * qbytes,
+                          hipMemcpyHostToDevice, ln.s_main));
+  if (e->psz)
+    BANG_TRY(bang_k_center_queries(dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_qc, ln.nq, e->D, e->m,
+                                   e->mp, e->psz, dim_adjust, ln.s_main));
+  else
+    BANG_TRY(bang_k_lut_build(e->d_pivots_T, dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_lut, ln.nq,
+                              e->D, e->m, dim_adjust, ln.s_main));
+
+  uint32_t iter = 1;                                                         // :596
+  p.first = 1; p.iter = iter;
+  if (dev_graph) p.d_active = e->d_active + iter;
+  {
+    hipEvent_t t = timing_begin(e, ln, 0);
+    BANG_TRY(bang_k_front(&p, ln.s_main));                                   // K5+K2+K4a :650-678
+    timing_end(e, ln, t);
+    ++ln.front_launches;
+  }
+  if (!dev_graph) LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
+
+  bool fp_pending = false;
+  for (;;) {
+    p.first = 0; p.iter = iter;
+    {
+      hipEvent_t t = timing_begin(e, ln, 1);
+      BANG_TRY(bang_k_back(&p, ln.s_main));                                  // K3a+K3b :726-738 (overlaps the walker)
+      timing_end(e, ln, t);
+    }
+    if (!dev_graph) {
+      LANE_HIP(hipEventSynchronize(ln.ev_front));                            // parents of this iteration are in h_parents
+      const auto t0 = Clock::now();
+      uint32_t n_par = 0;
+      const uint32_t active = walk(e, ln, iter, true, &n_par);               // CPU walker :771-813
+      ln.walker_ms += ms_since(t0);
+      if (active == 0) break;                                                // :958
+      LANE_HIP(hipMemcpyAsync((void*)p.d_stage, e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
+                              (size_t)ln.nq * BANG_STAGE_STRIDE * 4, hipMemcpyHostToDevice, ln.s_main));   // :827-833
+      if (n_par) {
+        const size_t off = ((size_t)iter * e->Qcur + ln.q0) * vb;
+        LANE_HIP(hipMemcpyAsync(e->d_fp + off, e->h_fp + off, (size_t)ln.nq * vb, hipMemcpyHostToDevice, ln.s_fp)); // :836-838
+        fp_pending = true;
+      }
+    }
+    ++iter;                                                                  // :879
+    p.iter = iter;
+    if (dev_graph) p.d_active = e->d_active + iter;
+    {
+      hipEvent_t t = timing_begin(e, ln, 0);
+      BANG_TRY(bang_k_front(&p, ln.s_main));                                 // K5+K2+K4b :855-917
+      timing_end(e, ln, t);
+      ++ln.front_launches;
+    }
+    if (!dev_graph) {
+      LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
+      if (iter == cap_iter) {                                                // :950-956
+        // CANON: the vectors of the parents chosen at the cap are still fetched for the re-rank
+        LANE_HIP(hipEventSynchronize(ln.ev_front));
+        uint32_t n_par = 0;
+        (void)walk(e, ln, iter, false, &n_par);
+        if (n_par) {
+          const size_t off = ((size_t)iter * e->Qcur + ln.q0) * vb;
+          LANE_HIP(hipMemcpyAsync(e->d_fp + off, e->h_fp + off, (size_t)ln.nq * vb, hipMemcpyHostToDevice, ln.s_fp));
+          fp_pending = true;
+        }
+        break;
+      }
+    } else {
+      if (iter == cap_iter) break;
+      if ((iter % (uint32_t)e->check_every) == 0) {                          // :942-943 (amortised)
+        uint32_t act = 0;
+        LANE_HIP(hipMemcpyAsync(&act, e->d_active + iter, 4, hipMemcpyDeviceToHost, ln.s_main));
+        LANE_HIP(hipStreamSynchronize(ln.s_main));
+        if (act == 0) break;
+      }
+    }
+  }
+  ln.iterations = iter;
+
+  // re-rank K6+K7 (:967-987)
+  if (fp_pending) {
+    LANE_HIP(hipEventRecord(ln.ev_fp, ln.s_fp));
+    LANE_HIP(hipStreamWaitEvent(ln.s_main, ln.ev_fp, 0));
+  }
+  {
+    hipEvent_t t = timing_begin(e, ln, 2);
+    if (dev_graph)
+      BANG_TRY(bang_k_rerank_range(e->d_graph, e->entry_len, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids,
+                                   nullptr, e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D,
+                                   (uint32_t)e->k, dim_adjust, e->d_ids_out, e->d_dists_out, ln.s_main));
+    else
+      BANG_TRY(bang_k_rerank_range(e->d_fp, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, e->d_cand_row,
+                                   e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k,
+                                   dim_adjust, e->d_ids_out, e->d_dists_out, ln.s_main));
+    timing_end(e, ln, t);
+  }
+  // results D2H (:997-999): ids [Q][k]; dists [k][Q] (rank-major)
+  LANE_HIP(hipMemcpyAsync(h_ids + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k,
+                          (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
+  LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
+                            (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
+  LANE_HIP(hipStreamSynchronize(ln.s_main));
+  ln.front_ms = ln.back_ms = ln.rerank_ms = 0;
+  for (size_t i = 0; i + 1 < ln.tev_used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ln.tev[i], ln.tev[i + 1]) == hipSuccess) {
+      const int kind = ln.tev_kind[i / 2];
+      (kind == 0 ? ln.front_ms : kind == 1 ? ln.back_ms : ln.rerank_ms) += ms;
+    }
+  }
+  return BANG_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C-ABI, engine level
+extern "C" int bang_create(int dtype, bang_engine_t** out) {
+  if (!out || dtype < BANG_U8 || dtype > BANG_F32) { bang_set_error("bad dtype"); return BANG_ERR_ARG; }
+  bang_engine* e = new (std::nothrow) bang_engine();
+  if (!e) return BANG_ERR_NOMEM;
+  e->dtype = dtype;
+  e->tsize = (dtype == BANG_F32) ? 4 : 1;
+  // defaults from the environment so that callers of the bang.h class API (no option methods,
+  // e.g. the bang_search CLI) can still choose the placement: BANG_GRAPH=host|device,
+  // BANG_LANES=n, BANG_DEVICE=ordinal, BANG_PQ=0|1, BANG_TIMING=0|1
+  if (const char* v = getenv("BANG_GRAPH")) e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
+  if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
+  if (const char* v = getenv("BANG_DEVICE")) e->device = atoi(v);
+  if (const char* v = getenv("BANG_PQ")) e->pq_mode = atoi(v);
+  if (const char* v = getenv("BANG_TIMING")) e->timing = atoi(v);
+  *out = e;
+  return BANG_OK;
+}
+
+extern "C" int bang_destroy(bang_engine_t* e) {
+  if (!e) return BANG_OK;
+  if (e->allocated) free_batch(e);
+  if (e->loaded) unload_index(e);
+  delete e;
+  return BANG_OK;
+}
+
+extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
+  if (!e || !key) return BANG_ERR_ARG;
+  const std::string k(key);
+  if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE) return BANG_ERR_ARG; e->graph_mode = (int)value; }
+  else if (k == "lanes") { if (value < 0 || value > 256) return BANG_ERR_ARG; e->lanes_opt = (int)value; }
+  else if (k == "threads") { if (value < 1) return BANG_ERR_ARG; e->threads_opt = (int)value; }
+  else if (k == "device") { e->device = (int)value; }
+  else if (k == "pq") { e->pq_mode = (int)value; }
+  else if (k == "timing") { e->timing = (int)value; }
+  else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
+  else { bang_set_error("unknown option %s", key); return BANG_ERR_ARG; }
+  return BANG_OK;
+}
+
+extern "C" int bang_load_e(bang_engine_t* e, const char* prefix) {
+  if (!e || !prefix) return BANG_ERR_ARG;
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  return load_files(e, prefix);
+}
+
+extern "C" int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* d) {
+  if (!e || !d || !d->graph || !d->pivots || !d->centroid || !d->chunk_off || (!d->codes && !d->d_codes)) {
+    bang_set_error("bad index descriptor");
+    return BANG_ERR_ARG;
+  }
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
+  e->graph = d->graph;
+  e->graph_owned = nullptr;
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+extern "C" int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn) {
+  if (!e) return BANG_ERR_ARG;
+  if (recall <= 0 || worklist_length < recall || worklist_length > BANG_MAX_L ||            // assert(2L <= 1024) :439
+      (distfn != BANG_DIST_L2 && distfn != BANG_DIST_MIPS)) {
+    bang_set_error("bad search params: recall=%d L=%d distfn=%d", recall, worklist_length, distfn);
+    return BANG_ERR_ARG;
+  }
+  if (e->allocated && (recall != e->k || worklist_length != e->L)) {
+    bang_set_error("bang_free must be called before changing recall / worklist length");   // sizes depend on them :370-384
+    return BANG_ERR_ARG;
+  }
+  e->k = recall; e->L = worklist_length; e->distfn = distfn;
+  e->params_set = true;
+  return BANG_OK;
+}
+
+static int alloc_buffers(bang_engine* e, int Q) {
+  const size_t L = (size_t)e->L, nq = (size_t)Q;
+  const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
+  const size_t vb = vec_bytes(e);
+  const bool dev_graph = (e->graph_mode == BANG_GRAPH_DEVICE);
+  HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
+  if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));
+  else BANG_TRY(dmalloc(&e->d_lut, nq * e->m * 256));                       // :380
+  BANG_TRY(dmalloc(&e->d_bloom, nq * BANG_BF_WORDS));                        // :393 (bit-packed: 8x smaller)
+  BANG_TRY(dmalloc(&e->d_nbrs, nq * BANG_NBR_STRIDE));
+  BANG_TRY(dmalloc(&e->d_dist, nq * BANG_NBR_STRIDE));
+  BANG_TRY(dmalloc(&e->d_cnt, nq));
+  BANG_TRY(dmalloc(&e->d_wl_ids, nq * L));
+  BANG_TRY(dmalloc(&e->d_wl_dist, nq * L));
+  BANG_TRY(dmalloc(&e->d_wl_vis, nq * L));
+  BANG_TRY(dmalloc(&e->d_wl_cnt, nq));
+  BANG_TRY(dmalloc(&e->d_mark, nq));
+  BANG_TRY(dmalloc(&e->d_cand_ids, nq * rows));
+  BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
+  BANG_TRY(dmalloc(&e->d_evals, 2));
+  BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
+  BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
+  if (dev_graph) {
+    BANG_TRY(dmalloc(&e->d_parents_dev, nq));
+    BANG_TRY(dmalloc(&e->d_active, rows + 2));
+  } else {
+    BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
+    BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
+    HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                    // :398
+    HIP_TRY(hipHostMalloc((void**)&e->h_parents, nq * 4, hipHostMallocMapped));              // :419
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
+    HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocDefault));     // :416
+    HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
+  }
+  int nl = e->lanes_opt;
+  if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(8, Q / 512));
+  nl = std::min(nl, Q);
+  e->lanes.resize((size_t)nl);
+  for (int i = 0; i < nl; ++i) {
+    Lane& ln = e->lanes[(size_t)i];
+    HIP_TRY(hipStreamCreateWithFlags(&ln.s_main, hipStreamNonBlocking));     // :407-410
+    HIP_TRY(hipStreamCreateWithFlags(&ln.s_fp, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ln.ev_fp, hipEventDisableTiming));
+    if (e->timing) {
+      ln.tev.assign(2 * (2 * rows + 4), nullptr);
+      ln.tev_kind.assign(ln.tev.size() / 2, 0);
+      for (hipEvent_t& ev : ln.tev) HIP_TRY(hipEventCreate(&ev));
+    }
+  }
+  return BANG_OK;
+}
+
+extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
+  if (!e || Q <= 0) return BANG_ERR_ARG;
+  if (!e->loaded || !e->params_set) { bang_set_error("bang_alloc: load an index and set search params first"); return BANG_ERR_ARG; }
+  if (e->allocated) { bang_set_error("bang_alloc: already allocated (call bang_free)"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->Qcap = Q;
+  e->Qcur = 0;
+  e->cand_stride = (uint32_t)e->L + BANG_EXTRA_ITERS;
+  const int rc = alloc_buffers(e, Q);
+  if (rc != BANG_OK) { free_batch(e); return rc; }
+  e->allocated = true;
+  e->inited = false;
+  return BANG_OK;
+}
+
+extern "C" int bang_init_e(bang_engine_t* e, int Q) {
+  if (!e || !e->allocated || Q <= 0 || Q > e->Qcap) { bang_set_error("bang_init: bad state / numQueries"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  const size_t nq = (size_t)Q;
+  HIP_TRY(hipMemsetAsync(e->d_bloom, 0, nq * BANG_BF_WORDS * 4, nullptr));                  // :443
+  HIP_TRY(hipMemsetAsync(e->d_evals, 0, 16, nullptr));
+  if (e->d_active) HIP_TRY(hipMemsetAsync(e->d_active, 0, ((size_t)e->cand_stride + 2) * 4, nullptr));
+  BANG_TRY(bang_k_init_state((uint32_t)Q, (uint32_t)e->medoid, e->cand_stride, e->d_cand_ids, e->d_cand_row, e->d_cand_cnt,
+                             e->d_wl_cnt, e->d_mark, e->d_parents_dev, e->d_cnt, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->h_parents) for (size_t i = 0; i < nq; ++i) e->h_parents[i] = BANG_NO_PARENT;
+  e->inited = true;
+  return BANG_OK;
+}
+
+extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists) {
+  if (!e || !h_queries || !h_ids || !h_dists) return BANG_ERR_ARG;
+  if (!e->allocated || !e->inited) { bang_set_error("bang_query: bang_alloc + bang_init must precede every query"); return BANG_ERR_ARG; }
+  if (Q <= 0 || Q > e->Qcap) { bang_set_error("bang_query: numQueries %d exceeds allocation %d", Q, e->Qcap); return BANG_ERR_ARG; }
+  e->inited = false;   // state is consumed
+  e->Qcur = Q;
+  const auto t0 = Clock::now();
+  // lanes were laid out for Qcap; re-slice for this Q
+  const int nl = (int)e->lanes.size();
+  for (int i = 0; i < nl; ++i) {
+    Lane& ln = e->lanes[(size_t)i];
+    ln.q0 = (uint32_t)((size_t)Q * i / nl);
+    ln.nq = (uint32_t)((size_t)Q * (i + 1) / nl) - ln.q0;
+  }
+  // NOTE: the vector log / dist output use row stride Qcap / Q respectively; log rows use Qcap.
+  std::vector<std::thread> th;
+  auto body = [&](Lane* ln) {
+    if (ln->nq == 0) { ln->rc = BANG_OK; return; }
+    ln->rc = lane_run(e, *ln, h_queries, h_ids, h_dists, Q);
+    if (ln->rc != BANG_OK) ln->err = bang_last_error();
+  };
+  for (int i = 1; i < nl; ++i) th.emplace_back(body, &e->lanes[(size_t)i]);
+  body(&e->lanes[0]);
+  for (auto& t : th) t.join();
+  int rc = BANG_OK;
+  for (Lane& ln : e->lanes)
+    if (ln.rc != BANG_OK) { rc = ln.rc; bang_set_error("%s", ln.err.c_str()); break; }
+  // stats
+  bang_stats& s = e->stats;
+  memset(&s, 0, sizeof(s));
+  s.wall_ms = ms_since(t0);
+  for (Lane& ln : e->lanes) {
+    s.iterations = std::max<uint64_t>(s.iterations, ln.iterations);
+    s.front_launches += ln.front_launches;
+    s.front_ms += ln.front_ms; s.back_ms += ln.back_ms; s.rerank_ms += ln.rerank_ms; s.walker_ms += ln.walker_ms;
+  }
+  return rc;
+}
+
+extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
+  if (!e || !out) return BANG_ERR_ARG;
+  bang_stats& s = e->stats;
+  if (e->allocated && e->Qcur > 0 && s.candidates == 0) {   // device-side counters are fetched lazily
+    unsigned long long ev[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ev, e->d_evals, 16, hipMemcpyDeviceToHost));
+    s.dist_evals = ev[0];
+    s.fetched = ev[1];
+    std::vector<uint32_t> cc((size_t)e->Qcur);
+    HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t c : cc) s.candidates += c;
+  }
+  *out = s;
+  return BANG_OK;
+}
+
+extern "C" int bang_free_e(bang_engine_t* e) {
+  if (!e) return BANG_ERR_ARG;
+  if (e->allocated) { (void)hipSetDevice(e->device); free_batch(e); }
+  return BANG_OK;
+}
+
+extern "C" int bang_unload_e(bang_engine_t* e) {
+  if (!e) return BANG_ERR_ARG;
+  if (e->allocated) free_batch(e);
+  if (e->loaded) { (void)hipSetDevice(e->device); unload_index(e); }
+  return BANG_OK;
+}

@@ -1,0 +1,30 @@
+// bang_internal.h -- declarations shared by the kernel launchers and the host engine (not public).
+#ifndef BANG_INTERNAL_H_
+#define BANG_INTERNAL_H_
+
+#include <stdint.h>
+
+#include "bang_c.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// printf-style; stores a thread-local message returned by bang_last_error()
+void bang_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// bang_k_rerank on the sub-range [q0, q0+nq) of a batch of Q_total queries (one lane's share)
+int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries,
+                        int dtype, const uint32_t* d_cand_ids, const uint32_t* d_cand_row, const uint32_t* d_cand_cnt,
+                        uint32_t cand_stride, uint32_t q0, uint32_t nq, uint32_t Q_total, uint32_t D, uint32_t k,
+                        uint32_t dim_adjust, uint64_t* d_ids_out, float* d_dists_out, void* stream);
+
+// device side of bang_init: candidate log = [MEDOID], empty worklists, mark = 0x01010101
+int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_t* d_cand_ids, uint32_t* d_cand_row,
+                      uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

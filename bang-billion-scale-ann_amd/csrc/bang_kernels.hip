@@ -1,0 +1,871 @@
+// bang_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the BANG_Base search path
+// and their C-ABI launchers (include/bang_c.h, section 2).
+//
+// Design (DESIGN.md has the long version):
+//  * one WAVEFRONT per query.  R = 64 neighbours == 64 lanes, so the visited filter is a
+//    __ballot + popcount compaction, the parent pick is a shuffle reduce, the 65-element sort is
+//    an in-LDS rank sort and the worklist merge is a merge-path done by one wave -- no
+//    __syncthreads anywhere on the per-iteration path.
+//  * PQ distances are "pivot-stationary": the whole pivot table (chunk-packed, <= 152 KB) lives
+//    in the CU's 160 KB LDS and is shared by the 4..16 waves (= queries) of the workgroup; an
+//    LUT entry LUT[c][code] = sum_j (P[j][code] - qc[j])^2 is recomputed from it with exactly the
+//    float operations populate_pqDist_par uses, so the 0.3-0.7 GB per-batch LUT of the reference
+//    is never materialised or re-read.  HBM traffic of the distance stage = the code rows.
+//  * compiled with -ffp-contract=off; every fused multiply-add is an explicit fmaf so the float
+//    results equal the CPU oracle's bit for bit.
+//
+// Reference line numbers: /root/reference/BANG_Base/bang_search.cu.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bang_c.h"
+#include "bang_internal.h"
+
+#define WAVE 64
+#define BIG_DIST ((float)3.402823E+38)  // bang_search.cu:1406,1484
+
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef const float __attribute__((address_space(4))) * cfloat_p;  // constant AS: scalar loads
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash1(uint32_t x) {  // hashFn1_d :1168-1178
+  uint64_t h = 0xcbf29ce4ull;
+  h = (h ^ (uint64_t)(x & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 8) & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 16) & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 24) & 0xff)) * 0x01000193ull;
+  return (uint32_t)(h % BANG_BF_ENTRIES);
+}
+__device__ __forceinline__ uint32_t hash2(uint32_t x) {  // hashFn2_d :1180-1189
+  uint64_t h = 0x84222325ull;
+  h = (h ^ (uint64_t)(x & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 8) & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 16) & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 24) & 0xff)) * 0x1B3ull;
+  return (uint32_t)(h % BANG_BF_ENTRIES);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void wave_sync() {
+  // orders LDS traffic of ONE wave (program order + compiler fence); no cross-wave meaning
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of mask bits below my lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 core: distance of one neighbour (one lane) -- pivot-stationary form
+// ------------------------------------------------------------------------------------------
+// Canonical float order (bang_search.cu:1229-1239): eight partial sums
+// s_l = (((0 + t_l) + t_{l+8}) + ...), then ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)).
+// t_c = LUT[c][code_c] is recomputed as the fmaf chain of populate_pqDist_par (:1118-1128);
+// zero padding of a chunk to PSZ dims adds fmaf(0,0,t) == t, i.e. nothing.
+template <int PSZ>
+__device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, cfloat_p qc, uint32_t c, uint32_t code) {
+  const float* e = piv_lds + ((size_t)c * 256 + code) * PSZ;
+  float t = 0.0f;
+  if (PSZ == 1) {
+    const float d = e[0] - qc[c];
+    t = __builtin_fmaf(d, d, t);
+  } else if (PSZ == 2) {
+    const float2 p = *(const float2*)e;
+    const float d0 = p.x - qc[c * 2 + 0];
+    t = __builtin_fmaf(d0, d0, t);
+    const float d1 = p.y - qc[c * 2 + 1];
+    t = __builtin_fmaf(d1, d1, t);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PSZ; i += 4) {
+      const float4 p = *(const float4*)(e + i);
+      const float d0 = p.x - qc[c * PSZ + i + 0];
+      t = __builtin_fmaf(d0, d0, t);
+      const float d1 = p.y - qc[c * PSZ + i + 1];
+      t = __builtin_fmaf(d1, d1, t);
+      const float d2 = p.z - qc[c * PSZ + i + 2];
+      t = __builtin_fmaf(d2, d2, t);
+      const float d3 = p.w - qc[c * PSZ + i + 3];
+      t = __builtin_fmaf(d3, d3, t);
+    }
+  }
+  return t;
+}
+
+// NDW = number of code dwords per row after padding the chunk count to MP = 4*NDW (the padding
+// chunks are all-zero in the packed pivot table and in qc, so they add fmaf(0,0,0) = +0).
+// ALIGNED = (m % 4 == 0): rows start dword-aligned, no funnel shift needed.
+// The loop is straight-line (no guards) so the compiler can batch the LDS reads and scalar loads.
+template <int PSZ, int NDW, bool ALIGNED>
+__device__ __forceinline__ float pq_distance(const uint8_t* __restrict__ codes, uint32_t m, uint32_t id,
+                                             const float* __restrict__ piv_lds, cfloat_p qc) {
+  const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
+  const uint32_t sh = (uint32_t)a & 3u;
+  constexpr int NLOAD = ALIGNED ? NDW : NDW + 1;      // dwords needed from the aligned base
+  constexpr int NX4 = (NLOAD + 3) / 4;
+  const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
+  uint32_t w[NX4 * 4 + 1];
+#pragma unroll
+  for (int i = 0; i < NX4; ++i) {
+    const u32x4a v = p[i];
+    w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  w[NX4 * 4] = 0;
+  float s[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) {
+    const uint32_t dw = ALIGNED ? w[k] : __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t c = 4 * k + b;
+      const uint32_t code = (dw >> (8 * b)) & 0xffu;
+      const float t = lut_entry<PSZ>(piv_lds, qc, c, code);
+      s[c & 7] = s[c & 7] + t;
+    }
+  }
+  const float x = (s[0] + s[1]) + (s[2] + s[3]);
+  const float y = (s[4] + s[5]) + (s[6] + s[7]);
+  return x + y;
+}
+
+// LUT path (PSZ == 0): LUT[m][256] gathered from global memory as the reference does (:1236); any m.
+__device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ codes, uint32_t m, uint32_t id,
+                                                 const float* __restrict__ lut) {
+  const uint8_t* row = codes + (uint64_t)id * m;
+  float s[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = 0.0f;
+  uint32_t c = 0;
+  for (; c + 8 <= m; c += 8) {
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s[l] = s[l] + lut[(size_t)(c + l) * 256 + row[c + l]];
+  }
+#pragma unroll
+  for (int l = 0; l < 8; ++l)
+    if (c + l < m) s[l] = s[l] + lut[(size_t)(c + l) * 256 + row[c + l]];
+  const float x = (s[0] + s[1]) + (s[2] + s[3]);
+  const float y = (s[4] + s[5]) + (s[6] + s[7]);
+  return x + y;
+}
+
+// ------------------------------------------------------------------------------------------
+// front kernel: K5 filter -> K2 distances -> K4 parent, one wave per query
+// ------------------------------------------------------------------------------------------
+struct FrontArgs {
+  bang_iter_params p;
+  uint32_t stages;      // bit0 filter, bit1 distance, bit2 parent
+  uint32_t lds_piv_floats;
+};
+
+// per-wave LDS scratch (uint32 words): compacted ids [0..71]
+#define FRONT_SCRATCH_WORDS 72
+
+template <int PSZ, int NDW, bool ALIGNED>
+__global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const bang_iter_params& p = a.p;
+  float* piv_lds = lds;
+  uint32_t* scratch_all = (uint32_t*)(lds + a.lds_piv_floats);
+
+  if (PSZ > 0 && (a.stages & 2u)) {
+    // stage the chunk-packed pivot table (query independent) once per workgroup, 16 B per lane
+    const float4* src = (const float4*)p.d_pivots_packed;
+    float4* dst = (float4*)piv_lds;
+    const uint32_t n4 = a.lds_piv_floats >> 2;
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+
+  const int lane = lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t nwaves = blockDim.x >> 6;
+  uint32_t* scratch = scratch_all + wave * FRONT_SCRATCH_WORDS;
+  const uint32_t medoid = p.medoid;
+  unsigned long long ev_surv = 0, ev_fetch = 0;
+  uint32_t n_active = 0;
+
+  for (uint32_t q = blockIdx.x * nwaves + wave; q < p.Q; q += gridDim.x * nwaves) {
+    uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
+    float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
+    uint32_t n = 0;        // survivors
+    uint32_t sid0 = 0;     // lane's survivor id (index lane) ; sid1: survivor index 64 (lane 0 only)
+    uint32_t sid1 = 0;
+
+    // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
+    if (a.stages & 1u) {
+      const uint32_t* src;
+      uint32_t cnt_in;
+      if (p.first) {                       // seed list [MEDOID, adj(MEDOID)...], bang_init :467-489
+        cnt_in = p.d_seed[0];
+        src = p.d_seed + 1;
+      } else if (p.d_graph != nullptr) {   // graph resident in HBM: read the parent's adjacency here
+        const uint32_t par = p.d_parents[q];
+        if (par >= BANG_IDLE_PARENT) { cnt_in = 0; src = p.d_seed; }
+        else {
+          const uint32_t* e = (const uint32_t*)(p.d_graph + (uint64_t)par * p.entry_len + p.vec_bytes);
+          cnt_in = e[0];
+          if (cnt_in > p.R) cnt_in = p.R;
+          src = e + 1;
+        }
+      } else {                             // adjacency staged by the host walker :827-833
+        src = p.d_stage + (size_t)q * BANG_STAGE_STRIDE;
+        cnt_in = src[0];
+        if (cnt_in > p.R) cnt_in = p.R;
+        src += 1;
+      }
+      cnt_in = uni(cnt_in);
+      ev_fetch += cnt_in;
+      uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
+      // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
+      const bool v0 = (uint32_t)lane < cnt_in;
+      const bool v1 = (lane == 0) && (cnt_in > 64);
+      const uint32_t x0 = v0 ? src[lane] : 0u;
+      const uint32_t x1 = v1 ? src[64] : 0u;
+      uint32_t h0a = 0, h0b = 0, h1a = 0, h1b = 0;
+      bool pass0 = false, pass1 = false;
+      // CANON: every id is tested against the filter state at entry (all loads before any set)
+      if (v0) {
+        h0a = hash1(x0); h0b = hash2(x0);
+        const uint32_t wa = bloom[h0a >> 5], wb = bloom[h0b >> 5];
+        pass0 = !(((wa >> (h0a & 31)) & 1u) && ((wb >> (h0b & 31)) & 1u));
+      }
+      if (v1) {
+        h1a = hash1(x1); h1b = hash2(x1);
+        const uint32_t wa = bloom[h1a >> 5], wb = bloom[h1b >> 5];
+        pass1 = !(((wa >> (h1a & 31)) & 1u) && ((wb >> (h1b & 31)) & 1u));
+      }
+      const uint64_t m0 = __ballot(pass0);
+      const uint64_t m1 = __ballot(pass1);
+      if (pass0) { atomicOr(&bloom[h0a >> 5], 1u << (h0a & 31)); atomicOr(&bloom[h0b >> 5], 1u << (h0b & 31)); }
+      if (pass1) { atomicOr(&bloom[h1a >> 5], 1u << (h1a & 31)); atomicOr(&bloom[h1b >> 5], 1u << (h1b & 31)); }
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      n = n0 + (uint32_t)__popcll(m1);
+      // ordered compaction: survivors keep input order (CANON; reference uses atomicAdd order :1161)
+      if (pass0) scratch[lanes_below(m0)] = x0;
+      if (pass1) scratch[n0] = x1;
+      wave_sync();
+      if ((uint32_t)lane < n) { sid0 = scratch[lane]; nbrs[lane] = sid0; }
+      if (lane == 0 && n > 64) { sid1 = scratch[64]; nbrs[64] = sid1; }
+      if (lane == 0) p.d_cnt[q] = n;
+      wave_sync();
+    } else {
+      n = uni(p.d_cnt[q]);
+      if ((uint32_t)lane < n) sid0 = nbrs[lane];
+      if (lane == 0 && n > 64) sid1 = nbrs[64];
+    }
+    ev_surv += n;
+
+    // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
+    float d0 = BIG_DIST, d1 = BIG_DIST;
+    if (a.stages & 2u) {
+      cfloat_p qc = (cfloat_p)(uintptr_t)(PSZ > 0 ? p.d_qc + (size_t)q * (NDW * 4 * (PSZ > 0 ? PSZ : 1)) : nullptr);
+      const float* lut = (PSZ == 0) ? p.d_lut + (size_t)q * p.m * 256 : nullptr;
+      // pass 0: survivors 0..63 (one per lane); pass 1: survivor 64 (seed list only), lane 0
+      for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t id = base ? sid1 : sid0;
+        if (base + (uint32_t)lane < n) {
+          float d;
+          if constexpr (PSZ > 0) d = pq_distance<(PSZ > 0 ? PSZ : 1), NDW, ALIGNED>(p.d_codes, p.m, id, piv_lds, qc);
+          else d = pq_distance_lut(p.d_codes, p.m, id, lut);
+          dist[base + lane] = d;
+          if (base) d1 = d; else d0 = d;
+        }
+      }
+    } else if (a.stages & 4u) {
+      if ((uint32_t)lane < n) d0 = dist[lane];
+      if (lane == 0 && n > 64) d1 = dist[64];
+    }
+
+    // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ------
+    if (a.stages & 4u) {
+      // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
+      float bd = ((uint32_t)lane < n && sid0 != medoid) ? d0 : BIG_DIST;
+      uint32_t bi = ((uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST) ? (uint32_t)lane : 0xFFFFu;
+      uint32_t bid = sid0;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) {
+        const float od = __shfl_xor(bd, off);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+        const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
+        const bool take = (oi != 0xFFFFu) && (bi == 0xFFFFu || od < bd || (od == bd && oi < bi));
+        if (take) { bd = od; bi = oi; bid = oid; }
+      }
+      // element 64 (lane 0 of the second round) can only win with a strictly smaller distance
+      {
+        const float e_d = __shfl(d1, 0);
+        const uint32_t e_id = (uint32_t)__shfl((int)sid1, 0);
+        if (n > 64 && e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
+      }
+      const bool have_best = (bi != 0xFFFFu);
+      if (!have_best) bd = BIG_DIST;
+
+      bool found = false;
+      uint32_t parent = 0;
+      bool from_best = false;
+      uint32_t w_hit = 0;
+      if (p.first) {
+        if (have_best) { found = true; parent = bid; from_best = true; }
+      } else {
+        const uint32_t w_n = uni(p.d_wl_cnt[q]);
+        const uint8_t* vis = p.d_wl_vis + (size_t)q * p.L;
+        const float* wd = p.d_wl_dist + (size_t)q * p.L;
+        const uint32_t* wi = p.d_wl_ids + (size_t)q * p.L;
+        for (uint32_t base = 0; base < w_n; base += WAVE) {   // first unvisited entry :1425-1439
+          const uint32_t i = base + lane;
+          const bool unv = (i < w_n) && (vis[i] == 0);
+          const uint64_t mk = __ballot(unv);
+          if (mk) {
+            w_hit = base + (uint32_t)__builtin_ctzll(mk);
+            found = true;
+            break;
+          }
+        }
+        if (found) {
+          const float wdist = wd[w_hit];
+          if (bd < wdist) { parent = bid; from_best = true; }
+          else parent = wi[w_hit];
+        } else if (w_n > 0 && bd < wd[w_n - 1]) {            // corner case :1442-1446
+          found = true; parent = bid; from_best = true;
+        }
+      }
+      if (lane == 0) {
+        if (found) {
+          if (from_best) p.d_mark[q] = parent;
+          else p.d_wl_vis[(size_t)q * p.L + w_hit] = 1;
+          const uint32_t cc = p.d_cand_cnt[q];
+          p.d_cand_ids[(size_t)q * (p.L + BANG_EXTRA_ITERS) + cc] = parent;
+          if (p.d_cand_row) p.d_cand_row[(size_t)q * (p.L + BANG_EXTRA_ITERS) + cc] = p.iter;
+          p.d_cand_cnt[q] = cc + 1;
+          p.d_parents[q] = parent;
+        } else {
+          p.d_parents[q] = (n > 0) ? BANG_IDLE_PARENT : BANG_NO_PARENT;
+        }
+      }
+      if (found || n > 0) ++n_active;
+    }
+  }
+
+  if (lane == 0) {
+    if (p.d_active && n_active) atomicAdd(p.d_active, n_active);
+    if (p.d_evals && (ev_surv | ev_fetch)) {
+      atomicAdd(&p.d_evals[0], ev_surv);
+      atomicAdd(&p.d_evals[1], ev_fetch);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// back kernel: K3a stable sort of the survivors + K3b merge into the worklist, one wave per query
+// ------------------------------------------------------------------------------------------
+#define BACK_WAVES 4
+struct BackLds {
+  float sd[BANG_NBR_STRIDE];      // unsorted distances
+  uint32_t si[BANG_NBR_STRIDE];
+  float td[BANG_NBR_STRIDE];      // sorted
+  uint32_t ti[BANG_NBR_STRIDE];
+  float wd[BANG_MAX_L];
+  uint32_t wi[BANG_MAX_L];
+  uint8_t wv[BANG_MAX_L];
+};
+
+__device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target <= arr[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t hi, float target) {  // :1735-1749
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target >= arr[mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_params p) {
+  __shared__ BackLds lds_all[BACK_WAVES];
+  const int lane = lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  BackLds& s = lds_all[wave];
+  const uint32_t L = p.L;
+
+  for (uint32_t q = blockIdx.x * BACK_WAVES + wave; q < p.Q; q += gridDim.x * BACK_WAVES) {
+    const uint32_t n = uni(p.d_cnt[q]);
+    if (n == 0) continue;   // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
+    const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
+    const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
+    uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
+    float* wl_dist = p.d_wl_dist + (size_t)q * L;
+    uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
+    const uint32_t mark = p.d_mark[q];
+
+    for (uint32_t i = lane; i < n; i += WAVE) { s.sd[i] = dist[i]; s.si[i] = nbrs[i]; }
+    wave_sync();
+    // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
+    for (uint32_t i = lane; i < n; i += WAVE) {
+      const float d = s.sd[i];
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < n; ++j) {
+        const float o = s.sd[j];
+        r += (o < d || (o == d && j < i)) ? 1u : 0u;
+      }
+      s.td[r] = d;
+      s.ti[r] = s.si[i];
+    }
+    wave_sync();
+
+    uint32_t new_n;
+    if (p.iter == 1) {                                     // :1638-1649
+      new_n = n < L ? n : L;
+      for (uint32_t i = lane; i < new_n; i += WAVE) {
+        const uint32_t id = s.ti[i];
+        wl_ids[i] = id;
+        wl_dist[i] = s.td[i];
+        wl_vis[i] = (id == p.medoid || id == mark) ? 1 : 0;  // + mark step :1711-1714
+      }
+    } else {                                               // :1650-1708
+      const uint32_t w_n = uni(p.d_wl_cnt[q]);
+      for (uint32_t i = lane; i < w_n; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
+      wave_sync();
+      const float worst = s.wd[w_n - 1];
+      const uint32_t lim = L < n ? L : n;
+      // nb = number of leading new entries with dist < worst (stop at the first >=) :1653-1657
+      uint32_t nb = lim;
+      for (uint32_t base = 0; base < lim; base += WAVE) {
+        const uint32_t i = base + lane;
+        const bool ge = (i < lim) && (s.td[i] >= worst);
+        const uint64_t mk = __ballot(ge);
+        if (mk) { nb = base + (uint32_t)__builtin_ctzll(mk); break; }
+      }
+      const uint32_t room = L - w_n;
+      const uint32_t fill = room < n ? room : n;
+      if (fill > nb) nb = fill;                            // :1660
+      new_n = (w_n + nb) < L ? (w_n + nb) : L;             // :1662
+      for (uint32_t i = lane; i < nb; i += WAVE) {         // new entries: lower_bound + i :1675-1677
+        const float d = s.td[i];
+        const uint32_t pos = lower_bound_lds(s.wd, w_n, d) + i;
+        if (pos < new_n) {
+          const uint32_t id = s.ti[i];
+          wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (id == mark) ? 1 : 0;
+        }
+      }
+      for (uint32_t k = lane; k < w_n; k += WAVE) {        // old entries: upper_bound + k :1678-1680
+        const float d = s.wd[k];
+        const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
+        if (pos < new_n) {
+          const uint32_t id = s.wi[k];
+          wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (s.wv[k] || id == mark) ? 1 : 0;
+        }
+      }
+    }
+    if (lane == 0) p.d_wl_cnt[q] = new_n;
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: populate_pqDist_par (:1083-1130) -- LUT path only
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict__ pivots_T, const T* __restrict__ queries,
+                                                        const float* __restrict__ centroid,
+                                                        const uint32_t* __restrict__ chunk_off, float* __restrict__ lut,
+                                                        uint32_t D, uint32_t m, uint32_t dim_adjust) {
+  extern __shared__ __attribute__((aligned(16))) float qc[];   // float(q[j]) - centroid[j]
+  const uint32_t q = blockIdx.x;
+  const uint32_t qdim = D - dim_adjust;
+  for (uint32_t j = threadIdx.x; j < D; j += blockDim.x) {
+    const float qv = (j < qdim) ? (float)queries[(size_t)q * qdim + j] : 0.0f;   // :1102-1113
+    qc[j] = qv - centroid[j];
+  }
+  __syncthreads();
+  const uint32_t k = threadIdx.x;   // one pivot column per thread: coalesced reads of pivots_T[j][0..255]
+  for (uint32_t c = 0; c < m; ++c) {
+    float acc = 0.0f;               // registers instead of the reference's global RMW :1126
+    for (uint32_t j = chunk_off[c]; j < chunk_off[c + 1]; ++j) {
+      const float diff = pivots_T[(size_t)j * 256 + k] - qc[j];
+      acc = __builtin_fmaf(diff, diff, acc);
+    }
+    lut[((size_t)q * m + c) * 256 + k] = acc;
+  }
+}
+
+// centred queries in chunk-padded layout (first half of K1, :1099-1113,1124)
+template <typename T>
+__global__ void center_queries_kernel(const T* __restrict__ queries, const float* __restrict__ centroid,
+                                      const uint32_t* __restrict__ chunk_off, float* __restrict__ qc, uint32_t Q,
+                                      uint32_t D, uint32_t m, uint32_t mp, uint32_t psz, uint32_t dim_adjust) {
+  const uint32_t per_q = mp * psz;
+  const uint32_t qdim = D - dim_adjust;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)Q * per_q;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t q = (uint32_t)(idx / per_q);
+    const uint32_t r = (uint32_t)(idx % per_q);
+    const uint32_t c = r / psz, i = r % psz;
+    float v = 0.0f;
+    const uint32_t j = (c < m) ? chunk_off[c] + i : 0xFFFFFFFFu;
+    if (c < m && j < chunk_off[c + 1]) {
+      const float qv = (j < qdim) ? (float)queries[(size_t)q * qdim + j] : 0.0f;
+      v = qv - centroid[j];
+    }
+    qc[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6 + K7: exact re-rank (compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368)
+// ------------------------------------------------------------------------------------------
+#define RERANK_MAX_CAND (BANG_MAX_L + BANG_EXTRA_ITERS)
+
+template <typename T>
+__device__ __forceinline__ float exact_dist(const uint8_t* __restrict__ vec, const T* __restrict__ qv, uint32_t D);
+
+template <>
+__device__ __forceinline__ float exact_dist<float>(const uint8_t* __restrict__ vec, const float* __restrict__ qv, uint32_t D) {
+  const float* v = (const float*)vec;
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < D; ++j) {
+    const float diff = v[j] - qv[j];
+    acc = __builtin_fmaf(diff, diff, acc);
+  }
+  return acc;
+}
+template <>
+__device__ __forceinline__ float exact_dist<uint8_t>(const uint8_t* __restrict__ vec, const uint8_t* __restrict__ qv, uint32_t D) {
+  float acc = 0.0f;
+  uint32_t j = 0;
+  if ((((uintptr_t)vec) & 3u) == 0) {
+    for (; j + 4 <= D; j += 4) {
+      const uint32_t w = *(const uint32_t*)(vec + j);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float diff = (float)((int)((w >> (8 * b)) & 0xffu) - (int)qv[j + b]);   // int subtract :1294
+        acc = __builtin_fmaf(diff, diff, acc);
+      }
+    }
+  }
+  for (; j < D; ++j) {
+    const float diff = (float)((int)vec[j] - (int)qv[j]);
+    acc = __builtin_fmaf(diff, diff, acc);
+  }
+  return acc;
+}
+template <>
+__device__ __forceinline__ float exact_dist<int8_t>(const uint8_t* __restrict__ vec, const int8_t* __restrict__ qv, uint32_t D) {
+  const int8_t* v = (const int8_t*)vec;
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < D; ++j) {
+    const float diff = (float)((int)v[j] - (int)qv[j]);
+    acc = __builtin_fmaf(diff, diff, acc);
+  }
+  return acc;
+}
+
+struct RerankArgs {
+  const uint8_t* vec_base;
+  uint64_t vec_stride;
+  const uint8_t* medoid_vec;
+  const void* queries;
+  const uint32_t* cand_ids;
+  const uint32_t* cand_row;
+  const uint32_t* cand_cnt;
+  uint32_t cand_stride, q0, nq, Q_total, D, k, dim_adjust;
+  uint64_t* ids_out;
+  float* dists_out;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
+  __shared__ float e[RERANK_MAX_CAND + 2];
+  __shared__ uint32_t ids[RERANK_MAX_CAND + 2];
+  extern __shared__ __attribute__((aligned(16))) uint8_t qraw[];
+  T* qv = (T*)qraw;
+  const uint32_t q = a.q0 + blockIdx.x;
+  const uint32_t qdim = a.D - a.dim_adjust;
+  for (uint32_t j = threadIdx.x; j < a.D; j += blockDim.x)          // MIPS zero pad :1276-1286
+    qv[j] = (j < qdim) ? ((const T*)a.queries)[(size_t)q * qdim + j] : (T)0;
+  uint32_t n = a.cand_cnt[q];
+  if (n > RERANK_MAX_CAND) n = RERANK_MAX_CAND;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t id = a.cand_ids[(size_t)q * a.cand_stride + i];
+    const uint8_t* vec;
+    if (a.cand_row) {
+      const uint32_t row = a.cand_row[(size_t)q * a.cand_stride + i];
+      vec = (row == 0) ? a.medoid_vec : a.vec_base + ((uint64_t)row * a.Q_total + q) * a.vec_stride;
+    } else {
+      vec = a.vec_base + (uint64_t)id * a.vec_stride;
+    }
+    e[i] = exact_dist<T>(vec, qv, a.D);
+    ids[i] = id;
+  }
+  __syncthreads();
+  // stable rank by exact distance; ties keep expansion order (:1330-1363)
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = e[i];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+      const float o = e[j];
+      r += (o < d || (o == d && j < i)) ? 1u : 0u;
+    }
+    if (r < a.k) {
+      a.ids_out[(size_t)q * a.k + r] = (uint64_t)ids[i];                 // [Q][k] u64 :1366
+      a.dists_out[(size_t)r * a.Q_total + q] = d;                         // [rank][Q] :999,1297
+    }
+  }
+  for (uint32_t r = n + threadIdx.x; r < a.k; r += blockDim.x) {          // CANON tail
+    a.ids_out[(size_t)q * a.k + r] = ~0ull;
+    a.dists_out[(size_t)r * a.Q_total + q] = BIG_DIST;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (C-ABI)
+// ------------------------------------------------------------------------------------------
+#define HIP_TRY(x)                                                         \
+  do {                                                                     \
+    hipError_t _e = (x);                                                   \
+    if (_e != hipSuccess) {                                                \
+      bang_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return BANG_ERR_HIP;                                                 \
+    }                                                                      \
+  } while (0)
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+// Supported (PSZ, NDW) instances of the LDS-resident distance kernel.  LDS need = NDW*4*256*PSZ*4 B.
+static const int kNdwList[4][4] = {{8, 16, 24, 32}, {8, 16, 18, 19}, {4, 8, 0, 0}, {2, 4, 0, 0}};
+static int psz_slot(int psz) { return psz == 1 ? 0 : psz == 2 ? 1 : psz == 4 ? 2 : psz == 8 ? 3 : -1; }
+
+extern "C" int bang_pq_layout(const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t* psz_out, uint32_t* mp_out) {
+  if (!chunk_off || m == 0 || !psz_out || !mp_out) return BANG_ERR_ARG;
+  *psz_out = 0;
+  *mp_out = m;
+  uint32_t mx = 0;
+  for (uint32_t c = 0; c < m; ++c) {
+    if (chunk_off[c + 1] < chunk_off[c] || chunk_off[c + 1] > D) { bang_set_error("bad chunk offsets"); return BANG_ERR_ARG; }
+    const uint32_t sz = chunk_off[c + 1] - chunk_off[c];
+    if (sz > mx) mx = sz;
+  }
+  const int psz = mx <= 1 ? 1 : mx <= 2 ? 2 : mx <= 4 ? 4 : mx <= 8 ? 8 : 0;
+  if (psz == 0) return BANG_OK;                       // LUT path
+  const int need = (int)((m + 3) / 4);
+  const int slot = psz_slot(psz);
+  for (int i = 0; i < 4; ++i) {
+    const int ndw = kNdwList[slot][i];
+    if (ndw >= need && ndw > 0) {
+      *psz_out = (uint32_t)psz;
+      *mp_out = (uint32_t)ndw * 4;
+      return BANG_OK;
+    }
+  }
+  return BANG_OK;                                     // too many chunks for LDS: LUT path
+}
+
+extern "C" int bang_pack_pivots(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t psz,
+                                uint32_t mp, float* out) {
+  if (!pivots || !chunk_off || !out || psz == 0 || mp < m) return BANG_ERR_ARG;
+  for (uint32_t c = 0; c < mp; ++c)
+    for (uint32_t code = 0; code < 256; ++code)
+      for (uint32_t i = 0; i < psz; ++i) {
+        float v = 0.0f;
+        if (c < m) {
+          const uint32_t j = chunk_off[c] + i;
+          if (j < chunk_off[c + 1]) v = pivots[(size_t)code * D + j];
+        }
+        out[((size_t)c * 256 + code) * psz + i] = v;
+      }
+  return BANG_OK;
+}
+
+template <typename F>
+static int dispatch_dtype(int dtype, F&& f) {
+  switch (dtype) {
+    case BANG_U8: return f((uint8_t)0);
+    case BANG_I8: return f((int8_t)0);
+    case BANG_F32: return f((float)0);
+    default: bang_set_error("bad dtype %d", dtype); return BANG_ERR_ARG;
+  }
+}
+
+extern "C" int bang_k_center_queries(const void* d_queries, int dtype, const float* d_centroid,
+                                     const uint32_t* d_chunk_off, float* d_qc, uint32_t Q, uint32_t D, uint32_t m,
+                                     uint32_t mp, uint32_t psz, uint32_t dim_adjust, void* stream) {
+  if (Q == 0) return BANG_OK;
+  if (psz == 0 || mp < m) { bang_set_error("bad pq layout"); return BANG_ERR_ARG; }
+  const size_t total = (size_t)Q * mp * psz;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(center_queries_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)d_queries,
+                       d_centroid, d_chunk_off, d_qc, Q, D, m, mp, psz, dim_adjust);
+    HIP_TRY(hipGetLastError());
+    return BANG_OK;
+  });
+}
+
+extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, int dtype, const float* d_centroid,
+                                const uint32_t* d_chunk_off, float* d_lut, uint32_t Q, uint32_t D, uint32_t m,
+                                uint32_t dim_adjust, void* stream) {
+  if (Q == 0) return BANG_OK;
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(lut_build_kernel<T>, dim3(Q), dim3(256), D * sizeof(float), (hipStream_t)stream, d_pivots_T,
+                       (const T*)d_queries, d_centroid, d_chunk_off, d_lut, D, m, dim_adjust);
+    HIP_TRY(hipGetLastError());
+    return BANG_OK;
+  });
+}
+
+template <int PSZ, int NDW, bool ALIGNED>
+static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED>), grid, block, lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return BANG_OK;
+}
+
+template <int PSZ, int NDW>
+static int launch_front_al(const FrontArgs& a, bool aligned, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  return aligned ? launch_front_inst<PSZ, NDW, true>(a, grid, block, lds, st)
+                 : launch_front_inst<PSZ, NDW, false>(a, grid, block, lds, st);
+}
+
+static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream) {
+  if (!p) return BANG_ERR_ARG;
+  if (p->Q == 0) return BANG_OK;
+  if (p->R > BANG_MAX_R || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
+  if (p->psz != 0 && (p->mp < p->m || (p->mp & 3u))) { bang_set_error("bad padded chunk count"); return BANG_ERR_ARG; }
+  FrontArgs a;
+  a.p = *p;
+  a.stages = stages;
+  const bool need_piv = (p->psz != 0) && (stages & 2u);
+  a.lds_piv_floats = need_piv ? p->mp * 256u * p->psz : 0u;
+  const size_t piv_bytes = (size_t)a.lds_piv_floats * 4;
+  const size_t lds_cap = 160 * 1024;
+  // waves per workgroup: enough to cover Q with one workgroup per CU, bounded by LDS
+  int waves = (int)((p->Q + (uint32_t)num_cus() - 1) / (uint32_t)num_cus());
+  if (waves < 1) waves = 1;
+  if (waves > 16) waves = 16;
+  while (waves > 1 && piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4 > lds_cap) --waves;
+  const size_t lds = piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4;
+  if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
+  int grid_n = (int)((p->Q + (uint32_t)waves - 1) / (uint32_t)waves);
+  const int max_grid = need_piv ? num_cus() : num_cus() * 8;
+  if (grid_n > max_grid) grid_n = max_grid;
+  const dim3 grid(grid_n), block(waves * WAVE);
+  const bool al = (p->m % 4u) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t key = p->psz * 100u + (p->psz ? p->mp / 4u : 0u);
+  switch (key) {
+    case 0: return launch_front_inst<0, 1, true>(a, grid, block, lds, st);
+    case 108: return launch_front_al<1, 8>(a, al, grid, block, lds, st);
+    case 116: return launch_front_al<1, 16>(a, al, grid, block, lds, st);
+    case 124: return launch_front_al<1, 24>(a, al, grid, block, lds, st);
+    case 132: return launch_front_al<1, 32>(a, al, grid, block, lds, st);
+    case 208: return launch_front_al<2, 8>(a, al, grid, block, lds, st);
+    case 216: return launch_front_al<2, 16>(a, al, grid, block, lds, st);
+    case 218: return launch_front_al<2, 18>(a, al, grid, block, lds, st);
+    case 219: return launch_front_al<2, 19>(a, al, grid, block, lds, st);
+    case 404: return launch_front_al<4, 4>(a, al, grid, block, lds, st);
+    case 408: return launch_front_al<4, 8>(a, al, grid, block, lds, st);
+    case 802: return launch_front_al<8, 2>(a, al, grid, block, lds, st);
+    case 804: return launch_front_al<8, 4>(a, al, grid, block, lds, st);
+    default: bang_set_error("no kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int bang_k_front(const bang_iter_params* p, void* stream) { return launch_front(p, 7u, stream); }
+extern "C" int bang_k_filter(const bang_iter_params* p, void* stream) { return launch_front(p, 1u, stream); }
+extern "C" int bang_k_pqdist(const bang_iter_params* p, void* stream) { return launch_front(p, 2u, stream); }
+extern "C" int bang_k_parent(const bang_iter_params* p, void* stream) { return launch_front(p, 4u, stream); }
+
+extern "C" int bang_k_back(const bang_iter_params* p, void* stream) {
+  if (!p) return BANG_ERR_ARG;
+  if (p->Q == 0) return BANG_OK;
+  if (p->L > BANG_MAX_L || p->L == 0) { bang_set_error("bad L"); return BANG_ERR_ARG; }
+  int grid = (int)((p->Q + BACK_WAVES - 1) / BACK_WAVES);
+  const int max_grid = num_cus() * 8;
+  if (grid > max_grid) grid = max_grid;
+  hipLaunchKernelGGL(back_kernel, dim3(grid), dim3(BACK_WAVES * WAVE), 0, (hipStream_t)stream, *p);
+  HIP_TRY(hipGetLastError());
+  return BANG_OK;
+}
+
+// per-batch state reset (device side of bang_init, bang_search.cu:440-464): candidate log row 0 = MEDOID
+__global__ void init_state_kernel(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_t* cand_ids, uint32_t* cand_row,
+                                  uint32_t* cand_cnt, uint32_t* wl_cnt, uint32_t* mark, uint32_t* parents, uint32_t* cnt) {
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+    cand_ids[(size_t)q * cand_stride] = medoid;
+    if (cand_row) cand_row[(size_t)q * cand_stride] = 0;
+    cand_cnt[q] = 1;
+    wl_cnt[q] = 0;
+    mark[q] = 0x01010101u;   // cudaMemset(d_mark, 1, ...) :446
+    if (parents) parents[q] = BANG_NO_PARENT;
+    cnt[q] = 0;
+  }
+}
+
+extern "C" int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_t* d_cand_ids,
+                                 uint32_t* d_cand_row, uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark,
+                                 uint32_t* d_parents, uint32_t* d_cnt, void* stream) {
+  if (Q == 0) return BANG_OK;
+  const int blocks = (int)((Q + 255) / 256);
+  hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Q, medoid, cand_stride,
+                     d_cand_ids, d_cand_row, d_cand_cnt, d_wl_cnt, d_mark, d_parents, d_cnt);
+  HIP_TRY(hipGetLastError());
+  return BANG_OK;
+}
+
+extern "C" int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, const void* d_medoid_vec,
+                                   const void* d_queries, int dtype, const uint32_t* d_cand_ids,
+                                   const uint32_t* d_cand_row, const uint32_t* d_cand_cnt, uint32_t cand_stride,
+                                   uint32_t q0, uint32_t nq, uint32_t Q_total, uint32_t D, uint32_t k,
+                                   uint32_t dim_adjust, uint64_t* d_ids_out, float* d_dists_out, void* stream) {
+  if (nq == 0) return BANG_OK;
+  if (k == 0 || k > BANG_MAX_L) { bang_set_error("bad k"); return BANG_ERR_ARG; }
+  RerankArgs a;
+  a.vec_base = (const uint8_t*)d_vec_base; a.vec_stride = vec_stride; a.medoid_vec = (const uint8_t*)d_medoid_vec;
+  a.queries = d_queries; a.cand_ids = d_cand_ids; a.cand_row = d_cand_row; a.cand_cnt = d_cand_cnt;
+  a.cand_stride = cand_stride; a.q0 = q0; a.nq = nq; a.Q_total = Q_total; a.D = D; a.k = k; a.dim_adjust = dim_adjust;
+  a.ids_out = d_ids_out; a.dists_out = d_dists_out;
+  return dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(rerank_kernel<T>, dim3(nq), dim3(256), ((size_t)D * sizeof(T) + 15) & ~(size_t)15,
+                       (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return BANG_OK;
+  });
+}
+
+extern "C" int bang_k_rerank(const void* d_vec_base, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries,
+                             int dtype, const uint32_t* d_cand_ids, const uint32_t* d_cand_row, const uint32_t* d_cand_cnt,
+                             uint32_t cand_stride, uint32_t Q, uint32_t D, uint32_t k, uint32_t dim_adjust,
+                             uint64_t* d_ids_out, float* d_dists_out, void* stream) {
+  return bang_k_rerank_range(d_vec_base, vec_stride, d_medoid_vec, d_queries, dtype, d_cand_ids, d_cand_row, d_cand_cnt,
+                             cand_stride, 0, Q, Q, D, k, dim_adjust, d_ids_out, d_dists_out, stream);
+}

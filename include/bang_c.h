@@ -1,0 +1,215 @@
+/*
+ * bang_c.h -- C-ABI of the MI355X-native BANG_Base search engine (libbang.so).
+ *
+ * Plain pointers and sizes only; every function returns an int status (0 = BANG_OK).
+ * Two layers:
+ *
+ *  (1) ENGINE level -- the live version of the C mirror the reference sketches but compiles out
+ *      (BANG_Base/bang.h:89-101, bang_search.cu:1787-1807; uint8-only there).  Same call order
+ *      as BANGSearch<T> (bang.h:36-84).  This is what a ctypes / cgo / JNI binding uses.
+ *
+ *  (2) KERNEL level -- the seam between the C++ host graph walker and the HIP kernels: one
+ *      entry per reference kernel (or fused group of kernels), device pointers + an explicit
+ *      hipStream_t passed as void*, no hidden globals, no allocation inside.  Each entry cites
+ *      the reference kernel it replaces.  tests/ drive these one by one against the oracle.
+ *
+ * All "d_" pointers are device pointers; "h_" host pointers.
+ */
+#ifndef BANG_C_H_
+#define BANG_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants */
+#define BANG_OK 0
+#define BANG_ERR_ARG (-1)       /* bad argument / call order */
+#define BANG_ERR_IO (-2)        /* missing / malformed index file (bang_load -> false) */
+#define BANG_ERR_NOMEM (-3)
+#define BANG_ERR_HIP (-4)       /* a HIP runtime call failed; see bang_last_error() */
+#define BANG_ERR_UNSUPPORTED (-5)
+#define BANG_ERR_NOGPU (-6)     /* no HIP device: the product has NO CPU fallback */
+
+#define BANG_MAX_L 512          /* bang.h:20 */
+#define BANG_MAX_R 64           /* bang_search.cu:35 */
+#define BANG_EXTRA_ITERS 50     /* NAX_EXTRA_ITERATION, bang_search.cu:53 */
+#define BANG_BF_ENTRIES 399887u /* bang_search.cu:48 */
+#define BANG_BF_WORDS 12512u    /* bit-packed filter, u32 words per query (>= ceil(399887/32), 64-B multiple) */
+#define BANG_NO_PARENT 0xFFFFFFFFu   /* parents[q]: query is finished */
+#define BANG_IDLE_PARENT 0xFFFFFFFEu /* parents[q]: no parent this step, unmerged survivors pending */
+#define BANG_NBR_STRIDE 72u     /* u32 stride of the per-query neighbour / distance rows (>= R+1) */
+#define BANG_STAGE_STRIDE 65u   /* u32 stride of a staged adjacency row: [count][id x R] */
+
+enum { BANG_U8 = 0, BANG_I8 = 1, BANG_F32 = 2 };            /* element type of vectors/queries */
+enum { BANG_DIST_L2 = 0, BANG_DIST_MIPS = 1 };              /* DistFunc, bang.h:26-30 */
+enum { BANG_GRAPH_HOST = 0,      /* graph in host RAM, C++ walker + staged H2D (BANG_Base) */
+       BANG_GRAPH_DEVICE = 1 };  /* graph + vectors resident in HBM (BANG_Inmemory placement) */
+
+/* ------------------------------------------------------------------ (1) engine level */
+typedef struct bang_engine bang_engine_t;
+
+const char* bang_last_error(void);          /* thread-local message of the last failure */
+int bang_device_count(void);                /* 0 if no HIP device */
+
+int bang_create(int dtype, bang_engine_t** out);             /* BANGSearch<T>() bang.h:42 */
+int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   bang.h:43 */
+
+/* options must be set before bang_load_e / bang_alloc_e:
+ *   "graph"   : BANG_GRAPH_HOST | BANG_GRAPH_DEVICE
+ *   "lanes"   : number of independent query groups pipelined against each other (>=1)
+ *   "threads" : host walker threads per lane (>=1)
+ *   "device"  : HIP device ordinal
+ *   "pq"      : 0 = pivot-stationary fused distance (default when it fits LDS), 1 = LUT path (K1+K2)
+ *   "timing"  : 1 = record per-launch HIP events for bang_get_stats */
+int bang_set_option(bang_engine_t* e, const char* key, long value);
+
+/* bang_load, bang.h:51 / bang_search.cu:138-362 */
+int bang_load_e(bang_engine_t* e, const char* indexfile_path_prefix);
+
+/* Same as bang_load_e but from memory (synthetic / already-mapped indices).  The graph pointer
+ * must stay valid until bang_unload_e (it is NOT copied in BANG_GRAPH_HOST mode); everything
+ * else is copied.  pivots is the file-order [256][D] table. */
+typedef struct {
+  uint64_t medoid, entry_len;
+  uint32_t D, R, N, m;
+  const uint8_t* graph;      /* N * entry_len bytes */
+  const uint8_t* codes;      /* N * m bytes (host) -- or NULL when d_codes is given */
+  const void* d_codes;       /* optional: codes already on the device (N*m + 256 bytes) */
+  const float* pivots;       /* [256][D] */
+  const float* centroid;     /* [D] */
+  const uint32_t* chunk_off; /* [m+1] */
+} bang_index_desc;
+int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* desc);
+
+int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn); /* bang.h:60 */
+int bang_alloc_e(bang_engine_t* e, int num_queries);                                        /* bang.h:53 */
+int bang_init_e(bang_engine_t* e, int num_queries);                                         /* bang.h:56 */
+/* bang_query, bang.h:75: ids [Q][k] u64, dists [k][Q] f32 (rank-major, bang_search.cu:999) */
+int bang_query_e(bang_engine_t* e, const void* h_queries, int num_queries, uint64_t* h_ids, float* h_dists);
+int bang_free_e(bang_engine_t* e);                                                          /* bang.h:80 */
+int bang_unload_e(bang_engine_t* e);                                                        /* bang.h:82 */
+
+/* statistics of the last bang_query_e */
+typedef struct {
+  double wall_ms;             /* bang_query_e wall time */
+  uint64_t iterations;        /* max `iter` reached over the lanes */
+  uint64_t dist_evals;        /* total surviving neighbours whose PQ distance was computed */
+  uint64_t fetched;           /* total adjacency ids offered to the filter */
+  uint64_t candidates;        /* total expanded nodes re-ranked */
+  uint64_t front_launches;    /* launches of the filter+distance+parent kernel */
+  double front_ms;            /* sum of their HIP-event durations ("timing"=1, else 0) */
+  double back_ms;             /* sort+merge launches */
+  double rerank_ms;
+  double walker_ms;           /* host time in the adjacency gather, summed over lanes */
+} bang_stats;
+int bang_get_stats(bang_engine_t* e, bang_stats* out);
+
+/* The reference's own C mirror (bang.h:91-100), uint8 only, one process-global engine. */
+int bang_load_c(char* indexfile_path_prefix);
+int bang_set_searchparams_c(int recall, int worklist_length, int nDistFunc);
+int bang_alloc_c(int num_queries);
+int bang_init_c(int num_queries);
+int bang_query_c(uint8_t* query_array, int num_queries, unsigned long* nearestNeighbours,
+                 float* nearestNeighbours_dist);
+int bang_free_c(void);
+int bang_unload_c(void);
+
+/* ------------------------------------------------------------------ device helpers */
+/* Raw device memory for callers without a tensor library (tests, bindings). */
+int bang_dev_malloc(void** d_ptr, size_t bytes);
+int bang_dev_free(void* d_ptr);
+int bang_dev_memset(void* d_ptr, int value, size_t bytes);
+int bang_dev_h2d(void* d_dst, const void* h_src, size_t bytes);
+int bang_dev_d2h(void* h_dst, const void* d_src, size_t bytes);
+int bang_dev_sync(void);
+
+/* ------------------------------------------------------------------ (2) kernel level */
+
+/* Layout of the LDS-resident ("pivot-stationary") distance kernel for an index: every chunk is padded
+ * to psz floats (1,2,4,8 >= the largest chunk) and the chunk count to mp (a multiple of 4 with a
+ * compiled kernel instance).  psz == 0 on return means "use the LUT path" (chunks wider than 8 dims or a
+ * table that cannot fit the 160 KB LDS). */
+int bang_pq_layout(const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t* psz_out, uint32_t* mp_out);
+
+/* Host-side re-layout of the file-order pivot table [256][D]:
+ * out[(c*256 + code)*psz + i] = pivots[code][chunk_off[c] + i], zero beyond the chunk and for c >= m.
+ * out holds mp*256*psz floats. */
+int bang_pack_pivots(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t psz,
+                     uint32_t mp, float* out);
+
+/* Centred queries in the same padded layout: d_qc[q][c*psz + i] = float(query[j]) - centroid[j],
+ * j = chunk_off[c] + i (0 in the padding and beyond D - dim_adjust).  First half of
+ * populate_pqDist_par (bang_search.cu:1099-1113,1124).  d_qc holds Q*mp*psz floats. */
+int bang_k_center_queries(const void* d_queries, int dtype, const float* d_centroid, const uint32_t* d_chunk_off,
+                          float* d_qc, uint32_t Q, uint32_t D, uint32_t m, uint32_t mp, uint32_t psz,
+                          uint32_t dim_adjust, void* stream);
+
+/* K1 populate_pqDist_par (bang_search.cu:1083-1130): d_lut [Q][m][256] f32. d_pivots_T is [D][256]. */
+int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, int dtype, const float* d_centroid,
+                     const uint32_t* d_chunk_off, float* d_lut, uint32_t Q, uint32_t D, uint32_t m,
+                     uint32_t dim_adjust, void* stream);
+
+/* Parameters of the per-iteration kernels.  One row per query in every [Q][...] array. */
+typedef struct {
+  uint32_t Q, R, m, L, medoid, iter;   /* iter = reference's 1-based iteration number */
+  uint32_t psz, mp;                    /* pivot layout (bang_pq_layout); psz == 0 => LUT path */
+  uint32_t first;                      /* 1: use the seed list + compute_parent1 semantics */
+  /* inputs */
+  const uint32_t* d_stage;             /* [Q][BANG_STAGE_STRIDE] staged adjacency {count, ids} (first==0) */
+  const uint32_t* d_seed;              /* [1 + R+1] {count, MEDOID, adj(MEDOID)...}  (first==1) */
+  const uint8_t* d_codes;              /* [N][m] + 256 B slack */
+  const float* d_pivots_packed;        /* [mp][256][psz]                        (psz != 0) */
+  const float* d_qc;                   /* [Q][mp*psz]                           (psz != 0) */
+  const float* d_lut;                  /* [Q][m][256]                           (psz == 0) */
+  /* graph-on-device mode: adjacency read by the kernel itself from d_graph via d_parents */
+  const uint8_t* d_graph;              /* NULL in host-graph mode */
+  uint64_t entry_len;
+  uint32_t vec_bytes;                  /* D*sizeof(T): offset of the degree word inside an entry */
+  /* state */
+  uint32_t* d_bloom;                   /* [Q][BANG_BF_WORDS] bit-packed visited filter */
+  uint32_t* d_nbrs;                    /* [Q][BANG_NBR_STRIDE] survivors of this iteration */
+  float* d_dist;                       /* [Q][BANG_NBR_STRIDE] their PQ distances */
+  uint32_t* d_cnt;                     /* [Q] survivor count */
+  uint32_t* d_wl_ids;                  /* [Q][L] worklist */
+  float* d_wl_dist;                    /* [Q][L] */
+  uint8_t* d_wl_vis;                   /* [Q][L] */
+  uint32_t* d_wl_cnt;                  /* [Q] */
+  uint32_t* d_mark;                    /* [Q] */
+  uint32_t* d_parents;                 /* [Q] parent id | BANG_NO_PARENT | BANG_IDLE_PARENT (device or mapped host) */
+  uint32_t* d_cand_ids;                /* [Q][L+50] expanded nodes (compact) */
+  uint32_t* d_cand_row;                /* [Q][L+50] iteration row holding the node's vector */
+  uint32_t* d_cand_cnt;                /* [Q] */
+  uint32_t* d_active;                  /* [1] incremented once per still-active query (may be NULL) */
+  unsigned long long* d_evals;         /* [2] += {survivors, fetched} (may be NULL) */
+} bang_iter_params;
+
+/* Fused K5 + K2 + K4: neighbor_filtering_new (bang_search.cu:1140-1165) -> compute_neighborDist_par
+ * (:1201-1241) -> compute_parent1 / compute_parent2 (:1464-1521 / :1384-1459), one wavefront per query. */
+int bang_k_front(const bang_iter_params* p, void* stream);
+
+/* Fused K3a + K3b: compute_BestLSets_par_sort_msort (bang_search.cu:1533-1585) ->
+ * compute_BestLSets_par_merge (:1605-1715), one wavefront per query. */
+int bang_k_back(const bang_iter_params* p, void* stream);
+
+/* Unfused stage entries (parity tests; same device code as the fused kernels). */
+int bang_k_filter(const bang_iter_params* p, void* stream);   /* K5 only: d_stage/d_seed -> d_nbrs, d_cnt */
+int bang_k_pqdist(const bang_iter_params* p, void* stream);   /* K2 only: d_nbrs,d_cnt -> d_dist */
+int bang_k_parent(const bang_iter_params* p, void* stream);   /* K4 only */
+
+/* Fused K6 + K7: compute_L2Dist (bang_search.cu:1254-1299) -> compute_NearestNeighbours (:1312-1368).
+ * Candidate i of query q has its vector at d_vec_base + (row*Q + q)*vec_stride (row = d_cand_row, host-graph
+ * mode: the per-iteration vector log) or at d_vec_base + id*vec_stride (d_cand_row == NULL: graph on device).
+ * d_ids_out [Q][k] u64; d_dists_out [k][Q] f32. */
+int bang_k_rerank(const void* d_vec_base, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries,
+                  int dtype, const uint32_t* d_cand_ids, const uint32_t* d_cand_row, const uint32_t* d_cand_cnt,
+                  uint32_t cand_stride, uint32_t Q, uint32_t D, uint32_t k, uint32_t dim_adjust,
+                  uint64_t* d_ids_out, float* d_dists_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BANG_C_H_ */

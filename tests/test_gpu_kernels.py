@@ -1,0 +1,152 @@
+"""Kernel-level parity on the GPU: every C-ABI kernel entry (include/bang_c.h section 2) is driven
+on its own and compared bit-for-bit with the oracle's restatement of the reference kernel it
+replaces.  The oracle plays the host walker (it owns the graph)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BIG = np.float32(3.402823E+38)
+
+
+class HostQuery:
+    """Per-query oracle-side state (bloom as bytes like the reference, worklist, candidate log)."""
+
+    def __init__(self, O, ix):
+        self.bloom = np.zeros(O.BF_MEMORY, dtype=np.uint8)
+        self.w = (np.zeros(0, np.uint32), np.zeros(0, np.float32), np.zeros(0, np.uint8))
+        self.mark = 0x01010101
+        self.cand = [ix.medoid]
+        self.parent = None
+        self.S = np.zeros(0, np.uint32)
+        self.d = np.zeros(0, np.float32)
+
+
+def _adj(ix, node):
+    deg = int(ix.degrees()[node])
+    return ix.adjacency()[node][:deg]
+
+
+@pytest.mark.parametrize("fixture,use_lut", [("small_f32", False), ("small_u8", False), ("small_deep", False),
+                                             ("small_i8", False), ("small_u8", True), ("small_f32", True)])
+def test_stage_by_stage(request, libbang, fixture, use_lut):
+    import bang_amd
+    from bang_amd.binding import IterState, NO_PARENT, IDLE_PARENT
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q, L, iters = 16, 24, 14
+    q = q[:Q]
+    orc = O.Oracle(ix)
+    st = IterState(ix, q, L, use_lut=use_lut)
+    luts = [orc.lut_build(q[i]) for i in range(Q)]
+    if use_lut:   # K1
+        assert np.array_equal(st.lut().view(np.uint32), np.stack(luts).view(np.uint32))
+    hq = [HostQuery(O, ix) for _ in range(Q)]
+    deg_adj = ix.adjacency(), ix.degrees()
+    seed = np.concatenate([[ix.medoid], deg_adj[0][ix.medoid][: int(deg_adj[1][ix.medoid])]]).astype(np.uint32)
+
+    for it in range(1, iters + 1):
+        st.iter, st.first = it, 1 if it == 1 else 0
+        # ---- K5 filter
+        lists = [seed if it == 1 else (_adj(ix, h.parent) if h.parent is not None else np.zeros(0, np.uint32)) for h in hq]
+        if it > 1:
+            st.stage(lists)
+        st.run("filter")
+        cnt, ids, _ = st.nbrs()
+        for i, h in enumerate(hq):
+            h.S = O.filter_ids(h.bloom, lists[i])
+            assert cnt[i] == len(h.S), (it, i)
+            assert np.array_equal(ids[i, :cnt[i]], h.S), (it, i)
+        # ---- K2 distances
+        st.run("pqdist")
+        _, _, dist = st.nbrs()
+        for i, h in enumerate(hq):
+            h.d = orc.pqdist(luts[i], h.S)
+            assert np.array_equal(dist[i, :len(h.S)].view(np.uint32), h.d.view(np.uint32)), (it, i)
+        # ---- K4 parent
+        st.run("parent")
+        par, mark = st.parents()
+        _, _, _, wvis = st.worklist()
+        ccnt, cids, crow = st.candidates()
+        for i, h in enumerate(hq):
+            if it == 1:
+                ok, p, mk = O.parent1(h.S, h.d, ix.medoid)
+            else:
+                ok, p, mk, vis = O.parent2(h.S, h.d, h.w[0], h.w[1], h.w[2], ix.medoid, h.mark)
+                h.w = (h.w[0], h.w[1], vis)
+            if ok:
+                h.parent, h.mark = p, mk
+                h.cand.append(p)
+                assert par[i] == p, (it, i)
+            else:
+                h.parent = None
+                assert par[i] == (IDLE_PARENT if len(h.S) else NO_PARENT), (it, i)
+            assert mark[i] == h.mark, (it, i)
+            assert ccnt[i] == len(h.cand) and np.array_equal(cids[i, :ccnt[i]], np.array(h.cand, np.uint32)), (it, i)
+            assert np.array_equal(wvis[i, :len(h.w[2])], h.w[2]), (it, i)
+        # ---- K3a + K3b sort + merge
+        st.run("back")
+        wn, wi, wd, wv = st.worklist()
+        for i, h in enumerate(hq):
+            s_ids, s_d = O.sort_pairs(h.S, h.d)
+            h.w = O.merge(s_ids, s_d, it, h.w[0], h.w[1], h.w[2], L, ix.medoid, h.mark)
+            n = len(h.w[0])
+            assert wn[i] == n, (it, i)
+            assert np.array_equal(wi[i, :n], h.w[0]) and np.array_equal(wv[i, :n], h.w[2]), (it, i)
+            assert np.array_equal(wd[i, :n].view(np.uint32), h.w[1].view(np.uint32)), (it, i)
+
+    # ---- K6 + K7 re-rank over the logged candidates
+    ids_g, dists_g = st.rerank(10)
+    for i, h in enumerate(hq):
+        e = np.array([orc.exact_dist(c, q[i]) for c in h.cand], dtype=np.float32)
+        ids_o, d_o = O.topk(np.array(h.cand, np.uint32), e, 10)
+        assert np.array_equal(ids_g[i], ids_o), i
+        assert np.array_equal(dists_g[:, i].view(np.uint32), d_o.view(np.uint32)), i
+
+
+def test_filter_snapshot_and_order(libbang, small_u8):
+    """CANON semantics of K5: duplicates inside one batch all pass (snapshot test), survivors keep input
+    order, a second offer of the same ids is rejected entirely."""
+    from bang_amd.binding import IterState
+    ix, q, _, _ = small_u8
+    st = IterState(ix, q[:4], 16)
+    st.first, st.iter = 0, 2
+    lists = [np.array([5, 9, 5, 1234, 9], np.uint32), np.arange(64, dtype=np.uint32)[::-1].copy(),
+             np.zeros(0, np.uint32), np.array([4294967295 % ix.N], np.uint32)]
+    st.stage(lists)
+    st.run("filter")
+    cnt, ids, _ = st.nbrs()
+    for i, l in enumerate(lists):
+        assert cnt[i] == len(l) and np.array_equal(ids[i, :cnt[i]], l)
+    st.run("filter")
+    cnt, _, _ = st.nbrs()
+    assert not cnt.any()
+
+
+def test_pqdist_float_order_is_canonical(libbang, small_u8):
+    """The 8-way strided partial sums + pairwise tree of compute_neighborDist_par differ from a plain
+    left-to-right sum in the last bits; the kernel must reproduce the canonical order, not 'a' sum."""
+    from bang_amd.binding import IterState
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    orc = O.Oracle(ix)
+    st = IterState(ix, q[:8], 16)
+    st.first, st.iter = 0, 2
+    rng = np.random.default_rng(5)
+    lists = [rng.choice(ix.N, 64, replace=False).astype(np.uint32) for _ in range(8)]
+    st.stage(lists)
+    st.run("filter")
+    st.run("pqdist")
+    cnt, ids, dist = st.nbrs()
+    naive_differs = 0
+    for i in range(8):
+        lut = orc.lut_build(q[i])
+        want = orc.pqdist(lut, ids[i, :cnt[i]])
+        assert np.array_equal(dist[i, :cnt[i]].view(np.uint32), want.view(np.uint32))
+        for j in range(cnt[i]):
+            row = ix.codes[ids[i, j]]
+            acc = np.float32(0)
+            for c in range(ix.m):
+                acc = np.float32(acc + lut[c, row[c]])
+            naive_differs += int(acc != want[j])
+    assert naive_differs > 0
