@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec @ 10-recall@10 >= 0.9 on a 10K-query batch (BASELINE.json metric), plus the
+roofline of the PQ-distance kernel and the CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|sift1b_shape|small] [--graph host|device]
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); the 10K-query batch is split into
+contiguous shards, one per rank, each rank searches its shard on its own replica of the PQ table and
+graph, and ONE RCCL all-gather of the result ids ends the step (strong scaling: total work is fixed).
+
+A "step" = one bang_query over the whole batch.  bang_init (visited-filter / worklist reset) is outside
+the timed bracket, exactly as in the reference harness (BANG_Base/test_driver.cpp:432-439); the
+init-inclusive rate is reported beside it.  Every step is bracketed by barrier + cuda.synchronize on both
+sides and the MAX over ranks is taken.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (N, D, dtype, R, m, Q, clusters)
+    "sift1m": (1_000_000, 128, "uint8", 64, 32, 10_000, 256),   # BASELINE.json configs[1]
+    "small": (100_000, 128, "uint8", 64, 32, 10_000, 64),       # quick functional run
+    "tiny": (20_000, 128, "uint8", 64, 32, 1_000, 32),
+}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sift1m", choices=sorted(WORKLOADS) + ["sift1b_shape"])
+    ap.add_argument("--graph", default="host", choices=["host", "device"],
+                    help="host: graph in host RAM + C++ walker (BANG_Base, the north-star path); device: graph in HBM")
+    ap.add_argument("--L", type=int, default=0, help="worklist length; 0 = smallest L on the harness grid with recall >= target")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--recall-target", type=float, default=90.0)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events in the timed steps")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (libbang has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bang_amd
+    from bang_amd import synth
+    from oracle import oracle as O           # checker + cpu_baseline leg only
+    bang_amd.build()
+
+    # ------------------------------------------------------------------ workload
+    t0 = time.time()
+    if args.workload == "sift1b_shape":
+        from tools import shape_workload
+        wl = shape_workload.make(dev, local_rank)
+        ix, queries, gt_i, gt_d, d_codes, wl_name = wl
+    else:
+        N, D, dtype, R, m, Q, ncl = WORKLOADS[args.workload]
+        ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q, K=args.k, n_clusters=ncl, device=dev)
+        d_codes = None
+        wl_name = (f"{args.workload}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
+                   f"Q={Q} k={args.k} (kNN+random-link graph, trained PQ, brute-force GT)")
+    torch.cuda.synchronize()
+    log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
+    Q = queries.shape[0]
+    k = args.k
+    q0, q1 = Q * rank // world, Q * (rank + 1) // world
+    my_q = np.ascontiguousarray(queries[q0:q1])
+    Qr = q1 - q0
+
+    graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
+    eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=args.lanes,
+                          timing=0 if args.no_events else 1)
+    eng.load_index(ix, d_codes=d_codes)
+
+    def run_once(L, timed=False):
+        eng.init(Qr)
+        if timed:
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        ids, dists = eng.query(my_q)
+        if world > 1:                                    # the single RCCL collective of the job
+            pad = (Q + world - 1) // world
+            mine = torch.zeros((pad, k), dtype=torch.int64, device=dev)
+            mine[:Qr] = torch.from_numpy(ids.view(np.int64)).to(dev)
+            allv = torch.empty((world * pad, k), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allv, mine)
+            if rank == 0:
+                _ = allv.cpu()
+        if timed:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+        return ids, dists, time.perf_counter() - t_a
+
+    # ------------------------------------------------------------------ choose L (untimed)
+    def recall_of(ids):
+        if gt_i is None:
+            return float("nan")
+        return O.recall(gt_i[q0:q1], gt_d[q0:q1], ids, k)
+
+    L = args.L
+    recall = float("nan")
+    if L == 0 and gt_i is not None:
+        for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
+            eng.set_searchparams(k, cand)
+            eng.alloc(Qr)
+            ids, _, _ = run_once(cand)
+            eng.free()
+            r = recall_of(ids)
+            if world > 1:
+                t = torch.tensor([r], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                r = float(t.item())
+            log(f"[bench] L={cand:3d} recall={r:.2f}")
+            if r >= args.recall_target:
+                L, recall = cand, r
+                break
+        if L == 0:
+            raise SystemExit("recall target not reached on the L grid")
+    elif L == 0:
+        L = 152                                          # reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
+
+    eng.set_searchparams(k, L)
+    eng.alloc(Qr)
+
+    # ------------------------------------------------------------------ timed steps
+    for _ in range(args.warmup):
+        run_once(L, timed=True)
+    step_s, init_s = [], []
+    agg = dict(front_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
+               fetched=0, candidates=0)
+    ids = None
+    for _ in range(args.steps):
+        ti = time.perf_counter()
+        ids, dists, el = run_once(L, timed=True)
+        init_s.append(time.perf_counter() - ti)
+        step_s.append(el)
+        st = eng.stats()
+        for key in agg:
+            agg[key] = agg[key] + st[key] if key != "iterations" else max(agg[key], st[key])
+    if gt_i is not None:
+        recall = recall_of(ids)
+    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        rc = torch.tensor([recall], dtype=torch.float64, device=dev)
+        dist.all_reduce(rc, op=dist.ReduceOp.MIN)
+        recall = float(rc.item())
+    total = float(times[0].sum().item())
+    total_incl_init = float(times[1].sum().item())
+    value = Q * args.steps / total
+
+    # parity spot check on the real workload: first 64 queries of this rank vs the oracle
+    orc = O.Oracle(ix)
+    chk = min(64, Qr)
+    ids_o, _ = orc.search(my_q[:chk], k, L)
+    parity_ok = bool(np.array_equal(ids[:chk], ids_o))
+
+    out = None
+    if rank == 0:
+        m = ix.m
+        bytes_per_eval = m + 8                           # m code bytes + 4 B id + 4 B distance
+        roof = None
+        if not args.no_events and agg["front_ms"] > 0:
+            launches = agg["front_launches"]
+            evals_per_launch = agg["dist_evals"] / launches
+            avg_ms = agg["front_ms"] / launches
+            achieved = evals_per_launch * bytes_per_eval / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                    "kernel": "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
+                    "algorithmic_bytes_per_launch": round(evals_per_launch * bytes_per_eval, 1),
+                    "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches,
+                    "bytes_per_distance_eval": bytes_per_eval}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            nthreads = os.cpu_count() or 1
+            orc.search(queries[: min(Q, 512)], k, L, nthreads=nthreads)     # warm
+            reps, t_cpu = 0, 0.0
+            while reps < 5 and t_cpu < 10.0:
+                t_a = time.perf_counter()
+                orc.search(queries, k, L, nthreads=nthreads)
+                t_cpu += time.perf_counter() - t_a
+                reps += 1
+            cpu = {"value": round(Q * reps / t_cpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
+                   "sample": f"{reps} x the full {Q}-query batch at L={L} through oracle/ (C + OpenMP, "
+                             f"{nthreads} threads), same timed region (search only)"}
+        out = {
+            "metric": "queries/sec @ recall@10>=0.9, 10K-query batch", "value": round(value, 1), "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * total / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_name, "L": L, "k": k, "recall_at_10": round(recall, 3), "graph": args.graph,
+                       "lanes": args.lanes, "iterations": agg["iterations"],
+                       "qps_incl_init": round(Q * args.steps / total_incl_init, 1),
+                       "parity_vs_oracle_first_64": parity_ok,
+                       "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
+                       "back_ms_per_step": round(agg["back_ms"] / args.steps, 3),
+                       "rerank_ms_per_step": round(agg["rerank_ms"] / args.steps, 3),
+                       "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
+                       "dist_evals_per_step": agg["dist_evals"] // args.steps},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    eng.free()
+    eng.unload()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
