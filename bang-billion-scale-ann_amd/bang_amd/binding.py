@@ -31,14 +31,14 @@ class BangError(RuntimeError):
 class IterParams(C.Structure):
     _fields_ = [
         ("Q", C.c_uint32), ("R", C.c_uint32), ("m", C.c_uint32), ("L", C.c_uint32), ("medoid", C.c_uint32),
-        ("iter", C.c_uint32), ("psz", C.c_uint32), ("mp", C.c_uint32), ("first", C.c_uint32),
+        ("iter", C.c_uint32), ("psz", C.c_uint32), ("mp", C.c_uint32), ("first", C.c_uint32), ("max_wgs", C.c_uint32),
         ("d_stage", C.c_void_p), ("d_seed", C.c_void_p), ("d_codes", C.c_void_p), ("d_pivots_packed", C.c_void_p),
         ("d_qc", C.c_void_p), ("d_lut", C.c_void_p), ("d_graph", C.c_void_p), ("entry_len", C.c_uint64),
         ("vec_bytes", C.c_uint32),
         ("d_bloom", C.c_void_p), ("d_nbrs", C.c_void_p), ("d_dist", C.c_void_p), ("d_cnt", C.c_void_p),
         ("d_wl_ids", C.c_void_p), ("d_wl_dist", C.c_void_p), ("d_wl_vis", C.c_void_p), ("d_wl_cnt", C.c_void_p),
         ("d_mark", C.c_void_p), ("d_parents", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_row", C.c_void_p),
-        ("d_cand_cnt", C.c_void_p), ("d_active", C.c_void_p), ("d_evals", C.c_void_p),
+        ("d_cand_cnt", C.c_void_p), ("d_active", C.c_void_p), ("d_qstats", C.c_void_p),
     ]
 
 
@@ -52,7 +52,7 @@ class Stats(C.Structure):
     _fields_ = [("wall_ms", C.c_double), ("iterations", C.c_uint64), ("dist_evals", C.c_uint64),
                 ("fetched", C.c_uint64), ("candidates", C.c_uint64), ("front_launches", C.c_uint64),
                 ("front_ms", C.c_double), ("back_ms", C.c_double), ("rerank_ms", C.c_double),
-                ("walker_ms", C.c_double)]
+                ("walker_ms", C.c_double), ("sync_ms", C.c_double), ("enqueue_ms", C.c_double)]
 
 
 def lib_path() -> str:
@@ -298,7 +298,7 @@ class IterState:
         self.d_cand_row = DeviceBuffer(Q * rows * 4)
         self.d_cand_cnt = DeviceBuffer(Q * 4)
         self.d_active = DeviceBuffer(4 * (rows + 2))
-        self.d_evals = DeviceBuffer(16)
+        self.d_qstats = DeviceBuffer(Q * 8)
         self.iter = 1
         self.first = 1
         self.reset()
@@ -313,7 +313,7 @@ class IterState:
 
     def reset(self):
         self.d_bloom.zero()
-        self.d_evals.zero()
+        self.d_qstats.zero()
         self.d_active.zero()
         _check(lib().bang_k_init_state(self.Q, self.ix.medoid, self.rows, C.c_void_p(self.d_cand_ids.ptr),
                                        C.c_void_p(self.d_cand_row.ptr), C.c_void_p(self.d_cand_cnt.ptr),
@@ -341,7 +341,7 @@ class IterState:
         p.d_mark, p.d_parents = self.d_mark.ptr, self.d_parents.ptr
         p.d_cand_ids, p.d_cand_row, p.d_cand_cnt = self.d_cand_ids.ptr, self.d_cand_row.ptr, self.d_cand_cnt.ptr
         p.d_active = None
-        p.d_evals = self.d_evals.ptr
+        p.d_qstats = self.d_qstats.ptr
         return p
 
     def run(self, entry: str):

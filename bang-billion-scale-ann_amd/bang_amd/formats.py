@@ -197,3 +197,82 @@ def read_truthset(path: str):
         ids = np.frombuffer(f.read(n * K * 4), dtype="<u4").reshape(n, K).copy()
         dists = np.frombuffer(f.read(n * K * 4), dtype="<f4").reshape(n, K).copy()
     return ids, dists
+
+
+# ---------------------------------------------------------------------------------------------
+# DiskANN `_disk.index`  ->  `_disk.bin` + `_disk_metadata.bin`   (reference: bang_preprocess.py)
+# ---------------------------------------------------------------------------------------------
+SECTOR_LEN = 4096  # bang_preprocess.py:21
+
+
+def write_diskann_index(path: str, vectors: np.ndarray, degrees: np.ndarray, adjacency: np.ndarray, medoid: int) -> None:
+    """Write a DiskANN-style sector-padded `_disk.index` (test input for the converter).
+    Sector 0 = header: {u32,u32 (skipped), u64 npts, u64 ndims, u64 medoid, u64 max_node_len, u64 nnodes_per_sector,
+    3 x u64 (skipped), u64 file_size}; then ``nnodes_per_sector`` node records per 4096-byte sector, each
+    [T vec[D]][u32 degree][u32 nbr[R]] with the adjacency in ARBITRARY (unsorted) order (bang_preprocess.py:28-109)."""
+    N, D = vectors.shape
+    R = adjacency.shape[1]
+    node_len = D * vectors.dtype.itemsize + 4 + 4 * R
+    per_sector = SECTOR_LEN // node_len
+    n_sectors = (N + per_sector - 1) // per_sector
+    fsize = (n_sectors + 1) * SECTOR_LEN
+    rng = np.random.default_rng(7)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 9, 1))
+        f.write(struct.pack("<QQQQQ", N, D, medoid, node_len, per_sector))
+        f.write(struct.pack("<QQQ", 0, 0, 0))
+        f.write(struct.pack("<Q", fsize))
+        f.write(b"\0" * (SECTOR_LEN - f.tell()))
+        for s in range(n_sectors):
+            buf = bytearray(SECTOR_LEN)
+            for j in range(per_sector):
+                i = s * per_sector + j
+                if i >= N:
+                    break
+                deg = int(degrees[i])
+                nb = adjacency[i, :deg].astype("<u4").copy()
+                rng.shuffle(nb)                     # DiskANN does not sort; the converter must
+                rec = vectors[i].tobytes() + struct.pack("<I", deg) + nb.tobytes()
+                rec += b"\0" * (node_len - len(rec))
+                buf[j * node_len:(j + 1) * node_len] = rec
+            f.write(bytes(buf))
+
+
+def convert_diskann_index(index_path: str, out_bin_path: str, D: int, dtype: str, R: int) -> dict:
+    """Compact a DiskANN `_disk.index` into `<x>_disk.bin` + `<x>_disk_metadata.bin`, sorting every adjacency list
+    ascending -- same outputs as the reference's bang_preprocess.py (header parse order :28-64, sector walk :75-80,
+    per-node copy + sort :81-109, metadata order :42,47,49-51,116), vectorised with numpy."""
+    isz = np.dtype(NP_DTYPE[dtype]).itemsize
+    meta_path = out_bin_path[:-4] + "_metadata" + out_bin_path[-4:]
+    with open(index_path, "rb") as f:
+        f.read(8)
+        npts, ndims, medoid, max_node_len, per_sector = struct.unpack("<QQQQQ", f.read(40))
+        f.read(24)
+        (fsize,) = struct.unpack("<Q", f.read(8))
+        n_sectors = fsize // SECTOR_LEN - 1
+        node_len = D * isz + 4 + 4 * R
+        out = np.zeros((npts, node_len), dtype=np.uint8)
+        done = 0
+        for s in range(n_sectors):
+            f.seek((s + 1) * SECTOR_LEN)
+            sec = np.frombuffer(f.read(SECTOR_LEN), dtype=np.uint8)
+            take = min(per_sector, npts - done)
+            if take <= 0:
+                break
+            recs = sec[: take * max_node_len].reshape(take, max_node_len)[:, :node_len]
+            out[done:done + take] = recs
+            done += take
+    deg = out[:, D * isz:D * isz + 4].copy().view("<u4").reshape(-1)
+    if (deg > R).any() or (deg == 0).any():
+        raise ValueError("bad degree in index (bang_preprocess.py:91-94)")
+    adj = out[:, D * isz + 4:].copy().view("<u4").reshape(npts, R)
+    col = np.arange(R)[None, :]
+    big = np.where(col < deg[:, None], adj, np.uint32(0xFFFFFFFF))
+    order = np.argsort(big, axis=1, kind="stable")
+    srt = np.take_along_axis(adj, order, axis=1)             # valid ids ascending first, padding after
+    out[:, D * isz + 4:] = np.ascontiguousarray(srt.astype("<u4")).view(np.uint8).reshape(npts, 4 * R)
+    with open(out_bin_path, "wb") as w:
+        w.write(out.tobytes())
+    with open(meta_path, "wb") as w:
+        w.write(struct.pack("<QQiIII", medoid, max_node_len, PREPROCESS_DTYPE_CODE[dtype], D, R, done))
+    return dict(npts=npts, ndims=ndims, medoid=medoid, max_node_len=max_node_len, nodes=done)

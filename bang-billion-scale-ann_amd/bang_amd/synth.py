@@ -4,7 +4,8 @@ The reference ships no dataset (sift10kfiles.tar.gz is absent) and relies on ext
 tools (``build_disk_index``, ``compute_groundtruth``; BANG_Base/ReadMe.pdf p.1-2) to produce the
 files ``bang_load`` reads.  This module produces the same files from a seed:
 
-* base vectors  = mixture of Gaussian clusters, clipped/rounded for uint8 / int8;
+* base vectors  = low-intrinsic-dimension Gaussian mixture (16-d latent mapped to D dims), clipped/rounded
+                  for uint8 / int8;
 * graph         = R/2 exact nearest neighbours + R/2 uniformly random long links per node,
                   de-duplicated, adjacency sorted ascending (bang_preprocess.py:102-104), ragged
                   degree allowed;
@@ -33,19 +34,29 @@ def _gen(seed: int, device) -> torch.Generator:
     return g
 
 
-def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, sigma: float = 12.0,
-                 seed: int = SEED, device="cpu") -> torch.Tensor:
-    """float32 tensor [N, D] already rounded/clipped to the value range of ``dtype``."""
+def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, d_lat: int = 16, spread: float = 3.0,
+                 noise: float = 2.0, seed: int = SEED, device="cpu") -> torch.Tensor:
+    """float32 tensor [N, D] already rounded/clipped to the value range of ``dtype``.
+
+    Low intrinsic dimension, like real descriptor data: a ``d_lat``-dimensional Gaussian-mixture latent
+    (``n_clusters`` centres with std ``spread``, unit within-cluster std) is mapped to D dims by a random
+    matrix with unit columns, scaled to a per-dimension std of 36 around 128 and perturbed by N(0, noise).
+    (An isotropic D-dimensional mixture makes every in-cluster point equidistant -- neither the graph nor
+    PQ can rank neighbours there and recall needs L > 400.)"""
     g = _gen(seed, device)
-    centres = torch.rand(n_clusters, D, generator=g, device=device) * 175.0 + 40.0
+    A = torch.randn(d_lat, D, generator=g, device=device)
+    A = A / A.norm(dim=0, keepdim=True)
+    centres = torch.randn(n_clusters, d_lat, generator=g, device=device) * spread
     assign = torch.randint(0, n_clusters, (N,), generator=g, device=device)
-    x = centres[assign] + torch.randn(N, D, generator=g, device=device) * sigma
+    z = centres[assign] + torch.randn(N, d_lat, generator=g, device=device)
+    x = z @ A
+    x = x * (36.0 / float(x.std())) + 128.0 + torch.randn(N, D, generator=g, device=device) * noise
     if dtype == "uint8":
         x = x.round().clamp_(0, 255)
     elif dtype == "int8":
         x = (x - 128.0).round().clamp_(-128, 127)
     else:
-        x = x / 128.0
+        x = (x - 128.0) / 128.0
     return x
 
 
@@ -152,7 +163,7 @@ def train_pq(x: torch.Tensor, m: int, iters: int = 8, sample: int = 65536, seed:
     return pivots, centroid, off, codes
 
 
-def make_queries(x: torch.Tensor, Q: int, dtype: str, noise: float = 6.0, seed: int = SEED) -> torch.Tensor:
+def make_queries(x: torch.Tensor, Q: int, dtype: str, noise: float = 4.5, seed: int = SEED) -> torch.Tensor:
     g = _gen(seed + 3, x.device)
     pick = torch.randint(0, x.shape[0], (Q,), generator=g, device=x.device)
     scale = noise if dtype != "float" else noise / 128.0

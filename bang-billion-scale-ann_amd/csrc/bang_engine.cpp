@@ -101,7 +101,7 @@ struct Lane {
   std::string err;
   uint32_t iterations = 0;
   uint64_t front_launches = 0;
-  double walker_ms = 0, front_ms = 0, back_ms = 0, rerank_ms = 0;
+  double walker_ms = 0, front_ms = 0, back_ms = 0, rerank_ms = 0, sync_ms = 0, enqueue_ms = 0;
 };
 
 }  // namespace
@@ -116,6 +116,8 @@ struct bang_engine {
   int device = 0;
   int pq_mode = 0;        // 0 auto (pivot-stationary if possible), 1 force LUT path
   int timing = 0;
+  int front_wgs_opt = -1; // -1 auto
+  int front_wgs = 0;      // workgroups per front-kernel launch (0 = all CUs); set from the lane count
   int check_every = 4;    // device-graph mode: poll the active counter every N iterations
   // index
   bool loaded = false;
@@ -162,7 +164,7 @@ struct bang_engine {
   uint32_t* d_cand_row = nullptr;
   uint32_t* d_cand_cnt = nullptr;
   uint32_t* d_active = nullptr;        // [L+50 + 2] per-iteration active counters (device-graph mode)
-  unsigned long long* d_evals = nullptr;
+  uint32_t* d_qstats = nullptr;        // [Q][2] per-query {survivors, fetched}
   uint8_t* d_fp = nullptr;             // [(L+50)][Q][vec_bytes] vector log (host-graph mode)
   uint8_t* h_fp = nullptr;             // pinned mirror
   uint32_t* h_stage = nullptr;         // pinned [Q][65]
@@ -294,7 +296,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_stage); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
-  dfree(e->d_active); dfree(e->d_evals); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
+  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_fp) (void)hipHostFree(e->h_fp);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -388,6 +390,7 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   memset(&p, 0, sizeof(p));
   p.Q = ln.nq; p.R = e->R; p.m = e->m; p.L = (uint32_t)e->L; p.medoid = (uint32_t)e->medoid;
   p.psz = e->psz; p.mp = e->mp;
+  p.max_wgs = e->front_wgs;
   p.d_stage = e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr;
   p.d_seed = e->d_seed;
   p.d_codes = e->d_codes;
@@ -411,7 +414,7 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   p.d_cand_row = e->d_cand_row ? e->d_cand_row + q0 * e->cand_stride : nullptr;
   p.d_cand_cnt = e->d_cand_cnt + q0;
   p.d_active = nullptr;
-  p.d_evals = e->d_evals;
+  p.d_qstats = e->d_qstats + q0 * 2;
 }
 
 hipEvent_t timing_begin(bang_engine* e, Lane& ln, int kind) {
@@ -497,7 +500,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
   ln.tev_used = 0;
-  ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0;
+  ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
+  auto t_enq = Clock::now();
+#define ENQ_BEGIN() (t_enq = Clock::now())
+#define ENQ_END() (ln.enqueue_ms += ms_since(t_enq))
   bang_iter_params p;
   fill_params(e, ln, p);
 
@@ -526,18 +532,25 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   bool fp_pending = false;
   for (;;) {
     p.first = 0; p.iter = iter;
+    ENQ_BEGIN();
     {
       hipEvent_t t = timing_begin(e, ln, 1);
       BANG_TRY(bang_k_back(&p, ln.s_main));                                  // K3a+K3b :726-738 (overlaps the walker)
       timing_end(e, ln, t);
     }
+    ENQ_END();
     if (!dev_graph) {
-      LANE_HIP(hipEventSynchronize(ln.ev_front));                            // parents of this iteration are in h_parents
+      {
+        const auto ts = Clock::now();
+        LANE_HIP(hipEventSynchronize(ln.ev_front));                          // parents of this iteration are in h_parents
+        ln.sync_ms += ms_since(ts);
+      }
       const auto t0 = Clock::now();
       uint32_t n_par = 0;
       const uint32_t active = walk(e, ln, iter, true, &n_par);               // CPU walker :771-813
       ln.walker_ms += ms_since(t0);
       if (active == 0) break;                                                // :958
+      ENQ_BEGIN();
       LANE_HIP(hipMemcpyAsync((void*)p.d_stage, e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
                               (size_t)ln.nq * BANG_STAGE_STRIDE * 4, hipMemcpyHostToDevice, ln.s_main));   // :827-833
       if (n_par) {
@@ -545,18 +558,21 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
         LANE_HIP(hipMemcpyAsync(e->d_fp + off, e->h_fp + off, (size_t)ln.nq * vb, hipMemcpyHostToDevice, ln.s_fp)); // :836-838
         fp_pending = true;
       }
+      ENQ_END();
     }
     ++iter;                                                                  // :879
     p.iter = iter;
     if (dev_graph) p.d_active = e->d_active + iter;
+    ENQ_BEGIN();
     {
       hipEvent_t t = timing_begin(e, ln, 0);
       BANG_TRY(bang_k_front(&p, ln.s_main));                                 // K5+K2+K4b :855-917
       timing_end(e, ln, t);
       ++ln.front_launches;
     }
+    if (!dev_graph) LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
+    ENQ_END();
     if (!dev_graph) {
-      LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
       if (iter == cap_iter) {                                                // :950-956
         // CANON: the vectors of the parents chosen at the cap are still fetched for the re-rank
         LANE_HIP(hipEventSynchronize(ln.ev_front));
@@ -653,6 +669,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
   else if (k == "timing") { e->timing = (int)value; }
+  else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
   else { bang_set_error("unknown option %s", key); return BANG_ERR_ARG; }
   return BANG_OK;
@@ -715,7 +732,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_mark, nq));
   BANG_TRY(dmalloc(&e->d_cand_ids, nq * rows));
   BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
-  BANG_TRY(dmalloc(&e->d_evals, 2));
+  BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
   BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
   if (dev_graph) {
@@ -734,6 +751,12 @@ static int alloc_buffers(bang_engine* e, int Q) {
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(8, Q / 512));
   nl = std::min(nl, Q);
   e->lanes.resize((size_t)nl);
+  {
+    int dev_id = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess) cus = prop.multiProcessorCount;
+    e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::max(1, cus / nl) : 0);
+  }
   for (int i = 0; i < nl; ++i) {
     Lane& ln = e->lanes[(size_t)i];
     HIP_TRY(hipStreamCreateWithFlags(&ln.s_main, hipStreamNonBlocking));     // :407-410
@@ -769,7 +792,7 @@ extern "C" int bang_init_e(bang_engine_t* e, int Q) {
   BANG_TRY(ensure_device(e));
   const size_t nq = (size_t)Q;
   HIP_TRY(hipMemsetAsync(e->d_bloom, 0, nq * BANG_BF_WORDS * 4, nullptr));                  // :443
-  HIP_TRY(hipMemsetAsync(e->d_evals, 0, 16, nullptr));
+  HIP_TRY(hipMemsetAsync(e->d_qstats, 0, nq * 8, nullptr));
   if (e->d_active) HIP_TRY(hipMemsetAsync(e->d_active, 0, ((size_t)e->cand_stride + 2) * 4, nullptr));
   BANG_TRY(bang_k_init_state((uint32_t)Q, (uint32_t)e->medoid, e->cand_stride, e->d_cand_ids, e->d_cand_row, e->d_cand_cnt,
                              e->d_wl_cnt, e->d_mark, e->d_parents_dev, e->d_cnt, nullptr));
@@ -814,6 +837,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.iterations = std::max<uint64_t>(s.iterations, ln.iterations);
     s.front_launches += ln.front_launches;
     s.front_ms += ln.front_ms; s.back_ms += ln.back_ms; s.rerank_ms += ln.rerank_ms; s.walker_ms += ln.walker_ms;
+    s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
   }
   return rc;
 }
@@ -822,10 +846,9 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   if (!e || !out) return BANG_ERR_ARG;
   bang_stats& s = e->stats;
   if (e->allocated && e->Qcur > 0 && s.candidates == 0) {   // device-side counters are fetched lazily
-    unsigned long long ev[2] = {0, 0};
-    HIP_TRY(hipMemcpy(ev, e->d_evals, 16, hipMemcpyDeviceToHost));
-    s.dist_evals = ev[0];
-    s.fetched = ev[1];
+    std::vector<uint32_t> qs((size_t)e->Qcur * 2);
+    HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < qs.size(); i += 2) { s.dist_evals += qs[i]; s.fetched += qs[i + 1]; }
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t c : cc) s.candidates += c;

@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bang_c.h"
 #include "bang_internal.h"
@@ -51,8 +52,8 @@ __device__ __forceinline__ uint32_t hash2(uint32_t x) {  // hashFn2_d :1180-1189
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_sync() {
-  // orders LDS traffic of ONE wave (program order + compiler fence); no cross-wave meaning
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // Intra-wave LDS hand-off: a wave executes its LDS instructions in program order, so a plain
+  // write followed by a read needs no fence; this only stops the compiler from moving code across.
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of mask bits below my lane
@@ -160,25 +161,45 @@ __device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ cod
 struct FrontArgs {
   bang_iter_params p;
   uint32_t stages;      // bit0 filter, bit1 distance, bit2 parent
+  uint32_t debug;       // timing-only ablations (BANG_FRONT_DEBUG): 1 no filter updates, 2 no distance math, 4 no pivot staging
   uint32_t lds_piv_floats;
 };
 
 // per-wave LDS scratch (uint32 words): compacted ids [0..71]
 #define FRONT_SCRATCH_WORDS 72
 
-template <int PSZ, int NDW, bool ALIGNED>
+// ALL = true: the production instantiation (filter + distance + parent, no stage branches so that the
+// independent loads of a query are issued back to back).  ALL = false: stage mask taken from a.stages
+// (kernel-level parity tests).
+template <int PSZ, int NDW, bool ALIGNED, bool ALL>
 __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_iter_params& p = a.p;
   float* piv_lds = lds;
   uint32_t* scratch_all = (uint32_t*)(lds + a.lds_piv_floats);
+  const bool do_filter = ALL || (a.stages & 1u);
+  const bool do_dist = ALL || (a.stages & 2u);
+  const bool do_parent = ALL || (a.stages & 4u);
 
-  if (PSZ > 0 && (a.stages & 2u)) {
-    // stage the chunk-packed pivot table (query independent) once per workgroup, 16 B per lane
+  if (PSZ > 0 && do_dist && !(a.debug & 4u)) {
+    // stage the chunk-packed pivot table (query independent) once per workgroup: 16 B per lane,
+    // 8 unconditional loads in flight per lane before the first LDS write
     const float4* src = (const float4*)p.d_pivots_packed;
     float4* dst = (float4*)piv_lds;
     const uint32_t n4 = a.lds_piv_floats >> 2;
-    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += blockDim.x * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t i = i0 + (uint32_t)j * blockDim.x;
+        v[j] = src[i < n4 ? i : n4 - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t i = i0 + (uint32_t)j * blockDim.x;
+        if (i < n4) dst[i] = v[j];
+      }
+    }
     __syncthreads();
   }
 
@@ -187,106 +208,117 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   const uint32_t nwaves = blockDim.x >> 6;
   uint32_t* scratch = scratch_all + wave * FRONT_SCRATCH_WORDS;
   const uint32_t medoid = p.medoid;
-  unsigned long long ev_surv = 0, ev_fetch = 0;
+  const uint32_t L = p.L;
+  const uint32_t first = p.first ? 1u : 0u;
+  const uint32_t lane_l = (uint32_t)lane < L ? (uint32_t)lane : L - 1;
   uint32_t n_active = 0;
 
   for (uint32_t q = blockIdx.x * nwaves + wave; q < p.Q; q += gridDim.x * nwaves) {
     uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
     float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
+    const uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
+    const float* wl_dist = p.d_wl_dist + (size_t)q * L;
+    const uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
+    uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
     uint32_t n = 0;        // survivors
     uint32_t sid0 = 0;     // lane's survivor id (index lane) ; sid1: survivor index 64 (lane 0 only)
     uint32_t sid1 = 0;
 
+    // ---- round trip A: every load that does not depend on another load of this query, issued
+    // unconditionally (the launcher guarantees all pointers are valid).  The worklist head needed by
+    // K4 is prefetched speculatively: the arrays always hold L valid words.
+    const uint32_t* row;   // {count, id x 64 (, 65th id for the seed list)}
+    bool have_row = true;
+    if (p.d_graph != nullptr && !first) {  // graph resident in HBM: the parent's adjacency is read in place
+      const uint32_t par = uni(p.d_parents[q]);
+      have_row = par < BANG_IDLE_PARENT;
+      row = (const uint32_t*)(p.d_graph + (uint64_t)(have_row ? par : 0u) * p.entry_len + p.vec_bytes);
+    } else {
+      // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) or the row staged by the host walker (:827-833)
+      row = first ? p.d_seed : p.d_stage + (size_t)q * BANG_STAGE_STRIDE;
+    }
+    uint32_t cnt_in = row[0];
+    const uint32_t x0 = row[1 + lane];                         // in bounds for every row kind (R <= 64)
+    const uint32_t x1 = row[65u * first];                      // 65th id exists only in the seed list
+    const uint32_t cc = p.d_cand_cnt[q];
+    uint32_t w_n = p.d_wl_cnt[q];
+    uint2 qs = make_uint2(0u, 0u);
+    if (p.d_qstats && lane == 0) qs = *(const uint2*)(p.d_qstats + (size_t)q * 2);
+    const uint32_t pw_vis = wl_vis[lane_l];
+    const float pw_dist = wl_dist[lane_l];
+    const uint32_t pw_id = wl_ids[lane_l];
+
     // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
-    if (a.stages & 1u) {
-      const uint32_t* src;
-      uint32_t cnt_in;
-      if (p.first) {                       // seed list [MEDOID, adj(MEDOID)...], bang_init :467-489
-        cnt_in = p.d_seed[0];
-        src = p.d_seed + 1;
-      } else if (p.d_graph != nullptr) {   // graph resident in HBM: read the parent's adjacency here
-        const uint32_t par = p.d_parents[q];
-        if (par >= BANG_IDLE_PARENT) { cnt_in = 0; src = p.d_seed; }
-        else {
-          const uint32_t* e = (const uint32_t*)(p.d_graph + (uint64_t)par * p.entry_len + p.vec_bytes);
-          cnt_in = e[0];
-          if (cnt_in > p.R) cnt_in = p.R;
-          src = e + 1;
-        }
-      } else {                             // adjacency staged by the host walker :827-833
-        src = p.d_stage + (size_t)q * BANG_STAGE_STRIDE;
-        cnt_in = src[0];
-        if (cnt_in > p.R) cnt_in = p.R;
-        src += 1;
-      }
+    if (do_filter) {
       cnt_in = uni(cnt_in);
-      ev_fetch += cnt_in;
-      uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
+      if (!have_row) cnt_in = 0;
+      const uint32_t cap = p.R + first;
+      if (cnt_in > cap) cnt_in = cap;
       // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
       const bool v0 = (uint32_t)lane < cnt_in;
       const bool v1 = (lane == 0) && (cnt_in > 64);
-      const uint32_t x0 = v0 ? src[lane] : 0u;
-      const uint32_t x1 = v1 ? src[64] : 0u;
-      uint32_t h0a = 0, h0b = 0, h1a = 0, h1b = 0;
-      bool pass0 = false, pass1 = false;
+      // ---- round trip B: visited-filter words (unconditional: a hash is always a valid index).
       // CANON: every id is tested against the filter state at entry (all loads before any set)
-      if (v0) {
-        h0a = hash1(x0); h0b = hash2(x0);
-        const uint32_t wa = bloom[h0a >> 5], wb = bloom[h0b >> 5];
-        pass0 = !(((wa >> (h0a & 31)) & 1u) && ((wb >> (h0b & 31)) & 1u));
-      }
-      if (v1) {
-        h1a = hash1(x1); h1b = hash2(x1);
-        const uint32_t wa = bloom[h1a >> 5], wb = bloom[h1b >> 5];
-        pass1 = !(((wa >> (h1a & 31)) & 1u) && ((wb >> (h1b & 31)) & 1u));
-      }
+      const uint32_t h0a = hash1(x0), h0b = hash2(x0), h1a = hash1(x1), h1b = hash2(x1);
+      const uint32_t w0a = bloom[h0a >> 5], w0b = bloom[h0b >> 5];
+      const uint32_t w1a = bloom[h1a >> 5], w1b = bloom[h1b >> 5];
+      const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
+      const bool pass1 = v1 && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
       const uint64_t m1 = __ballot(pass1);
+      if (!(a.debug & 1u)) {
       if (pass0) { atomicOr(&bloom[h0a >> 5], 1u << (h0a & 31)); atomicOr(&bloom[h0b >> 5], 1u << (h0b & 31)); }
       if (pass1) { atomicOr(&bloom[h1a >> 5], 1u << (h1a & 31)); atomicOr(&bloom[h1b >> 5], 1u << (h1b & 31)); }
+      }
       const uint32_t n0 = (uint32_t)__popcll(m0);
       n = n0 + (uint32_t)__popcll(m1);
-      // ordered compaction: survivors keep input order (CANON; reference uses atomicAdd order :1161)
+      // ordered compaction through LDS: survivors keep input order (CANON; reference uses atomicAdd
+      // order :1161).  One wave executes in order, so no fence is needed between the write and the read.
       if (pass0) scratch[lanes_below(m0)] = x0;
       if (pass1) scratch[n0] = x1;
       wave_sync();
       if ((uint32_t)lane < n) { sid0 = scratch[lane]; nbrs[lane] = sid0; }
       if (lane == 0 && n > 64) { sid1 = scratch[64]; nbrs[64] = sid1; }
-      if (lane == 0) p.d_cnt[q] = n;
+      if (lane == 0) {
+        p.d_cnt[q] = n;
+        if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(qs.x + n, qs.y + cnt_in);
+      }
       wave_sync();
     } else {
       n = uni(p.d_cnt[q]);
       if ((uint32_t)lane < n) sid0 = nbrs[lane];
       if (lane == 0 && n > 64) sid1 = nbrs[64];
     }
-    ev_surv += n;
 
     // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
     float d0 = BIG_DIST, d1 = BIG_DIST;
-    if (a.stages & 2u) {
+    if (do_dist) {
       cfloat_p qc = (cfloat_p)(uintptr_t)(PSZ > 0 ? p.d_qc + (size_t)q * (NDW * 4 * (PSZ > 0 ? PSZ : 1)) : nullptr);
       const float* lut = (PSZ == 0) ? p.d_lut + (size_t)q * p.m * 256 : nullptr;
-      // pass 0: survivors 0..63 (one per lane); pass 1: survivor 64 (seed list only), lane 0
+      // ---- round trip C: the code rows.  pass 0: survivors 0..63 (one per lane); pass 1: survivor 64
+      // (seed list only), lane 0
       for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t id = base ? sid1 : sid0;
         if (base + (uint32_t)lane < n) {
           float d;
-          if constexpr (PSZ > 0) d = pq_distance<(PSZ > 0 ? PSZ : 1), NDW, ALIGNED>(p.d_codes, p.m, id, piv_lds, qc);
+          if (a.debug & 2u) d = (float)id;
+          else if constexpr (PSZ > 0) d = pq_distance<(PSZ > 0 ? PSZ : 1), NDW, ALIGNED>(p.d_codes, p.m, id, piv_lds, qc);
           else d = pq_distance_lut(p.d_codes, p.m, id, lut);
           dist[base + lane] = d;
           if (base) d1 = d; else d0 = d;
         }
       }
-    } else if (a.stages & 4u) {
+    } else if (do_parent) {
       if ((uint32_t)lane < n) d0 = dist[lane];
       if (lane == 0 && n > 64) d1 = dist[64];
     }
 
     // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ------
-    if (a.stages & 4u) {
+    if (do_parent) {
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
-      float bd = ((uint32_t)lane < n && sid0 != medoid) ? d0 : BIG_DIST;
-      uint32_t bi = ((uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST) ? (uint32_t)lane : 0xFFFFu;
+      const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
+      float bd = elig ? d0 : BIG_DIST;
+      uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
       uint32_t bid = sid0;
 #pragma unroll
       for (int off = 1; off < WAVE; off <<= 1) {
@@ -297,50 +329,55 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
         if (take) { bd = od; bi = oi; bid = oid; }
       }
       // element 64 (lane 0 of the second round) can only win with a strictly smaller distance
-      {
+      if (n > 64) {
         const float e_d = __shfl(d1, 0);
         const uint32_t e_id = (uint32_t)__shfl((int)sid1, 0);
-        if (n > 64 && e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
+        if (e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
       }
       const bool have_best = (bi != 0xFFFFu);
       if (!have_best) bd = BIG_DIST;
 
-      bool found = false;
-      uint32_t parent = 0;
-      bool from_best = false;
-      uint32_t w_hit = 0;
-      if (p.first) {
+      bool found = false, from_best = false;
+      uint32_t parent = 0, w_hit = 0;
+      if (first) {
         if (have_best) { found = true; parent = bid; from_best = true; }
       } else {
-        const uint32_t w_n = uni(p.d_wl_cnt[q]);
-        const uint8_t* vis = p.d_wl_vis + (size_t)q * p.L;
-        const float* wd = p.d_wl_dist + (size_t)q * p.L;
-        const uint32_t* wi = p.d_wl_ids + (size_t)q * p.L;
-        for (uint32_t base = 0; base < w_n; base += WAVE) {   // first unvisited entry :1425-1439
+        w_n = uni(w_n);
+        float wdist = 0.0f;
+        uint32_t wid = 0;
+        {                                                   // first unvisited entry :1425-1439, head from registers
+          const uint64_t mk = __ballot((uint32_t)lane < w_n && (uint32_t)lane < L && pw_vis == 0);
+          if (mk) {
+            w_hit = (uint32_t)__builtin_ctzll(mk);
+            found = true;
+            wdist = __shfl(pw_dist, (int)w_hit);
+            wid = (uint32_t)__shfl((int)pw_id, (int)w_hit);
+          }
+        }
+        for (uint32_t base = WAVE; !found && base < w_n; base += WAVE) {   // rare: L > 64 and the head is all visited
           const uint32_t i = base + lane;
-          const bool unv = (i < w_n) && (vis[i] == 0);
-          const uint64_t mk = __ballot(unv);
+          const uint64_t mk = __ballot((i < w_n) && (wl_vis[i < w_n ? i : 0] == 0));
           if (mk) {
             w_hit = base + (uint32_t)__builtin_ctzll(mk);
             found = true;
-            break;
+            wdist = wl_dist[w_hit];
+            wid = wl_ids[w_hit];
           }
         }
         if (found) {
-          const float wdist = wd[w_hit];
           if (bd < wdist) { parent = bid; from_best = true; }
-          else parent = wi[w_hit];
-        } else if (w_n > 0 && bd < wd[w_n - 1]) {            // corner case :1442-1446
-          found = true; parent = bid; from_best = true;
+          else parent = wid;
+        } else if (w_n > 0) {                               // corner case :1442-1446
+          const float worst = (w_n <= WAVE) ? __shfl(pw_dist, (int)(w_n - 1)) : wl_dist[w_n - 1];
+          if (bd < worst) { found = true; parent = bid; from_best = true; }
         }
       }
       if (lane == 0) {
         if (found) {
           if (from_best) p.d_mark[q] = parent;
-          else p.d_wl_vis[(size_t)q * p.L + w_hit] = 1;
-          const uint32_t cc = p.d_cand_cnt[q];
-          p.d_cand_ids[(size_t)q * (p.L + BANG_EXTRA_ITERS) + cc] = parent;
-          if (p.d_cand_row) p.d_cand_row[(size_t)q * (p.L + BANG_EXTRA_ITERS) + cc] = p.iter;
+          else p.d_wl_vis[(size_t)q * L + w_hit] = 1;
+          p.d_cand_ids[(size_t)q * (L + BANG_EXTRA_ITERS) + cc] = parent;
+          if (p.d_cand_row) p.d_cand_row[(size_t)q * (L + BANG_EXTRA_ITERS) + cc] = p.iter;
           p.d_cand_cnt[q] = cc + 1;
           p.d_parents[q] = parent;
         } else {
@@ -351,13 +388,8 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
     }
   }
 
-  if (lane == 0) {
-    if (p.d_active && n_active) atomicAdd(p.d_active, n_active);
-    if (p.d_evals && (ev_surv | ev_fetch)) {
-      atomicAdd(&p.d_evals[0], ev_surv);
-      atomicAdd(&p.d_evals[1], ev_fetch);
-    }
-  }
+  // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
+  if (lane == 0 && p.d_active && n_active) *p.d_active = 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -736,23 +768,26 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
   });
 }
 
-template <int PSZ, int NDW, bool ALIGNED>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
 
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  return aligned ? launch_front_inst<PSZ, NDW, true>(a, grid, block, lds, st)
-                 : launch_front_inst<PSZ, NDW, false>(a, grid, block, lds, st);
+  const bool all = (a.stages == 7u);
+  if (aligned) return all ? launch_front_inst<PSZ, NDW, true, true>(a, grid, block, lds, st)
+                          : launch_front_inst<PSZ, NDW, true, false>(a, grid, block, lds, st);
+  return all ? launch_front_inst<PSZ, NDW, false, true>(a, grid, block, lds, st)
+             : launch_front_inst<PSZ, NDW, false, false>(a, grid, block, lds, st);
 }
 
 static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream) {
@@ -760,29 +795,53 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (p->Q == 0) return BANG_OK;
   if (p->R > BANG_MAX_R || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
   if (p->psz != 0 && (p->mp < p->m || (p->mp & 3u))) { bang_set_error("bad padded chunk count"); return BANG_ERR_ARG; }
+  if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_seed) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
+  if ((stages & 4u) && (!p->d_wl_ids || !p->d_wl_dist || !p->d_wl_vis || !p->d_wl_cnt || !p->d_mark || !p->d_parents ||
+                        !p->d_cand_ids || !p->d_cand_cnt)) { bang_set_error("null worklist/candidate buffer"); return BANG_ERR_ARG; }
+  if ((stages & 1u) && (!p->d_bloom || (!p->first && !p->d_stage && !p->d_graph))) { bang_set_error("null filter buffer"); return BANG_ERR_ARG; }
+  if ((stages & 2u) && (p->psz ? (!p->d_pivots_packed || !p->d_qc) : !p->d_lut)) { bang_set_error("null PQ buffer"); return BANG_ERR_ARG; }
   FrontArgs a;
   a.p = *p;
   a.stages = stages;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* v = getenv("BANG_FRONT_DEBUG"); dbg = v ? atoi(v) : 0; }
+    a.debug = (uint32_t)dbg;
+  }
+  // the kernel issues its independent loads unconditionally: give unused optional inputs a valid address
+  {
+    bang_iter_params& x = a.p;
+    const uint32_t* dummy = p->d_seed;   // >= 67 words
+    if (!x.d_stage) x.d_stage = dummy;
+    if (!x.d_wl_cnt) x.d_wl_cnt = x.d_cnt;
+    if (!x.d_cand_cnt) x.d_cand_cnt = x.d_cnt;
+    if (!x.d_wl_vis) x.d_wl_vis = (uint8_t*)x.d_nbrs;
+    if (!x.d_wl_dist) x.d_wl_dist = x.d_dist;
+    if (!x.d_wl_ids) x.d_wl_ids = x.d_nbrs;
+    if (!x.d_bloom) x.d_bloom = x.d_nbrs;
+  }
   const bool need_piv = (p->psz != 0) && (stages & 2u);
   a.lds_piv_floats = need_piv ? p->mp * 256u * p->psz : 0u;
   const size_t piv_bytes = (size_t)a.lds_piv_floats * 4;
   const size_t lds_cap = 160 * 1024;
-  // waves per workgroup: enough to cover Q with one workgroup per CU, bounded by LDS
-  int waves = (int)((p->Q + (uint32_t)num_cus() - 1) / (uint32_t)num_cus());
+  // One workgroup per CU at most (the pivot table takes most of the LDS); a lane that shares the GPU
+  // with other lanes gets max_wgs of them.  Waves per workgroup: enough to cover Q, bounded by LDS.
+  int wgs = need_piv ? num_cus() : num_cus() * 8;
+  if (p->max_wgs && (int)p->max_wgs < wgs) wgs = (int)p->max_wgs;
+  int waves = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;
   while (waves > 1 && piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4 > lds_cap) --waves;
   const size_t lds = piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4;
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
   int grid_n = (int)((p->Q + (uint32_t)waves - 1) / (uint32_t)waves);
-  const int max_grid = need_piv ? num_cus() : num_cus() * 8;
-  if (grid_n > max_grid) grid_n = max_grid;
+  if (grid_n > wgs) grid_n = wgs;
   const dim3 grid(grid_n), block(waves * WAVE);
   const bool al = (p->m % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + (p->psz ? p->mp / 4u : 0u);
   switch (key) {
-    case 0: return launch_front_inst<0, 1, true>(a, grid, block, lds, st);
+    case 0: return launch_front_al<0, 1>(a, true, grid, block, lds, st);
     case 108: return launch_front_al<1, 8>(a, al, grid, block, lds, st);
     case 116: return launch_front_al<1, 16>(a, al, grid, block, lds, st);
     case 124: return launch_front_al<1, 24>(a, al, grid, block, lds, st);

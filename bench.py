@@ -70,7 +70,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import bang_amd
-    from bang_amd import synth
+    from bang_amd import shard, synth
     from oracle import oracle as O           # checker + cpu_baseline leg only
     bang_amd.build()
 
@@ -90,7 +90,7 @@ def main():
     log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
     Q = queries.shape[0]
     k = args.k
-    q0, q1 = Q * rank // world, Q * (rank + 1) // world
+    q0, q1 = shard.shard_range(Q, rank, world)
     my_q = np.ascontiguousarray(queries[q0:q1])
     Qr = q1 - q0
 
@@ -108,13 +108,7 @@ def main():
         t_a = time.perf_counter()
         ids, dists = eng.query(my_q)
         if world > 1:                                    # the single RCCL collective of the job
-            pad = (Q + world - 1) // world
-            mine = torch.zeros((pad, k), dtype=torch.int64, device=dev)
-            mine[:Qr] = torch.from_numpy(ids.view(np.int64)).to(dev)
-            allv = torch.empty((world * pad, k), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allv, mine)
-            if rank == 0:
-                _ = allv.cpu()
+            shard.gather_ids(ids, Q, k, rank, world, device=dev)
         if timed:
             torch.cuda.synchronize()
             if world > 1:
@@ -156,7 +150,7 @@ def main():
     for _ in range(args.warmup):
         run_once(L, timed=True)
     step_s, init_s = [], []
-    agg = dict(front_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
+    agg = dict(front_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
                fetched=0, candidates=0)
     ids = None
     for _ in range(args.steps):
@@ -227,6 +221,8 @@ def main():
                        "back_ms_per_step": round(agg["back_ms"] / args.steps, 3),
                        "rerank_ms_per_step": round(agg["rerank_ms"] / args.steps, 3),
                        "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
+                       "sync_ms_per_step": round(agg["sync_ms"] / args.steps, 3),
+                       "enqueue_ms_per_step": round(agg["enqueue_ms"] / args.steps, 3),
                        "dist_evals_per_step": agg["dist_evals"] // args.steps},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -105,6 +105,8 @@ typedef struct {
   double back_ms;             /* sort+merge launches */
   double rerank_ms;
   double walker_ms;           /* host time in the adjacency gather, summed over lanes */
+  double sync_ms;             /* host time blocked waiting for the parents of an iteration, summed over lanes */
+  double enqueue_ms;          /* host time spent inside launch / memcpy-enqueue calls, summed over lanes */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 
@@ -158,6 +160,7 @@ typedef struct {
   uint32_t Q, R, m, L, medoid, iter;   /* iter = reference's 1-based iteration number */
   uint32_t psz, mp;                    /* pivot layout (bang_pq_layout); psz == 0 => LUT path */
   uint32_t first;                      /* 1: use the seed list + compute_parent1 semantics */
+  uint32_t max_wgs;                    /* cap on workgroups of the front kernel (0 = one per CU); lanes share the GPU */
   /* inputs */
   const uint32_t* d_stage;             /* [Q][BANG_STAGE_STRIDE] staged adjacency {count, ids} (first==0) */
   const uint32_t* d_seed;              /* [1 + R+1] {count, MEDOID, adj(MEDOID)...}  (first==1) */
@@ -183,8 +186,8 @@ typedef struct {
   uint32_t* d_cand_ids;                /* [Q][L+50] expanded nodes (compact) */
   uint32_t* d_cand_row;                /* [Q][L+50] iteration row holding the node's vector */
   uint32_t* d_cand_cnt;                /* [Q] */
-  uint32_t* d_active;                  /* [1] incremented once per still-active query (may be NULL) */
-  unsigned long long* d_evals;         /* [2] += {survivors, fetched} (may be NULL) */
+  uint32_t* d_active;                  /* [1] set to 1 if any query is still active (plain store; may be NULL) */
+  uint32_t* d_qstats;                  /* [Q][2] per-query running totals {survivors, ids fetched} (may be NULL) */
 } bang_iter_params;
 
 /* Fused K5 + K2 + K4: neighbor_filtering_new (bang_search.cu:1140-1165) -> compute_neighborDist_par

@@ -1,0 +1,92 @@
+"""The drop-in boundary: libbang.so loads, exports every symbol include/bang_c.h declares, and fails loudly
+(never falls back to a CPU path) when no HIP device is present.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "bang_c.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|char\s*\*|const char\s*\*)\s+\*?(bang_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared_functions()
+    for must in ("bang_load_e", "bang_set_searchparams_e", "bang_alloc_e", "bang_init_e", "bang_query_e", "bang_free_e",
+                 "bang_unload_e", "bang_load_c", "bang_query_c", "bang_k_front", "bang_k_back", "bang_k_rerank",
+                 "bang_k_lut_build", "bang_k_filter", "bang_k_pqdist", "bang_k_parent", "bang_k_center_queries"):
+        assert must in names
+    assert len(names) >= 35
+
+
+def test_library_exports_every_declared_symbol(libbang):
+    for name in _declared_functions():
+        assert hasattr(libbang, name), name
+
+
+def test_cpp_class_symbols_are_exported(libbang):
+    """bang.h's BANGSearch<T> for float / uint8_t / int8_t (reference bang.h:85-87) -- what test_driver links against."""
+    import bang_amd
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", bang_amd.lib_path()], text=True)
+    for t in ("float", "unsigned char", "signed char"):
+        for meth in ("bang_load(char*)", "bang_alloc(int)", "bang_init(int)", "bang_set_searchparams(int, int, _DistFunc)",
+                     "bang_free()", "bang_unload()"):
+            assert f"BANGSearch<{t}>::{meth}" in out, (t, meth)
+        assert f"BANGSearch<{t}>::bang_query(" in out
+    assert os.path.exists(os.path.join(os.path.dirname(os.path.dirname(bang_amd.lib_path())), "bin", "bang_search"))
+
+
+def test_gpu_kernels_are_compiled_for_gfx950(libbang):
+    import bang_amd
+    blob = open(bang_amd.lib_path(), "rb").read()
+    assert b"gfx950" in blob and b"front_kernel" in blob and b"back_kernel" in blob and b"rerank_kernel" in blob
+
+
+def test_pq_layout_and_pivot_packing_host_side(libbang):
+    from bang_amd import binding
+    from bang_amd.synth import chunk_offsets
+    assert binding.pq_layout(chunk_offsets(128, 32), 128, 32) == (4, 32)       # SIFT1M: 4 dims/chunk, 8 code dwords
+    assert binding.pq_layout(chunk_offsets(128, 70), 128, 70) == (2, 72)       # SIFT1B: padded to 18 dwords
+    assert binding.pq_layout(chunk_offsets(96, 74), 96, 74) == (2, 76)         # DEEP100M
+    assert binding.pq_layout(chunk_offsets(256, 16), 256, 16)[0] == 0          # 16 dims/chunk -> LUT path
+    off = chunk_offsets(10, 4)                                                  # sizes 3,3,2,2 -> psz 4
+    piv = np.arange(256 * 10, dtype=np.float32).reshape(256, 10)
+    psz, mp = binding.pq_layout(off, 10, 4)
+    assert (psz, mp) == (4, 16)
+    packed = binding.pack_pivots(piv, off, 10, 4, psz, mp)
+    assert packed.shape == (16, 256, 4)
+    assert list(packed[0, 3]) == [30, 31, 32, 0] and list(packed[2, 255]) == [2556, 2557, 0, 0]
+    assert not packed[4:].any()
+
+
+def test_no_gpu_means_error_not_fallback(libbang):
+    """On a box without a HIP device every engine entry point must fail with BANG_ERR_NOGPU (-6)."""
+    import bang_amd
+    if bang_amd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    e = bang_amd.Engine("uint8")
+    with pytest.raises(bang_amd.BangError, match="no CPU fallback"):
+        e.load("/nonexistent/prefix")
+    p = C.c_void_p()
+    assert libbang.bang_dev_malloc(C.byref(p), C.c_size_t(16)) == -6
+
+
+def test_bad_arguments_are_rejected(libbang):
+    import bang_amd
+    e = bang_amd.Engine("float")
+    with pytest.raises(bang_amd.BangError):
+        e.set_searchparams(10, 5)            # L < k
+    with pytest.raises(bang_amd.BangError):
+        e.set_searchparams(10, 513)          # L > MAX_L (bang.h:20)
+    with pytest.raises(bang_amd.BangError):
+        e.alloc(100)                         # nothing loaded
+    with pytest.raises(bang_amd.BangError):
+        e.set_option("nonsense", 1)

@@ -1,0 +1,57 @@
+"""N > 1 path on CPU: two processes over gloo shard the query batch, search their shards (with the oracle
+standing in for the GPU engine -- tests may use it) and rebuild the full result with the single all-gather
+that bench.py issues over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, Q, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
+    import torch.distributed as dist
+    from bang_amd import shard, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ix, q, _, _ = synth.make_index(1500, 32, "uint8", 32, 8, Q, K=10, n_clusters=16, seed=21, pq_iters=3)
+    a, b = shard.shard_range(Q, rank, world)
+    ids, _ = O.Oracle(ix).search(q[a:b], 10, 24, nthreads=1)
+    full = shard.gather_ids(ids, Q, 10, rank, world)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+    if rank == 0:
+        ref, _ = O.Oracle(ix).search(q, 10, 24, nthreads=2)
+        np.save(os.path.join(out_dir, "ref.npy"), ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_reproduces_the_single_process_result(tmp_path):
+    Q, world = 37, 2            # odd Q: ragged shards
+    mp.spawn(_worker, args=(world, _free_port(), Q, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "ref.npy")
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), ref)
+
+
+def test_shard_ranges_cover_the_batch():
+    from bang_amd.shard import shard_range
+    for Q in (1, 7, 10000):
+        for W in (1, 2, 3, 8):
+            cuts = [shard_range(Q, r, W) for r in range(W)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == Q
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))

@@ -1,0 +1,91 @@
+"""File formats of the path: byte-level layout and round trips."""
+import struct
+
+import numpy as np
+
+from bang_amd import formats
+
+
+def test_graph_metadata_is_the_packed_32_byte_struct(tmp_path):
+    p = str(tmp_path / "x_disk_metadata.bin")
+    formats.write_graph_metadata(p, medoid=123742, entry_len_=388, dtype="uint8", D=128, R=64, N=1000000)
+    raw = open(p, "rb").read()
+    assert len(raw) == 32                                           # bang_search.cuh:42-50
+    assert struct.unpack("<QQiIII", raw) == (123742, 388, 1, 128, 64, 1000000)
+
+
+def test_entry_layout_matches_reference_offsets(small_u8):
+    ix = small_u8[0]
+    assert ix.entry_len == 128 + 4 + 4 * 64                         # D*sizeof(T) + 4 + 4R
+    e = ix.graph[17]
+    deg = struct.unpack("<I", e[128:132].tobytes())[0]              # bang_search.cu:335,801
+    nbrs = np.frombuffer(e[132:132 + 4 * deg].tobytes(), "<u4")
+    assert deg == ix.degrees()[17] and np.array_equal(nbrs, ix.adjacency()[17][:deg])
+    assert (np.diff(nbrs.astype(np.int64)) > 0).all()               # sorted ascending, bang_preprocess.py:102-104
+
+
+def test_pivots_file_sections(tmp_path, small_u8):
+    ix = small_u8[0]
+    p = str(tmp_path / "x_pq_pivots.bin")
+    formats.write_pq_pivots(p, ix.pivots, ix.centroid, ix.chunk_off)
+    raw = open(p, "rb").read()
+    assert struct.unpack("<I", raw[:4])[0] == 4                     # PQ_PIVOTS_NUM_SECTIONS+1, bang_search.cu:246-251
+    offs = struct.unpack("<QQQQ", raw[8:40])                        # read at byte 8 (:254-255)
+    assert offs[3] == len(raw)
+    piv = np.frombuffer(raw[offs[0] + 8: offs[0] + 8 + 256 * ix.D * 4], "<f4").reshape(256, ix.D)   # offset + 8 (:263)
+    assert np.array_equal(piv, ix.pivots)
+    assert struct.unpack("<ii", raw[offs[2]: offs[2] + 8]) == (ix.m + 1, 1)
+    pv, cen, off = formats.read_pq_pivots(p, ix.D, ix.m)
+    assert np.array_equal(pv, ix.pivots) and np.array_equal(cen, ix.centroid) and np.array_equal(off, ix.chunk_off)
+
+
+def test_index_round_trip(tmp_path, small_deep):
+    ix = small_deep[0]
+    prefix = str(tmp_path / "deep")
+    formats.write_index(prefix, ix)
+    raw = open(prefix + "_pq_compressed.bin", "rb").read()
+    assert struct.unpack("<ii", raw[:8]) == (ix.N, ix.m) and len(raw) == 8 + ix.N * ix.m   # bang_search.cu:218-234
+    back = formats.read_index(prefix, ix.dtype)
+    for f in ("graph", "codes", "pivots", "centroid", "chunk_off"):
+        assert np.array_equal(getattr(back, f), getattr(ix, f)), f
+    assert (back.N, back.D, back.R, back.m, back.medoid) == (ix.N, ix.D, ix.R, ix.m, ix.medoid)
+
+
+def test_query_and_truthset_files(tmp_path):
+    q = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    p = str(tmp_path / "q.bin")
+    formats.write_bin(p, q)
+    assert open(p, "rb").read()[:8] == struct.pack("<ii", 3, 4)     # test_driver.cpp:360-362
+    assert np.array_equal(formats.read_bin(p, "uint8"), q)
+    ids = np.array([[1, 2], [3, 4]], np.uint32)
+    d = np.array([[0.5, 1.5], [2.5, 3.5]], np.float32)
+    t = str(tmp_path / "gt.bin")
+    formats.write_truthset(t, ids, d)
+    assert len(open(t, "rb").read()) == 8 + 2 * 2 * 2 * 4           # size check test_driver.cpp:254-266
+    i2, d2 = formats.read_truthset(t)
+    assert np.array_equal(i2, ids) and np.array_equal(d2, d)
+
+
+def test_chunk_offsets_follow_diskann_split():
+    from bang_amd.synth import chunk_offsets
+    off = chunk_offsets(128, 70)
+    sizes = np.diff(off)
+    assert off[0] == 0 and off[-1] == 128 and list(sizes[:58]) == [2] * 58 and list(sizes[58:]) == [1] * 12
+    assert list(np.diff(chunk_offsets(96, 74))) == [2] * 22 + [1] * 52
+    assert list(np.diff(chunk_offsets(128, 32))) == [4] * 32
+
+
+def test_diskann_index_conversion_sorts_and_compacts(tmp_path, small_i8):
+    """Our counterpart of bang_preprocess.py: sector-padded _disk.index -> contiguous _disk.bin + metadata."""
+    ix = small_i8[0]
+    src = str(tmp_path / "x_disk.index")
+    formats.write_diskann_index(src, ix.vectors(), ix.degrees(), ix.adjacency(), ix.medoid)
+    raw = open(src, "rb").read()
+    assert len(raw) % 4096 == 0 and struct.unpack("<Q", raw[8:16])[0] == ix.N     # bang_preprocess.py:28-33
+    out = str(tmp_path / "x_disk.bin")
+    info = formats.convert_diskann_index(src, out, ix.D, ix.dtype, ix.R)
+    assert info["nodes"] == ix.N and info["medoid"] == ix.medoid
+    got = np.fromfile(out, np.uint8).reshape(ix.N, ix.entry_len)
+    assert np.array_equal(got, ix.graph)                             # shuffled lists come back sorted, vectors intact
+    md = formats.read_graph_metadata(str(tmp_path / "x_disk_metadata.bin"))
+    assert md == dict(medoid=ix.medoid, entry_len=ix.entry_len, dtype_code=0, D=ix.D, R=ix.R, N=ix.N)
