@@ -10,8 +10,12 @@
 //    PCIe / CPU latency hides behind another lane's kernels (the reference advances all 10K
 //    queries in lock-step and pays every round trip serially, bang_search.cu:701-958).
 //  * per iteration a lane issues 2 kernels (front = filter+distance+parent, back = sort+merge)
-//    instead of 6 kernels + 2 memsets; parents are written by the kernel straight into mapped
-//    pinned host memory (no D2H copy), adjacency rows travel in one H2D copy.
+//    instead of 6 kernels + 2 memsets.  Host and device talk through mapped pinned memory, not
+//    copies: the kernel writes the parents and a completion flag straight into host memory (the
+//    walker spins on the flag, no HIP call).  Adjacency rows travel in one H2D copy per lane and
+//    iteration (reading them in place over PCIe from the kernel was measured 5x slower: narrow
+//    reads, few in flight); full-precision vectors travel by batched async copies on a second stream.
+//  * lane and walker threads are persistent (created in bang_alloc), woken per query.
 //  * graph placement is a run-time option: host RAM + C++ walker (BANG_Base) or HBM-resident
 //    (BANG_Inmemory placement) with the identical search semantics, hence identical results.
 //  * there is NO CPU fallback: without a HIP device every call fails with BANG_ERR_NOGPU.
@@ -21,11 +25,15 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <immintrin.h>
 #include <thread>
 #include <vector>
 
@@ -91,17 +99,41 @@ static double ms_since(Clock::time_point t0) {
 
 struct Lane {
   uint32_t q0 = 0, nq = 0;
+  int index = 0;
   hipStream_t s_main = nullptr, s_fp = nullptr;
   hipEvent_t ev_front = nullptr, ev_fp = nullptr;
   std::vector<hipEvent_t> tev;      // timing events (pairs), "timing"=1
   size_t tev_used = 0;
   std::vector<int> tev_kind;        // 0 front, 1 back, 2 rerank
+  // walker team of this lane: the lane thread + (threads-1) helpers, spin-synchronised while a query runs
+  std::vector<std::thread> helpers;
+  std::atomic<uint32_t> epoch{0};
+  std::atomic<uint32_t> pending{0};
+  std::atomic<bool> team_active{false};
+  uint32_t job_row = 0;
+  bool job_adj = false;
+  std::atomic<uint32_t> job_active{0}, job_parents{0};
+  std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
+  std::atomic<uint32_t> phase_iter{0};
   // results of the last run
   int rc = BANG_OK;
   std::string err;
   uint32_t iterations = 0;
   uint64_t front_launches = 0;
   double walker_ms = 0, front_ms = 0, back_ms = 0, rerank_ms = 0, sync_ms = 0, enqueue_ms = 0;
+};
+
+struct Pool {                       // persistent lane threads, woken once per bang_query
+  std::mutex m;
+  std::condition_variable cv_start, cv_done, cv_team;
+  uint64_t query_seq = 0;
+  int lanes_done = 0;
+  bool shutdown = false;
+  const void* h_queries = nullptr;
+  uint64_t* h_ids = nullptr;
+  float* h_dists = nullptr;
+  int Q = 0;
+  std::vector<std::thread> lane_threads;
 };
 
 }  // namespace
@@ -112,7 +144,7 @@ struct bang_engine {
   // options
   int graph_mode = BANG_GRAPH_HOST;
   int lanes_opt = 0;      // 0 = auto
-  int threads_opt = 1;
+  int threads_opt = 2;    // walker threads per lane (lane thread + helpers)
   int device = 0;
   int pq_mode = 0;        // 0 auto (pivot-stationary if possible), 1 force LUT path
   int timing = 0;
@@ -148,7 +180,6 @@ struct bang_engine {
   float* d_qc = nullptr;
   float* d_lut = nullptr;
   uint32_t* d_bloom = nullptr;
-  uint32_t* d_stage = nullptr;
   uint32_t* d_nbrs = nullptr;
   float* d_dist = nullptr;
   uint32_t* d_cnt = nullptr;
@@ -170,7 +201,17 @@ struct bang_engine {
   uint32_t* h_stage = nullptr;         // pinned [Q][65]
   uint64_t* d_ids_out = nullptr;
   float* d_dists_out = nullptr;
-  std::vector<Lane> lanes;
+  std::vector<std::unique_ptr<Lane>> lanes;
+  Pool pool;
+  uint32_t* d_stage = nullptr;         // [Q][65] device copy of the staged adjacency rows (one H2D per lane and iteration)
+  uint32_t* h_done = nullptr;          // mapped pinned [lanes*16]: completion flags written by the front kernel
+  uint32_t* h_done_dev = nullptr;
+  uint32_t* d_done_count = nullptr;    // [lanes*16] device arrival counters
+  int stage_zero_copy = 1;             // 1: the front kernel reads the staged rows in place from mapped pinned memory
+  uint32_t* h_stage_dev = nullptr;     // device alias of h_stage
+  int use_flag = 1;                    // 0: wait for the front kernel with hipStreamSynchronize + D2H copy of the parents (debug/ablation)
+  int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
+  int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
   bang_stats stats{};
 };
 
@@ -284,8 +325,12 @@ void unload_index(bang_engine* e) {
   e->loaded = false;
 }
 
+void stop_threads(bang_engine* e);
+
 void free_batch(bang_engine* e) {
-  for (Lane& ln : e->lanes) {
+  stop_threads(e);
+  for (auto& lp : e->lanes) {
+    Lane& ln = *lp;
     if (ln.s_main) (void)hipStreamDestroy(ln.s_main);
     if (ln.s_fp) (void)hipStreamDestroy(ln.s_fp);
     if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
@@ -293,14 +338,17 @@ void free_batch(bang_engine* e) {
     for (hipEvent_t ev : ln.tev) if (ev) (void)hipEventDestroy(ev);
   }
   e->lanes.clear();
-  dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_stage); dfree(e->d_nbrs);
+  dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
   dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
+  dfree(e->d_done_count); dfree(e->d_stage);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_fp) (void)hipHostFree(e->h_fp);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
-  e->h_parents = nullptr; e->d_parents_map = nullptr; e->h_fp = nullptr; e->h_stage = nullptr;
+  if (e->h_done) (void)hipHostFree(e->h_done);
+  e->h_parents = nullptr; e->d_parents_map = nullptr; e->h_fp = nullptr; e->h_stage = nullptr; e->h_stage_dev = nullptr;
+  e->h_done = nullptr; e->h_done_dev = nullptr;
   e->allocated = false;
   e->inited = false;
 }
@@ -379,19 +427,14 @@ int load_files(bang_engine* e, const char* prefix) {
 }
 
 // ------------------------------------------------------------------ the search loop of one lane
-struct LaneCtx {
-  bang_engine* e;
-  Lane* ln;
-  bang_iter_params p;   // pointers already offset to the lane's first query
-};
-
 void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   const size_t q0 = ln.q0;
   memset(&p, 0, sizeof(p));
   p.Q = ln.nq; p.R = e->R; p.m = e->m; p.L = (uint32_t)e->L; p.medoid = (uint32_t)e->medoid;
   p.psz = e->psz; p.mp = e->mp;
   p.max_wgs = e->front_wgs;
-  p.d_stage = e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr;
+  p.d_stage = e->stage_zero_copy ? (e->h_stage_dev ? e->h_stage_dev + q0 * BANG_STAGE_STRIDE : nullptr)
+                                 : (e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr);
   p.d_seed = e->d_seed;
   p.d_codes = e->d_codes;
   p.d_pivots_packed = e->d_pivots_packed;
@@ -409,12 +452,17 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   p.d_wl_vis = e->d_wl_vis + q0 * e->L;
   p.d_wl_cnt = e->d_wl_cnt + q0;
   p.d_mark = e->d_mark + q0;
-  p.d_parents = (e->graph_mode == BANG_GRAPH_DEVICE ? e->d_parents_dev : e->d_parents_map) + q0;
+  p.d_parents = e->d_parents_dev + q0;
   p.d_cand_ids = e->d_cand_ids + q0 * e->cand_stride;
   p.d_cand_row = e->d_cand_row ? e->d_cand_row + q0 * e->cand_stride : nullptr;
   p.d_cand_cnt = e->d_cand_cnt + q0;
   p.d_active = nullptr;
   p.d_qstats = e->d_qstats + q0 * 2;
+  if (e->graph_mode != BANG_GRAPH_DEVICE && e->use_flag) {
+    p.d_done_count = e->d_done_count + (size_t)ln.index * 16;
+    p.h_done_flag = e->h_done_dev + (size_t)ln.index * 16;
+    p.h_parents = e->d_parents_map + q0;
+  }
 }
 
 hipEvent_t timing_begin(bang_engine* e, Lane& ln, int kind) {
@@ -431,10 +479,11 @@ void timing_end(bang_engine* e, Lane& ln, hipEvent_t a) {
   (void)e;
 }
 
-// Host graph walker for one lane and one iteration (bang_search.cu:771-813): for every query with a
-// parent copy the parent's full-precision vector into the vector log row `row` and its adjacency
-// list into the staging row.  Returns the number of queries that are still active.
-uint32_t walk(bang_engine* e, const Lane& ln, uint32_t row, bool adjacency, uint32_t* n_parents) {
+// Host graph walker (bang_search.cu:771-813) for queries [i0, i1) of a lane: for every query with a parent copy
+// the parent's full-precision vector into row `row` of the vector log and its adjacency list into the staging
+// row (both mapped pinned memory).  Counts queries that are still active / have a parent.
+void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32_t row, bool adjacency,
+                uint32_t* n_active, uint32_t* n_parents) {
   const size_t vb = vec_bytes(e);
   const uint64_t elen = e->entry_len;
   const uint8_t* graph = e->graph;
@@ -443,16 +492,16 @@ uint32_t walk(bang_engine* e, const Lane& ln, uint32_t row, bool adjacency, uint
   uint8_t* fp_row = e->h_fp + ((size_t)row * e->Qcur + ln.q0) * vb;
   const uint32_t R = e->R;
   uint32_t active = 0, np = 0;
-  const uint32_t PF = 8;
-  for (uint32_t i = 0; i < ln.nq && i < PF; ++i) {
+  const uint32_t PF = 8;                                   // software prefetch distance (entries are 388-644 B)
+  for (uint32_t i = i0; i < i1 && i < i0 + PF; ++i) {
     const uint32_t par = parents[i];
     if (par < BANG_IDLE_PARENT) {
       const uint8_t* ent = graph + (uint64_t)par * elen;
       for (uint64_t o = 0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
     }
   }
-  for (uint32_t i = 0; i < ln.nq; ++i) {
-    if (i + PF < ln.nq) {
+  for (uint32_t i = i0; i < i1; ++i) {
+    if (i + PF < i1) {
       const uint32_t par = parents[i + PF];
       if (par < BANG_IDLE_PARENT) {
         const uint8_t* ent = graph + (uint64_t)par * elen;
@@ -478,8 +527,65 @@ uint32_t walk(bang_engine* e, const Lane& ln, uint32_t row, bool adjacency, uint
       if (par == BANG_IDLE_PARENT) ++active;
     }
   }
+  *n_active = active;
   *n_parents = np;
-  return active;
+}
+
+inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
+  *i0 = (uint32_t)((uint64_t)ln.nq * (uint32_t)t / (uint32_t)T);
+  *i1 = (uint32_t)((uint64_t)ln.nq * (uint32_t)(t + 1) / (uint32_t)T);
+}
+
+// helper thread t (1..T-1) of a lane's walker team
+// `seen` = the lane's job epoch at the time the thread was CREATED (captured by the creator: reading it here
+// would race with a first job posted before this thread gets to run, and that job would never be done)
+void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
+  Pool& pool = e->pool;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(pool.m);
+      pool.cv_team.wait(lk, [&] { return pool.shutdown || ln->team_active.load(std::memory_order_acquire); });
+      if (pool.shutdown) return;
+    }
+    while (ln->team_active.load(std::memory_order_acquire)) {
+      const uint32_t ep = ln->epoch.load(std::memory_order_acquire);
+      if (ep != seen) {
+        seen = ep;
+        uint32_t i0, i1, a = 0, np = 0;
+        slice_of(*ln, t, T, &i0, &i1);
+        walk_slice(e, *ln, i0, i1, ln->job_row, ln->job_adj, &a, &np);
+        ln->job_active.fetch_add(a, std::memory_order_relaxed);
+        ln->job_parents.fetch_add(np, std::memory_order_relaxed);
+        ln->pending.fetch_sub(1, std::memory_order_release);
+      } else {
+        _mm_pause();
+      }
+    }
+  }
+}
+
+// walk the whole lane with its team; returns the number of active queries
+uint32_t walk(bang_engine* e, Lane& ln, uint32_t row, bool adjacency, uint32_t* n_parents) {
+  ln.phase.store(2);
+  const int T = 1 + (int)ln.helpers.size();
+  ln.job_row = row;
+  ln.job_adj = adjacency;
+  ln.job_active.store(0, std::memory_order_relaxed);
+  ln.job_parents.store(0, std::memory_order_relaxed);
+  if (T > 1) {
+    ln.pending.store((uint32_t)(T - 1), std::memory_order_relaxed);
+    ln.epoch.fetch_add(1, std::memory_order_release);
+  }
+  uint32_t i0, i1, a = 0, np = 0;
+  slice_of(ln, 0, T, &i0, &i1);
+  walk_slice(e, ln, i0, i1, row, adjacency, &a, &np);
+  if (T > 1) {
+    ln.phase.store(3);
+    while (ln.pending.load(std::memory_order_acquire) != 0) _mm_pause();
+  }
+  ln.phase.store(4);
+  *n_parents = np + ln.job_parents.load(std::memory_order_relaxed);
+  return a + ln.job_active.load(std::memory_order_relaxed);
 }
 
 #define LANE_HIP(x)                                                                               \
@@ -491,7 +597,43 @@ uint32_t walk(bang_engine* e, const Lane& ln, uint32_t row, bool adjacency, uint
     }                                                                                             \
   } while (0)
 
+// spin until the front kernel of iteration `value` has published its completion flag (no HIP call)
+int wait_flag(bang_engine* e, Lane& ln, uint32_t value) {
+  ln.phase.store(1); ln.phase_iter.store(value);
+  if (!e->use_flag) {                                  // ablation path: runtime calls instead of the in-kernel signal
+    const auto t0 = Clock::now();
+    if (hipMemcpyAsync(e->h_parents + ln.q0, e->d_parents_dev + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main) != hipSuccess ||
+        hipStreamSynchronize(ln.s_main) != hipSuccess) { bang_set_error("parent copy failed"); return BANG_ERR_HIP; }
+    ln.sync_ms += ms_since(t0);
+    return BANG_OK;
+  }
+  volatile uint32_t* flag = e->h_done + (size_t)ln.index * 16;
+  const auto t0 = Clock::now();
+  uint32_t spins = 0;
+  while (*flag != value) {
+    _mm_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      if (ms_since(t0) > 20000.0) {
+        bang_set_error("timeout waiting for the front kernel of iteration %u (lane %d)", value, ln.index);
+        return BANG_ERR_HIP;
+      }
+      const hipError_t st = hipStreamQuery(ln.s_main);
+      if (st != hipSuccess && st != hipErrorNotReady) {
+        bang_set_error("stream error while waiting for iteration %u: %s", value, hipGetErrorString(st));
+        return BANG_ERR_HIP;
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  ln.sync_ms += ms_since(t0);
+  return BANG_OK;
+}
+
+static int g_dbg = -1;
+#define DBG(...) do { if (g_dbg < 0) g_dbg = getenv("BANG_DEBUG") ? 1 : 0; if (g_dbg) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+
 int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, float* h_dists, int Q) {
+  DBG("[lane %d] start q0=%u nq=%u\n", ln.index, ln.q0, ln.nq);
   LANE_HIP(hipSetDevice(e->device));
   const bool dev_graph = (e->graph_mode == BANG_GRAPH_DEVICE);
   const uint32_t dim_adjust = (e->distfn == BANG_DIST_MIPS) ? 1u : 0u;      // :631
@@ -506,6 +648,11 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
 #define ENQ_END() (ln.enqueue_ms += ms_since(t_enq))
   bang_iter_params p;
   fill_params(e, ln, p);
+  if (!dev_graph) e->h_done[(size_t)ln.index * 16] = 0;
+  if (!dev_graph && e->stagger_us > 0 && ln.index > 0) {
+    const auto ts = Clock::now();
+    while (ms_since(ts) * 1000.0 < (double)(e->stagger_us * ln.index)) _mm_pause();
+  }
 
   // queries H2D (:612) + K1 (:623)
   uint8_t* dq = (uint8_t*)e->d_queries + (size_t)ln.q0 * qbytes;
@@ -519,7 +666,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                               e->D, e->m, dim_adjust, ln.s_main));
 
   uint32_t iter = 1;                                                         // :596
-  p.first = 1; p.iter = iter;
+  p.first = 1; p.iter = iter; p.done_value = iter;
   if (dev_graph) p.d_active = e->d_active + iter;
   {
     hipEvent_t t = timing_begin(e, ln, 0);
@@ -527,9 +674,20 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     timing_end(e, ln, t);
     ++ln.front_launches;
   }
-  if (!dev_graph) LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
 
-  bool fp_pending = false;
+  // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
+  uint32_t fp_lo = 0, fp_hi = 0;
+  bool fp_pending = false, fp_any = false;
+  auto flush_fp = [&]() -> int {                                             // :836-838, batched
+    if (!fp_pending) return BANG_OK;
+    const size_t off = ((size_t)fp_lo * e->Qcur + ln.q0) * vb;
+    LANE_HIP(hipMemcpy2DAsync(e->d_fp + off, (size_t)e->Qcur * vb, e->h_fp + off, (size_t)e->Qcur * vb,
+                              (size_t)ln.nq * vb, (size_t)(fp_hi - fp_lo + 1), hipMemcpyHostToDevice, ln.s_fp));
+    fp_pending = false;
+    fp_any = true;
+    return BANG_OK;
+  };
+
   for (;;) {
     p.first = 0; p.iter = iter;
     ENQ_BEGIN();
@@ -540,48 +698,45 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     }
     ENQ_END();
     if (!dev_graph) {
-      {
-        const auto ts = Clock::now();
-        LANE_HIP(hipEventSynchronize(ln.ev_front));                          // parents of this iteration are in h_parents
-        ln.sync_ms += ms_since(ts);
-      }
+      DBG("[lane %d] wait flag %u\n", ln.index, iter);
+      BANG_TRY(wait_flag(e, ln, iter));                                      // parents of this iteration are in h_parents :709,763
+      DBG("[lane %d] got flag %u\n", ln.index, iter);
       const auto t0 = Clock::now();
       uint32_t n_par = 0;
       const uint32_t active = walk(e, ln, iter, true, &n_par);               // CPU walker :771-813
       ln.walker_ms += ms_since(t0);
+      if (n_par) {
+        if (!fp_pending) { fp_lo = iter; fp_pending = true; }
+        fp_hi = iter;
+      }
       if (active == 0) break;                                                // :958
       ENQ_BEGIN();
-      LANE_HIP(hipMemcpyAsync((void*)p.d_stage, e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
+      if (!e->stage_zero_copy)
+      LANE_HIP(hipMemcpyAsync((void*)(e->d_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE), e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
                               (size_t)ln.nq * BANG_STAGE_STRIDE * 4, hipMemcpyHostToDevice, ln.s_main));   // :827-833
-      if (n_par) {
-        const size_t off = ((size_t)iter * e->Qcur + ln.q0) * vb;
-        LANE_HIP(hipMemcpyAsync(e->d_fp + off, e->h_fp + off, (size_t)ln.nq * vb, hipMemcpyHostToDevice, ln.s_fp)); // :836-838
-        fp_pending = true;
-      }
       ENQ_END();
+      if (fp_pending && fp_hi - fp_lo + 1 >= (uint32_t)e->fp_batch) { ENQ_BEGIN(); BANG_TRY(flush_fp()); ENQ_END(); }
     }
     ++iter;                                                                  // :879
-    p.iter = iter;
+    p.iter = iter; p.done_value = iter;
     if (dev_graph) p.d_active = e->d_active + iter;
     ENQ_BEGIN();
     {
       hipEvent_t t = timing_begin(e, ln, 0);
-      BANG_TRY(bang_k_front(&p, ln.s_main));                                 // K5+K2+K4b :855-917
+      BANG_TRY(bang_k_front(&p, ln.s_main));                                 // K5+K2+K4b :855-917 
       timing_end(e, ln, t);
       ++ln.front_launches;
     }
-    if (!dev_graph) LANE_HIP(hipEventRecord(ln.ev_front, ln.s_main));
     ENQ_END();
     if (!dev_graph) {
       if (iter == cap_iter) {                                                // :950-956
         // CANON: the vectors of the parents chosen at the cap are still fetched for the re-rank
-        LANE_HIP(hipEventSynchronize(ln.ev_front));
+        BANG_TRY(wait_flag(e, ln, iter));
         uint32_t n_par = 0;
         (void)walk(e, ln, iter, false, &n_par);
         if (n_par) {
-          const size_t off = ((size_t)iter * e->Qcur + ln.q0) * vb;
-          LANE_HIP(hipMemcpyAsync(e->d_fp + off, e->h_fp + off, (size_t)ln.nq * vb, hipMemcpyHostToDevice, ln.s_fp));
-          fp_pending = true;
+          if (!fp_pending) { fp_lo = iter; fp_pending = true; }
+          fp_hi = iter;
         }
         break;
       }
@@ -596,9 +751,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     }
   }
   ln.iterations = iter;
+  ln.phase.store(5);
+  DBG("[lane %d] loop done iter=%u\n", ln.index, iter);
+  BANG_TRY(flush_fp());
 
   // re-rank K6+K7 (:967-987)
-  if (fp_pending) {
+  if (fp_any) {
     LANE_HIP(hipEventRecord(ln.ev_fp, ln.s_fp));
     LANE_HIP(hipStreamWaitEvent(ln.s_main, ln.ev_fp, 0));
   }
@@ -619,7 +777,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                           (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
+  ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
+  ln.phase.store(7);
+  DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;
   for (size_t i = 0; i + 1 < ln.tev_used; i += 2) {
     float ms = 0;
@@ -629,6 +790,69 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     }
   }
   return BANG_OK;
+}
+
+// one lane's work for the current query, with its walker team switched on for the duration
+void lane_job(bang_engine* e, Lane& ln) {
+  Pool& pool = e->pool;
+  if (ln.nq == 0) { ln.rc = BANG_OK; return; }
+  if (!ln.helpers.empty()) {
+    { std::lock_guard<std::mutex> lk(pool.m); ln.team_active.store(true, std::memory_order_release); }
+    pool.cv_team.notify_all();
+  }
+  ln.rc = lane_run(e, ln, pool.h_queries, pool.h_ids, pool.h_dists, pool.Q);
+  if (ln.rc != BANG_OK) ln.err = bang_last_error();
+  ln.team_active.store(false, std::memory_order_release);
+}
+
+void lane_thread_main(bang_engine* e, Lane* ln) {
+  Pool& pool = e->pool;
+  uint64_t seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(pool.m);
+      pool.cv_start.wait(lk, [&] { return pool.shutdown || pool.query_seq != seen; });
+      if (pool.shutdown) return;
+      seen = pool.query_seq;
+    }
+    lane_job(e, *ln);
+    {
+      std::lock_guard<std::mutex> lk(pool.m);
+      ++pool.lanes_done;
+    }
+    pool.cv_done.notify_all();
+  }
+}
+
+void start_threads(bang_engine* e) {
+  Pool& pool = e->pool;
+  pool.shutdown = false;
+  pool.query_seq = 0;
+  const int nl = (int)e->lanes.size();
+  const int T = std::max(1, e->threads_opt);
+  for (int i = 0; i < nl; ++i) {
+    Lane* ln = e->lanes[(size_t)i].get();
+    const uint32_t epoch0 = ln->epoch.load(std::memory_order_acquire);
+    for (int t = 1; t < T; ++t) ln->helpers.emplace_back(helper_main, e, ln, t, T, epoch0);
+    if (i > 0) pool.lane_threads.emplace_back(lane_thread_main, e, ln);      // lane 0 runs on the caller's thread
+  }
+}
+
+void stop_threads(bang_engine* e) {
+  Pool& pool = e->pool;
+  {
+    std::lock_guard<std::mutex> lk(pool.m);
+    pool.shutdown = true;
+  }
+  pool.cv_start.notify_all();
+  pool.cv_team.notify_all();
+  for (auto& t : pool.lane_threads) t.join();
+  pool.lane_threads.clear();
+  for (auto& lp : e->lanes) {
+    for (auto& t : lp->helpers) t.join();
+    lp->helpers.clear();
+  }
+  pool.shutdown = false;
 }
 
 }  // namespace
@@ -645,6 +869,11 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   // BANG_LANES=n, BANG_DEVICE=ordinal, BANG_PQ=0|1, BANG_TIMING=0|1
   if (const char* v = getenv("BANG_GRAPH")) e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
   if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
+  if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(1, atoi(v));
+  if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
+  if (const char* v = getenv("BANG_FP_BATCH")) e->fp_batch = std::max(1, atoi(v));
   if (const char* v = getenv("BANG_DEVICE")) e->device = atoi(v);
   if (const char* v = getenv("BANG_PQ")) e->pq_mode = atoi(v);
   if (const char* v = getenv("BANG_TIMING")) e->timing = atoi(v);
@@ -669,6 +898,9 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
   else if (k == "timing") { e->timing = (int)value; }
+  else if (k == "stage_zero_copy") { e->stage_zero_copy = value ? 1 : 0; }
+  else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
+  else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
   else { bang_set_error("unknown option %s", key); return BANG_ERR_ARG; }
@@ -735,22 +967,32 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
   BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
+  BANG_TRY(dmalloc(&e->d_parents_dev, nq));
   if (dev_graph) {
-    BANG_TRY(dmalloc(&e->d_parents_dev, nq));
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {
-    BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
     BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
     HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                    // :398
     HIP_TRY(hipHostMalloc((void**)&e->h_parents, nq * 4, hipHostMallocMapped));              // :419
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
-    HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocDefault));     // :416
+    HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocMapped));      // :416
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->h_stage_dev, e->h_stage, 0));
+    BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
+    memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
     HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
   }
   int nl = e->lanes_opt;
-  if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(8, Q / 512));
+  if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  e->lanes.resize((size_t)nl);
+  if (!dev_graph) {
+    HIP_TRY(hipHostMalloc((void**)&e->h_done, (size_t)nl * 16 * 4, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->h_done_dev, e->h_done, 0));
+    memset(e->h_done, 0, (size_t)nl * 16 * 4);
+    BANG_TRY(dmalloc(&e->d_done_count, (size_t)nl * 16));
+    HIP_TRY(hipMemset(e->d_done_count, 0, (size_t)nl * 16 * 4));
+  }
+  e->lanes.clear();
+  for (int i = 0; i < nl; ++i) e->lanes.emplace_back(new Lane());
   {
     int dev_id = 0, cus = 256;
     hipDeviceProp_t prop;
@@ -758,7 +1000,8 @@ static int alloc_buffers(bang_engine* e, int Q) {
     e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::max(1, cus / nl) : 0);
   }
   for (int i = 0; i < nl; ++i) {
-    Lane& ln = e->lanes[(size_t)i];
+    Lane& ln = *e->lanes[(size_t)i];
+    ln.index = i;
     HIP_TRY(hipStreamCreateWithFlags(&ln.s_main, hipStreamNonBlocking));     // :407-410
     HIP_TRY(hipStreamCreateWithFlags(&ln.s_fp, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
@@ -769,6 +1012,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
       for (hipEvent_t& ev : ln.tev) HIP_TRY(hipEventCreate(&ev));
     }
   }
+  start_threads(e);
   return BANG_OK;
 }
 
@@ -809,31 +1053,54 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   e->inited = false;   // state is consumed
   e->Qcur = Q;
   const auto t0 = Clock::now();
-  // lanes were laid out for Qcap; re-slice for this Q
   const int nl = (int)e->lanes.size();
-  for (int i = 0; i < nl; ++i) {
-    Lane& ln = e->lanes[(size_t)i];
+  for (int i = 0; i < nl; ++i) {                       // lanes were laid out for Qcap; re-slice for this Q
+    Lane& ln = *e->lanes[(size_t)i];
     ln.q0 = (uint32_t)((size_t)Q * i / nl);
     ln.nq = (uint32_t)((size_t)Q * (i + 1) / nl) - ln.q0;
   }
-  // NOTE: the vector log / dist output use row stride Qcap / Q respectively; log rows use Qcap.
-  std::vector<std::thread> th;
-  auto body = [&](Lane* ln) {
-    if (ln->nq == 0) { ln->rc = BANG_OK; return; }
-    ln->rc = lane_run(e, *ln, h_queries, h_ids, h_dists, Q);
-    if (ln->rc != BANG_OK) ln->err = bang_last_error();
-  };
-  for (int i = 1; i < nl; ++i) th.emplace_back(body, &e->lanes[(size_t)i]);
-  body(&e->lanes[0]);
-  for (auto& t : th) t.join();
+  std::atomic<bool> wd_stop{false};
+  std::thread wd;
+  if (getenv("BANG_WATCHDOG")) {
+    wd = std::thread([&] {
+      FILE* wf = fopen(getenv("BANG_WATCHDOG"), "a");
+      if (!wf) wf = stderr;
+      int ticks = 0;
+      while (!wd_stop.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (++ticks % 50 == 0) {
+          for (auto& lp : e->lanes)
+            fprintf(wf, "[watchdog] lane %d phase %d iter %u pending %u epoch %u flag %u active %d\n", lp->index, lp->phase.load(),
+                    lp->phase_iter.load(), lp->pending.load(), lp->epoch.load(), e->h_done ? e->h_done[(size_t)lp->index * 16] : 0u,
+                    (int)lp->team_active.load());
+          fflush(wf);
+        }
+      }
+      if (wf != stderr) fclose(wf);
+    });
+  }
+  Pool& pool = e->pool;
+  {
+    std::lock_guard<std::mutex> lk(pool.m);
+    pool.h_queries = h_queries; pool.h_ids = h_ids; pool.h_dists = h_dists; pool.Q = Q;
+    pool.lanes_done = 0;
+    ++pool.query_seq;
+  }
+  pool.cv_start.notify_all();
+  lane_job(e, *e->lanes[0]);                           // lane 0 on the calling thread
+  if (nl > 1) {
+    std::unique_lock<std::mutex> lk(pool.m);
+    pool.cv_done.wait(lk, [&] { return pool.lanes_done == nl - 1; });
+  }
+  if (wd.joinable()) { wd_stop.store(true); wd.join(); }
   int rc = BANG_OK;
-  for (Lane& ln : e->lanes)
-    if (ln.rc != BANG_OK) { rc = ln.rc; bang_set_error("%s", ln.err.c_str()); break; }
-  // stats
+  for (auto& lp : e->lanes)
+    if (lp->rc != BANG_OK) { rc = lp->rc; bang_set_error("%s", lp->err.c_str()); break; }
   bang_stats& s = e->stats;
   memset(&s, 0, sizeof(s));
   s.wall_ms = ms_since(t0);
-  for (Lane& ln : e->lanes) {
+  for (auto& lp : e->lanes) {
+    Lane& ln = *lp;
     s.iterations = std::max<uint64_t>(s.iterations, ln.iterations);
     s.front_launches += ln.front_launches;
     s.front_ms += ln.front_ms; s.back_ms += ln.back_ms; s.rerank_ms += ln.rerank_ms; s.walker_ms += ln.walker_ms;

@@ -100,28 +100,40 @@ __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, cf
 // NDW = number of code dwords per row after padding the chunk count to MP = 4*NDW (the padding
 // chunks are all-zero in the packed pivot table and in qc, so they add fmaf(0,0,0) = +0).
 // ALIGNED = (m % 4 == 0): rows start dword-aligned, no funnel shift needed.
-// The loop is straight-line (no guards) so the compiler can batch the LDS reads and scalar loads.
-template <int PSZ, int NDW, bool ALIGNED>
-__device__ __forceinline__ float pq_distance(const uint8_t* __restrict__ codes, uint32_t m, uint32_t id,
-                                             const float* __restrict__ piv_lds, cfloat_p qc) {
-  const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
-  const uint32_t sh = (uint32_t)a & 3u;
-  constexpr int NLOAD = ALIGNED ? NDW : NDW + 1;      // dwords needed from the aligned base
-  constexpr int NX4 = (NLOAD + 3) / 4;
-  const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
+// A code row is fetched with 16-byte loads from its 4-byte-aligned base (pq_row_load) and consumed by
+// straight-line code (pq_row_reduce) so that the compiler can batch the LDS reads and scalar loads;
+// splitting load from use lets the caller put another query's row in flight first.
+template <int NDW, bool ALIGNED>
+struct PqRow {
+  static constexpr int NLOAD = ALIGNED ? NDW : NDW + 1;   // dwords needed from the aligned base
+  static constexpr int NX4 = (NLOAD + 3) / 4;
   uint32_t w[NX4 * 4 + 1];
+  uint32_t sh;
+};
+
+template <int NDW, bool ALIGNED>
+__device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_t* __restrict__ codes, uint32_t m,
+                                            uint32_t id) {
+  const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
+  r.sh = (uint32_t)a & 3u;
+  const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
 #pragma unroll
-  for (int i = 0; i < NX4; ++i) {
+  for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4; ++i) {
     const u32x4a v = p[i];
-    w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
   }
-  w[NX4 * 4] = 0;
+  r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
+}
+
+template <int PSZ, int NDW, bool ALIGNED>
+__device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds,
+                                               cfloat_p qc) {
   float s[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = 0.0f;
 #pragma unroll
   for (int k = 0; k < NDW; ++k) {
-    const uint32_t dw = ALIGNED ? w[k] : __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+    const uint32_t dw = ALIGNED ? r.w[k] : __builtin_amdgcn_alignbyte(r.w[k + 1], r.w[k], r.sh);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const uint32_t c = 4 * k + b;
@@ -168,11 +180,14 @@ struct FrontArgs {
 // per-wave LDS scratch (uint32 words): compacted ids [0..71]
 #define FRONT_SCRATCH_WORDS 72
 
-// ALL = true: the production instantiation (filter + distance + parent, no stage branches so that the
-// independent loads of a query are issued back to back).  ALL = false: stage mask taken from a.stages
-// (kernel-level parity tests).
-template <int PSZ, int NDW, bool ALIGNED, bool ALL>
-__global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
+// ALL = true: the production instantiation (filter + distance + parent, no stage branches).  ALL = false:
+// stage mask taken from a.stages (kernel-level parity tests).
+// NQW = queries a wave works on AT THE SAME TIME.  The kernel is bound by dependent memory latency (row ->
+// filter words -> code rows, ~2 us each) with at most 16 waves per CU (the pivot table owns the LDS), so every
+// phase is executed for NQW independent queries back to back: their loads are in flight together and the wave
+// pays each round trip once per NQW queries.
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT>
+__global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_iter_params& p = a.p;
   float* piv_lds = lds;
@@ -206,190 +221,308 @@ __global__ __launch_bounds__(1024) void front_kernel(const FrontArgs a) {
   const int lane = lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
-  uint32_t* scratch = scratch_all + wave * FRONT_SCRATCH_WORDS;
+  uint32_t* scratch = scratch_all + wave * (FRONT_SCRATCH_WORDS * NQW);
   const uint32_t medoid = p.medoid;
   const uint32_t L = p.L;
   const uint32_t first = p.first ? 1u : 0u;
   const uint32_t lane_l = (uint32_t)lane < L ? (uint32_t)lane : L - 1;
+  const uint32_t total_waves = gridDim.x * nwaves;
+  const uint32_t gw = blockIdx.x * nwaves + wave;
+  const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   uint32_t n_active = 0;
 
-  for (uint32_t q = blockIdx.x * nwaves + wave; q < p.Q; q += gridDim.x * nwaves) {
-    uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
-    float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
-    const uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
-    const float* wl_dist = p.d_wl_dist + (size_t)q * L;
-    const uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
-    uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
-    uint32_t n = 0;        // survivors
-    uint32_t sid0 = 0;     // lane's survivor id (index lane) ; sid1: survivor index 64 (lane 0 only)
-    uint32_t sid1 = 0;
+  for (uint32_t g0 = gw; g0 < p.Q; g0 += total_waves * NQW) {
+    uint32_t q[NQW];
+    bool valid[NQW];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) {
+      const uint32_t qq = g0 + (uint32_t)u * total_waves;
+      valid[u] = qq < p.Q;
+      q[u] = valid[u] ? qq : g0;          // invalid slots shadow slot 0: loads stay legal, every store is guarded
+    }
 
-    // ---- round trip A: every load that does not depend on another load of this query, issued
-    // unconditionally (the launcher guarantees all pointers are valid).  The worklist head needed by
-    // K4 is prefetched speculatively: the arrays always hold L valid words.
-    const uint32_t* row;   // {count, id x 64 (, 65th id for the seed list)}
-    bool have_row = true;
+    // ---- round trip A: every load that does not depend on another load of the query, issued
+    // unconditionally (the launcher guarantees all pointers are valid).  The worklist head needed by K4 is
+    // prefetched speculatively: the arrays always hold L valid words.
+    uint32_t cnt_in[NQW], x0[NQW], x1[NQW], cc[NQW], w_n[NQW], pw_vis[NQW], pw_id[NQW];
+    float pw_dist[NQW];
+    uint2 qs[NQW];
+    bool have_row[NQW];
+    const uint32_t* row[NQW];     // {count, id x 64 (, 65th id for the seed list)}
     if (p.d_graph != nullptr && !first) {  // graph resident in HBM: the parent's adjacency is read in place
-      const uint32_t par = uni(p.d_parents[q]);
-      have_row = par < BANG_IDLE_PARENT;
-      row = (const uint32_t*)(p.d_graph + (uint64_t)(have_row ? par : 0u) * p.entry_len + p.vec_bytes);
+      uint32_t par[NQW];
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) par[u] = p.d_parents[q[u]];
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        const uint32_t pr = uni(par[u]);
+        have_row[u] = pr < BANG_IDLE_PARENT;
+        row[u] = (const uint32_t*)(p.d_graph + (uint64_t)(have_row[u] ? pr : 0u) * p.entry_len + p.vec_bytes);
+      }
     } else {
       // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) or the row staged by the host walker (:827-833)
-      row = first ? p.d_seed : p.d_stage + (size_t)q * BANG_STAGE_STRIDE;
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        have_row[u] = true;
+        row[u] = first ? p.d_seed : p.d_stage + (size_t)q[u] * BANG_STAGE_STRIDE;
+      }
     }
-    uint32_t cnt_in = row[0];
-    const uint32_t x0 = row[1 + lane];                         // in bounds for every row kind (R <= 64)
-    const uint32_t x1 = row[65u * first];                      // 65th id exists only in the seed list
-    const uint32_t cc = p.d_cand_cnt[q];
-    uint32_t w_n = p.d_wl_cnt[q];
-    uint2 qs = make_uint2(0u, 0u);
-    if (p.d_qstats && lane == 0) qs = *(const uint2*)(p.d_qstats + (size_t)q * 2);
-    const uint32_t pw_vis = wl_vis[lane_l];
-    const float pw_dist = wl_dist[lane_l];
-    const uint32_t pw_id = wl_ids[lane_l];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) {
+      cnt_in[u] = row[u][0];
+      x0[u] = row[u][1 + lane];                          // in bounds for every row kind (R <= 64)
+      x1[u] = row[u][65u * first];                       // 65th id exists only in the seed list
+      cc[u] = p.d_cand_cnt[q[u]];
+      w_n[u] = p.d_wl_cnt[q[u]];
+      pw_vis[u] = p.d_wl_vis[(size_t)q[u] * L + lane_l];
+      pw_dist[u] = p.d_wl_dist[(size_t)q[u] * L + lane_l];
+      pw_id[u] = p.d_wl_ids[(size_t)q[u] * L + lane_l];
+      qs[u] = make_uint2(0u, 0u);
+      if (p.d_qstats && lane == 0) qs[u] = *(const uint2*)(p.d_qstats + (size_t)q[u] * 2);
+    }
+
+    uint32_t n[NQW], sid0[NQW], sid1[NQW];   // survivors; lane's survivor id; survivor 64 (lane 0 only)
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) { n[u] = 0; sid0[u] = 0; sid1[u] = 0; }
 
     // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
     if (do_filter) {
-      cnt_in = uni(cnt_in);
-      if (!have_row) cnt_in = 0;
-      const uint32_t cap = p.R + first;
-      if (cnt_in > cap) cnt_in = cap;
-      // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
-      const bool v0 = (uint32_t)lane < cnt_in;
-      const bool v1 = (lane == 0) && (cnt_in > 64);
+      uint32_t h0a[NQW], h0b[NQW], h1a[NQW], h1b[NQW], w0a[NQW], w0b[NQW], w1a[NQW], w1b[NQW];
       // ---- round trip B: visited-filter words (unconditional: a hash is always a valid index).
       // CANON: every id is tested against the filter state at entry (all loads before any set)
-      const uint32_t h0a = hash1(x0), h0b = hash2(x0), h1a = hash1(x1), h1b = hash2(x1);
-      const uint32_t w0a = bloom[h0a >> 5], w0b = bloom[h0b >> 5];
-      const uint32_t w1a = bloom[h1a >> 5], w1b = bloom[h1b >> 5];
-      const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
-      const bool pass1 = v1 && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
-      const uint64_t m0 = __ballot(pass0);
-      const uint64_t m1 = __ballot(pass1);
-      if (!(a.debug & 1u)) {
-      if (pass0) { atomicOr(&bloom[h0a >> 5], 1u << (h0a & 31)); atomicOr(&bloom[h0b >> 5], 1u << (h0b & 31)); }
-      if (pass1) { atomicOr(&bloom[h1a >> 5], 1u << (h1a & 31)); atomicOr(&bloom[h1b >> 5], 1u << (h1b & 31)); }
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        const uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
+        h0a[u] = hash1(x0[u]); h0b[u] = hash2(x0[u]); h1a[u] = hash1(x1[u]); h1b[u] = hash2(x1[u]);
+        if (a.debug & 8u) { w0a[u] = w0b[u] = w1a[u] = w1b[u] = 0; }
+        else {
+        w0a[u] = bloom[h0a[u] >> 5]; w0b[u] = bloom[h0b[u] >> 5];
+        w1a[u] = bloom[h1a[u] >> 5]; w1b[u] = bloom[h1b[u] >> 5];
+        }
       }
-      const uint32_t n0 = (uint32_t)__popcll(m0);
-      n = n0 + (uint32_t)__popcll(m1);
-      // ordered compaction through LDS: survivors keep input order (CANON; reference uses atomicAdd
-      // order :1161).  One wave executes in order, so no fence is needed between the write and the read.
-      if (pass0) scratch[lanes_below(m0)] = x0;
-      if (pass1) scratch[n0] = x1;
-      wave_sync();
-      if ((uint32_t)lane < n) { sid0 = scratch[lane]; nbrs[lane] = sid0; }
-      if (lane == 0 && n > 64) { sid1 = scratch[64]; nbrs[64] = sid1; }
-      if (lane == 0) {
-        p.d_cnt[q] = n;
-        if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(qs.x + n, qs.y + cnt_in);
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
+        uint32_t* sc = scratch + u * FRONT_SCRATCH_WORDS;
+        uint32_t ci = uni(cnt_in[u]);
+        if (!have_row[u] || !valid[u]) ci = 0;
+        const uint32_t cap = p.R + first;
+        if (ci > cap) ci = cap;
+        cnt_in[u] = ci;
+        // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
+        const bool v0 = (uint32_t)lane < ci;
+        const bool v1 = (lane == 0) && (ci > 64);
+        const bool pass0 = v0 && !(((w0a[u] >> (h0a[u] & 31)) & 1u) && ((w0b[u] >> (h0b[u] & 31)) & 1u));
+        const bool pass1 = v1 && !(((w1a[u] >> (h1a[u] & 31)) & 1u) && ((w1b[u] >> (h1b[u] & 31)) & 1u));
+        const uint64_t m0 = __ballot(pass0);
+        const uint64_t m1 = __ballot(pass1);
+        const uint32_t n0 = (uint32_t)__popcll(m0);
+        n[u] = n0 + (uint32_t)__popcll(m1);
+        // ordered compaction through LDS: survivors keep input order (CANON; reference uses atomicAdd
+        // order :1161).  One wave executes in order, so no fence is needed between the write and the read.
+        if (pass0) sc[lanes_below(m0)] = x0[u];
+        if (pass1) sc[n0] = x1[u];
+        wave_sync();
+        if ((uint32_t)lane < n[u]) sid0[u] = sc[lane];
+        if (lane == 0 && n[u] > 64) sid1[u] = sc[64];
+        // the filter updates are issued AFTER everything the distance stage needs from LDS; they are
+        // fire-and-forget (no return value)
+        if (!(a.debug & 1u)) {
+          if (pass0) { atomicOr(&bloom[h0a[u] >> 5], 1u << (h0a[u] & 31)); atomicOr(&bloom[h0b[u] >> 5], 1u << (h0b[u] & 31)); }
+          if (pass1) { atomicOr(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); atomicOr(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
+        }
       }
-      wave_sync();
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        if (valid[u]) {
+          uint32_t* nbrs = p.d_nbrs + (size_t)q[u] * BANG_NBR_STRIDE;
+          if ((uint32_t)lane < n[u]) nbrs[lane] = sid0[u];
+          if (lane == 0) {
+            if (n[u] > 64) nbrs[64] = sid1[u];
+            p.d_cnt[q[u]] = n[u];
+            if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q[u] * 2) = make_uint2(qs[u].x + n[u], qs[u].y + cnt_in[u]);
+          }
+        }
+      }
     } else {
-      n = uni(p.d_cnt[q]);
-      if ((uint32_t)lane < n) sid0 = nbrs[lane];
-      if (lane == 0 && n > 64) sid1 = nbrs[64];
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        const uint32_t* nbrs = p.d_nbrs + (size_t)q[u] * BANG_NBR_STRIDE;
+        n[u] = valid[u] ? uni(p.d_cnt[q[u]]) : 0u;
+        if ((uint32_t)lane < n[u]) sid0[u] = nbrs[lane];
+        if (lane == 0 && n[u] > 64) sid1[u] = nbrs[64];
+      }
     }
 
     // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
-    float d0 = BIG_DIST, d1 = BIG_DIST;
+    float d0[NQW], d1[NQW];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) { d0[u] = BIG_DIST; d1[u] = BIG_DIST; }
     if (do_dist) {
-      cfloat_p qc = (cfloat_p)(uintptr_t)(PSZ > 0 ? p.d_qc + (size_t)q * (NDW * 4 * (PSZ > 0 ? PSZ : 1)) : nullptr);
-      const float* lut = (PSZ == 0) ? p.d_lut + (size_t)q * p.m * 256 : nullptr;
-      // ---- round trip C: the code rows.  pass 0: survivors 0..63 (one per lane); pass 1: survivor 64
-      // (seed list only), lane 0
-      for (uint32_t base = 0; base < n; base += WAVE) {
-        const uint32_t id = base ? sid1 : sid0;
-        if (base + (uint32_t)lane < n) {
-          float d;
-          if (a.debug & 2u) d = (float)id;
-          else if constexpr (PSZ > 0) d = pq_distance<(PSZ > 0 ? PSZ : 1), NDW, ALIGNED>(p.d_codes, p.m, id, piv_lds, qc);
-          else d = pq_distance_lut(p.d_codes, p.m, id, lut);
-          dist[base + lane] = d;
-          if (base) d1 = d; else d0 = d;
+      if constexpr (PSZ > 0) {
+        // ---- round trip C: the code rows, software pipelined over the NQW queries
+        PqRow<NDW, ALIGNED> rows[2];
+        if ((uint32_t)lane < n[0]) pq_row_load(rows[0], p.d_codes, p.m, sid0[0]);
+#pragma unroll
+        for (int u = 0; u < NQW; ++u) {
+          if (u + 1 < NQW) {
+            if ((uint32_t)lane < n[u + 1]) pq_row_load(rows[(u + 1) & 1], p.d_codes, p.m, sid0[u + 1]);
+          }
+          cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q[u] * (NDW * 4 * PSZ));
+          if ((uint32_t)lane < n[u]) {
+            float d = pq_row_reduce<PSZ, NDW, ALIGNED>(rows[u & 1], piv_lds, qc);
+            if (a.debug & 2u) d = (float)sid0[u];
+            d0[u] = d;
+          }
+          if (n[u] > 64) {                                  // survivor 64 (seed list only), lane 0
+            if (lane == 0) {
+              PqRow<NDW, ALIGNED> r1;
+              pq_row_load(r1, p.d_codes, p.m, sid1[u]);
+              d1[u] = pq_row_reduce<PSZ, NDW, ALIGNED>(r1, piv_lds, qc);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NQW; ++u) {
+          const float* lut = p.d_lut + (size_t)q[u] * p.m * 256;
+          if ((uint32_t)lane < n[u]) d0[u] = pq_distance_lut(p.d_codes, p.m, sid0[u], lut);
+          if (n[u] > 64 && lane == 0) d1[u] = pq_distance_lut(p.d_codes, p.m, sid1[u], lut);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        if (valid[u]) {
+          float* dist = p.d_dist + (size_t)q[u] * BANG_NBR_STRIDE;
+          if ((uint32_t)lane < n[u]) dist[lane] = d0[u];
+          if (lane == 0 && n[u] > 64) dist[64] = d1[u];
         }
       }
     } else if (do_parent) {
-      if ((uint32_t)lane < n) d0 = dist[lane];
-      if (lane == 0 && n > 64) d1 = dist[64];
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        const float* dist = p.d_dist + (size_t)q[u] * BANG_NBR_STRIDE;
+        if ((uint32_t)lane < n[u]) d0[u] = dist[lane];
+        if (lane == 0 && n[u] > 64) d1[u] = dist[64];
+      }
     }
 
     // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ------
     if (do_parent) {
-      // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
-      const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
-      float bd = elig ? d0 : BIG_DIST;
-      uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
-      uint32_t bid = sid0;
 #pragma unroll
-      for (int off = 1; off < WAVE; off <<= 1) {
-        const float od = __shfl_xor(bd, off);
-        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
-        const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
-        const bool take = (oi != 0xFFFFu) && (bi == 0xFFFFu || od < bd || (od == bd && oi < bi));
-        if (take) { bd = od; bi = oi; bid = oid; }
-      }
-      // element 64 (lane 0 of the second round) can only win with a strictly smaller distance
-      if (n > 64) {
-        const float e_d = __shfl(d1, 0);
-        const uint32_t e_id = (uint32_t)__shfl((int)sid1, 0);
-        if (e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
-      }
-      const bool have_best = (bi != 0xFFFFu);
-      if (!have_best) bd = BIG_DIST;
+      for (int u = 0; u < NQW; ++u) {
+        if (!valid[u]) continue;
+        const uint32_t nn = n[u];
+        // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
+        const bool elig = (uint32_t)lane < nn && sid0[u] != medoid && d0[u] < BIG_DIST;
+        float bd = elig ? d0[u] : BIG_DIST;
+        uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
+        uint32_t bid = sid0[u];
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+          const float od = __shfl_xor(bd, off);
+          const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+          const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
+          const bool take = (oi != 0xFFFFu) && (bi == 0xFFFFu || od < bd || (od == bd && oi < bi));
+          if (take) { bd = od; bi = oi; bid = oid; }
+        }
+        // element 64 (lane 0 of the second round) can only win with a strictly smaller distance
+        if (nn > 64) {
+          const float e_d = __shfl(d1[u], 0);
+          const uint32_t e_id = (uint32_t)__shfl((int)sid1[u], 0);
+          if (e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
+        }
+        const bool have_best = (bi != 0xFFFFu);
+        if (!have_best) bd = BIG_DIST;
 
-      bool found = false, from_best = false;
-      uint32_t parent = 0, w_hit = 0;
-      if (first) {
-        if (have_best) { found = true; parent = bid; from_best = true; }
-      } else {
-        w_n = uni(w_n);
-        float wdist = 0.0f;
-        uint32_t wid = 0;
-        {                                                   // first unvisited entry :1425-1439, head from registers
-          const uint64_t mk = __ballot((uint32_t)lane < w_n && (uint32_t)lane < L && pw_vis == 0);
-          if (mk) {
-            w_hit = (uint32_t)__builtin_ctzll(mk);
-            found = true;
-            wdist = __shfl(pw_dist, (int)w_hit);
-            wid = (uint32_t)__shfl((int)pw_id, (int)w_hit);
-          }
-        }
-        for (uint32_t base = WAVE; !found && base < w_n; base += WAVE) {   // rare: L > 64 and the head is all visited
-          const uint32_t i = base + lane;
-          const uint64_t mk = __ballot((i < w_n) && (wl_vis[i < w_n ? i : 0] == 0));
-          if (mk) {
-            w_hit = base + (uint32_t)__builtin_ctzll(mk);
-            found = true;
-            wdist = wl_dist[w_hit];
-            wid = wl_ids[w_hit];
-          }
-        }
-        if (found) {
-          if (bd < wdist) { parent = bid; from_best = true; }
-          else parent = wid;
-        } else if (w_n > 0) {                               // corner case :1442-1446
-          const float worst = (w_n <= WAVE) ? __shfl(pw_dist, (int)(w_n - 1)) : wl_dist[w_n - 1];
-          if (bd < worst) { found = true; parent = bid; from_best = true; }
-        }
-      }
-      if (lane == 0) {
-        if (found) {
-          if (from_best) p.d_mark[q] = parent;
-          else p.d_wl_vis[(size_t)q * L + w_hit] = 1;
-          p.d_cand_ids[(size_t)q * (L + BANG_EXTRA_ITERS) + cc] = parent;
-          if (p.d_cand_row) p.d_cand_row[(size_t)q * (L + BANG_EXTRA_ITERS) + cc] = p.iter;
-          p.d_cand_cnt[q] = cc + 1;
-          p.d_parents[q] = parent;
+        bool found = false, from_best = false;
+        uint32_t parent = 0, w_hit = 0;
+        if (first) {
+          if (have_best) { found = true; parent = bid; from_best = true; }
         } else {
-          p.d_parents[q] = (n > 0) ? BANG_IDLE_PARENT : BANG_NO_PARENT;
+          const uint32_t wn = uni(w_n[u]);
+          const uint8_t* wl_vis = p.d_wl_vis + (size_t)q[u] * L;
+          const float* wl_dist = p.d_wl_dist + (size_t)q[u] * L;
+          const uint32_t* wl_ids = p.d_wl_ids + (size_t)q[u] * L;
+          float wdist = 0.0f;
+          uint32_t wid = 0;
+          {                                                 // first unvisited entry :1425-1439, head from registers
+            const uint64_t mk = __ballot((uint32_t)lane < wn && (uint32_t)lane < L && pw_vis[u] == 0);
+            if (mk) {
+              w_hit = (uint32_t)__builtin_ctzll(mk);
+              found = true;
+              wdist = __shfl(pw_dist[u], (int)w_hit);
+              wid = (uint32_t)__shfl((int)pw_id[u], (int)w_hit);
+            }
+          }
+          for (uint32_t base = WAVE; !found && base < wn; base += WAVE) {   // rare: L > 64 and the head is all visited
+            const uint32_t i = base + lane;
+            const uint64_t mk = __ballot((i < wn) && (wl_vis[i < wn ? i : 0] == 0));
+            if (mk) {
+              w_hit = base + (uint32_t)__builtin_ctzll(mk);
+              found = true;
+              wdist = wl_dist[w_hit];
+              wid = wl_ids[w_hit];
+            }
+          }
+          if (found) {
+            if (bd < wdist) { parent = bid; from_best = true; }
+            else parent = wid;
+          } else if (wn > 0) {                              // corner case :1442-1446
+            const float worst = (wn <= WAVE) ? __shfl(pw_dist[u], (int)(wn - 1)) : wl_dist[wn - 1];
+            if (bd < worst) { found = true; parent = bid; from_best = true; }
+          }
         }
+        if (lane == 0) {
+          const uint32_t qq = q[u];
+          if (found) {
+            if (from_best) p.d_mark[qq] = parent;
+            else p.d_wl_vis[(size_t)qq * L + w_hit] = 1;
+            p.d_cand_ids[(size_t)qq * cand_stride + cc[u]] = parent;
+            if (p.d_cand_row) p.d_cand_row[(size_t)qq * cand_stride + cc[u]] = p.iter;
+            p.d_cand_cnt[qq] = cc[u] + 1;
+            __hip_atomic_store(&p.d_parents[qq], parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+          } else {
+            __hip_atomic_store(&p.d_parents[qq], (nn > 0) ? BANG_IDLE_PARENT : BANG_NO_PARENT, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (found || nn > 0) ++n_active;
       }
-      if (found || n > 0) ++n_active;
     }
   }
 
   // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
   if (lane == 0 && p.d_active && n_active) *p.d_active = 1u;
+
+  // Completion signal for the host walker, without any L2-wide fence (a release fence writes back every dirty
+  // line of the XCD's L2: measured +85 us per launch when every wave issued one).  Parents are stored
+  // write-through (agent-scope atomic stores = `sc1`), every wave drains its stores, the workgroup arrives on a
+  // device counter; the LAST workgroup re-reads the parents with `sc1` loads, copies them to mapped pinned host
+  // memory with system-scope stores (coalesced: one 4-byte PCIe write per query from every wave was measured at
+  // +75 us per launch), drains, and publishes done_value.  The walker thread spins on that word.
+  if (p.h_done_flag) {
+    volatile uint32_t* s_last = scratch_all;        // dynamic LDS: no static allocation next to the 160 KB request
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t old = atomicAdd(p.d_done_count, 1u);
+      const uint32_t last = (old + 1 == gridDim.x) ? 1u : 0u;
+      *s_last = last;
+      if (last) atomicExch(p.d_done_count, 0u);     // every other workgroup has already arrived
+    }
+    __syncthreads();
+    if (*s_last) {
+      for (uint32_t i = threadIdx.x; i < p.Q; i += blockDim.x) {
+        const uint32_t v = __hip_atomic_load(&p.d_parents[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.h_parents[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag must not overtake the stores (MI355X guide)
+      __syncthreads();
+      if (threadIdx.x == 0)
+        __hip_atomic_store(p.h_done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -768,26 +901,37 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
   });
 }
 
-template <int PSZ, int NDW, bool ALIGNED, bool ALL>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL>,
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
 
+// nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
-static int launch_front_al(const FrontArgs& a, bool aligned, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   const bool all = (a.stages == 7u);
-  if (aligned) return all ? launch_front_inst<PSZ, NDW, true, true>(a, grid, block, lds, st)
-                          : launch_front_inst<PSZ, NDW, true, false>(a, grid, block, lds, st);
-  return all ? launch_front_inst<PSZ, NDW, false, true>(a, grid, block, lds, st)
-             : launch_front_inst<PSZ, NDW, false, false>(a, grid, block, lds, st);
+  if (!all) {
+    return aligned ? launch_front_inst<PSZ, NDW, true, false, 1, 1024>(a, grid, block, lds, st)
+                   : launch_front_inst<PSZ, NDW, false, false, 1, 1024>(a, grid, block, lds, st);
+  }
+  const bool small = block.x <= 512;
+#define BANG_FRONT_PICK(AL)                                                                                    \
+  switch (nqw) {                                                                                               \
+    case 1: return launch_front_inst<PSZ, NDW, AL, true, 1, 1024>(a, grid, block, lds, st);                    \
+    default: return small ? launch_front_inst<PSZ, NDW, AL, true, 4, 512>(a, grid, block, lds, st)             \
+                          : launch_front_inst<PSZ, NDW, AL, true, 4, 1024>(a, grid, block, lds, st);           \
+  }
+  if (aligned) { BANG_FRONT_PICK(true) }
+  BANG_FRONT_PICK(false)
+#undef BANG_FRONT_PICK
 }
 
 static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream) {
@@ -798,6 +942,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_seed) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
   if ((stages & 4u) && (!p->d_wl_ids || !p->d_wl_dist || !p->d_wl_vis || !p->d_wl_cnt || !p->d_mark || !p->d_parents ||
                         !p->d_cand_ids || !p->d_cand_cnt)) { bang_set_error("null worklist/candidate buffer"); return BANG_ERR_ARG; }
+  if (p->h_done_flag && (!p->d_done_count || !p->h_parents)) { bang_set_error("completion flag needs d_done_count and h_parents"); return BANG_ERR_ARG; }
   if ((stages & 1u) && (!p->d_bloom || (!p->first && !p->d_stage && !p->d_graph))) { bang_set_error("null filter buffer"); return BANG_ERR_ARG; }
   if ((stages & 2u) && (p->psz ? (!p->d_pivots_packed || !p->d_qc) : !p->d_lut)) { bang_set_error("null PQ buffer"); return BANG_ERR_ARG; }
   FrontArgs a;
@@ -825,35 +970,47 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   const size_t piv_bytes = (size_t)a.lds_piv_floats * 4;
   const size_t lds_cap = 160 * 1024;
   // One workgroup per CU at most (the pivot table takes most of the LDS); a lane that shares the GPU
-  // with other lanes gets max_wgs of them.  Waves per workgroup: enough to cover Q, bounded by LDS.
+  // with other lanes gets max_wgs of them.  Each wave keeps nqw queries in flight; waves per workgroup:
+  // enough to cover Q in one sweep if possible, bounded by LDS.
+  static int env_nqw = -1, env_waves = -1;
+  if (env_nqw < 0) { const char* v = getenv("BANG_FRONT_NQW"); env_nqw = v ? atoi(v) : 0; }
+  if (env_waves < 0) { const char* v = getenv("BANG_FRONT_WAVES"); env_waves = v ? atoi(v) : 0; }
   int wgs = need_piv ? num_cus() : num_cus() * 8;
   if (p->max_wgs && (int)p->max_wgs < wgs) wgs = (int)p->max_wgs;
-  int waves = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);
+  const int per_wg = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
+  // interleaving 4 queries per wave did not pay on SIFT1M-like data (the kernel is bound by random-access
+  // throughput of the visited filter, not by dependent latency); kept selectable for other shapes
+  int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : 1);
+  nqw = (nqw >= 2) ? 4 : 1;
+  int max_waves = env_waves > 0 ? env_waves : 16;
+  if (max_waves > 16) max_waves = 16;
+  int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;
-  if (waves > 16) waves = 16;
-  while (waves > 1 && piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4 > lds_cap) --waves;
-  const size_t lds = piv_bytes + (size_t)waves * FRONT_SCRATCH_WORDS * 4;
+  if (waves > max_waves) waves = max_waves;
+  const size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
+  while (waves > 1 && piv_bytes + (size_t)waves * scratch_per_wave > lds_cap) --waves;
+  const size_t lds = piv_bytes + (size_t)waves * scratch_per_wave;
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
-  int grid_n = (int)((p->Q + (uint32_t)waves - 1) / (uint32_t)waves);
+  int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
   const dim3 grid(grid_n), block(waves * WAVE);
   const bool al = (p->m % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + (p->psz ? p->mp / 4u : 0u);
   switch (key) {
-    case 0: return launch_front_al<0, 1>(a, true, grid, block, lds, st);
-    case 108: return launch_front_al<1, 8>(a, al, grid, block, lds, st);
-    case 116: return launch_front_al<1, 16>(a, al, grid, block, lds, st);
-    case 124: return launch_front_al<1, 24>(a, al, grid, block, lds, st);
-    case 132: return launch_front_al<1, 32>(a, al, grid, block, lds, st);
-    case 208: return launch_front_al<2, 8>(a, al, grid, block, lds, st);
-    case 216: return launch_front_al<2, 16>(a, al, grid, block, lds, st);
-    case 218: return launch_front_al<2, 18>(a, al, grid, block, lds, st);
-    case 219: return launch_front_al<2, 19>(a, al, grid, block, lds, st);
-    case 404: return launch_front_al<4, 4>(a, al, grid, block, lds, st);
-    case 408: return launch_front_al<4, 8>(a, al, grid, block, lds, st);
-    case 802: return launch_front_al<8, 2>(a, al, grid, block, lds, st);
-    case 804: return launch_front_al<8, 4>(a, al, grid, block, lds, st);
+    case 0: return launch_front_al<0, 1>(a, true, nqw, grid, block, lds, st);
+    case 108: return launch_front_al<1, 8>(a, al, nqw, grid, block, lds, st);
+    case 116: return launch_front_al<1, 16>(a, al, nqw, grid, block, lds, st);
+    case 124: return launch_front_al<1, 24>(a, al, nqw, grid, block, lds, st);
+    case 132: return launch_front_al<1, 32>(a, al, nqw, grid, block, lds, st);
+    case 208: return launch_front_al<2, 8>(a, al, nqw, grid, block, lds, st);
+    case 216: return launch_front_al<2, 16>(a, al, nqw, grid, block, lds, st);
+    case 218: return launch_front_al<2, 18>(a, al, nqw, grid, block, lds, st);
+    case 219: return launch_front_al<2, 19>(a, al, nqw, grid, block, lds, st);
+    case 404: return launch_front_al<4, 4>(a, al, nqw, grid, block, lds, st);
+    case 408: return launch_front_al<4, 8>(a, al, nqw, grid, block, lds, st);
+    case 802: return launch_front_al<8, 2>(a, al, nqw, grid, block, lds, st);
+    case 804: return launch_front_al<8, 4>(a, al, nqw, grid, block, lds, st);
     default: bang_set_error("no kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
   }
 }

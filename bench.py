@@ -50,6 +50,7 @@ def main():
                     help="host: graph in host RAM + C++ walker (BANG_Base, the north-star path); device: graph in HBM")
     ap.add_argument("--L", type=int, default=0, help="worklist length; 0 = smallest L on the harness grid with recall >= target")
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--queries", type=int, default=0, help="override the batch size of the workload")
     ap.add_argument("--recall-target", type=float, default=90.0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,6 +83,8 @@ def main():
         ix, queries, gt_i, gt_d, d_codes, wl_name = wl
     else:
         N, D, dtype, R, m, Q, ncl = WORKLOADS[args.workload]
+        if args.queries:
+            Q = args.queries
         ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q, K=args.k, n_clusters=ncl, device=dev)
         d_codes = None
         wl_name = (f"{args.workload}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "

@@ -182,12 +182,19 @@ typedef struct {
   uint8_t* d_wl_vis;                   /* [Q][L] */
   uint32_t* d_wl_cnt;                  /* [Q] */
   uint32_t* d_mark;                    /* [Q] */
-  uint32_t* d_parents;                 /* [Q] parent id | BANG_NO_PARENT | BANG_IDLE_PARENT (device or mapped host) */
+  uint32_t* d_parents;                 /* [Q] parent id | BANG_NO_PARENT | BANG_IDLE_PARENT (device memory) */
   uint32_t* d_cand_ids;                /* [Q][L+50] expanded nodes (compact) */
   uint32_t* d_cand_row;                /* [Q][L+50] iteration row holding the node's vector */
   uint32_t* d_cand_cnt;                /* [Q] */
   uint32_t* d_active;                  /* [1] set to 1 if any query is still active (plain store; may be NULL) */
   uint32_t* d_qstats;                  /* [Q][2] per-query running totals {survivors, ids fetched} (may be NULL) */
+  /* completion signal of the front kernel (host-graph mode): the last workgroup to finish stores done_value to
+   * h_done_flag (mapped pinned host memory) after copying the parents to h_parents and a system-scope release, so the
+   * walker thread can spin on it instead of calling into the HIP runtime.  d_done_count is a zero-initialised device word. NULL = off. */
+  uint32_t* d_done_count;
+  uint32_t* h_done_flag;
+  uint32_t* h_parents;                 /* mapped pinned [Q]: the last workgroup copies d_parents there (coalesced) before the flag */
+  uint32_t done_value;
 } bang_iter_params;
 
 /* Fused K5 + K2 + K4: neighbor_filtering_new (bang_search.cu:1140-1165) -> compute_neighborDist_par
