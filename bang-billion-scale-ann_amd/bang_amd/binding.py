@@ -39,7 +39,7 @@ class IterParams(C.Structure):
         ("d_wl_ids", C.c_void_p), ("d_wl_dist", C.c_void_p), ("d_wl_vis", C.c_void_p), ("d_wl_cnt", C.c_void_p),
         ("d_mark", C.c_void_p), ("d_parents", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_row", C.c_void_p),
         ("d_cand_cnt", C.c_void_p), ("d_active", C.c_void_p), ("d_qstats", C.c_void_p),
-        ("d_done_count", C.c_void_p), ("h_done_flag", C.c_void_p), ("h_parents", C.c_void_p), ("done_value", C.c_uint32),
+        ("d_done_count", C.c_void_p), ("h_done_flag", C.c_void_p), ("d_ktime", C.c_void_p), ("h_parents", C.c_void_p), ("done_value", C.c_uint32),
     ]
 
 

@@ -97,14 +97,15 @@ static double ms_since(Clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
 }
 
+constexpr size_t KT_WGS = 256;   // workgroups per front launch never exceed the CU count
+
 struct Lane {
   uint32_t q0 = 0, nq = 0;
   int index = 0;
   hipStream_t s_main = nullptr, s_fp = nullptr;
   hipEvent_t ev_front = nullptr, ev_fp = nullptr;
-  std::vector<hipEvent_t> tev;      // timing events (pairs), "timing"=1
-  size_t tev_used = 0;
-  std::vector<int> tev_kind;        // 0 front, 1 back, 2 rerank
+  unsigned long long* d_ktime = nullptr;   // [max launches][KT_WGS][2] in-kernel stamps, "timing"=1
+  size_t kt_launches = 0, kt_used = 0;
   // walker team of this lane: the lane thread + (threads-1) helpers, spin-synchronised while a query runs
   std::vector<std::thread> helpers;
   std::atomic<uint32_t> epoch{0};
@@ -335,7 +336,8 @@ void free_batch(bang_engine* e) {
     if (ln.s_fp) (void)hipStreamDestroy(ln.s_fp);
     if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
     if (ln.ev_fp) (void)hipEventDestroy(ln.ev_fp);
-    for (hipEvent_t ev : ln.tev) if (ev) (void)hipEventDestroy(ev);
+    if (ln.d_ktime) (void)hipFree(ln.d_ktime);
+    ln.d_ktime = nullptr;
   }
   e->lanes.clear();
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
@@ -465,18 +467,10 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   }
 }
 
-hipEvent_t timing_begin(bang_engine* e, Lane& ln, int kind) {
-  if (!e->timing || ln.tev_used + 2 > ln.tev.size()) return nullptr;
-  hipEvent_t a = ln.tev[ln.tev_used];
-  ln.tev_kind[ln.tev_used / 2] = kind;
-  (void)hipEventRecord(a, ln.s_main);
-  return a;
-}
-void timing_end(bang_engine* e, Lane& ln, hipEvent_t a) {
-  if (!a) return;
-  (void)hipEventRecord(ln.tev[ln.tev_used + 1], ln.s_main);
-  ln.tev_used += 2;
-  (void)e;
+// slot for the in-kernel {start,end} stamps of the next front launch ("timing"=1), or NULL
+unsigned long long* ktime_slot(bang_engine* e, Lane& ln) {
+  if (!e->timing || !ln.d_ktime || ln.kt_used >= ln.kt_launches) return nullptr;
+  return ln.d_ktime + (ln.kt_used++) * KT_WGS * 2;
 }
 
 // Host graph walker (bang_search.cu:771-813) for queries [i0, i1) of a lane: for every query with a parent copy
@@ -641,7 +635,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t qbytes = qdim * e->tsize;
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
-  ln.tev_used = 0;
+  if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16); ln.kt_used = 0; }   // stats not collected
   ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
   auto t_enq = Clock::now();
 #define ENQ_BEGIN() (t_enq = Clock::now())
@@ -668,12 +662,9 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   uint32_t iter = 1;                                                         // :596
   p.first = 1; p.iter = iter; p.done_value = iter;
   if (dev_graph) p.d_active = e->d_active + iter;
-  {
-    hipEvent_t t = timing_begin(e, ln, 0);
-    BANG_TRY(bang_k_front(&p, ln.s_main));                                   // K5+K2+K4a :650-678
-    timing_end(e, ln, t);
-    ++ln.front_launches;
-  }
+  p.d_ktime = ktime_slot(e, ln);
+  BANG_TRY(bang_k_front(&p, ln.s_main));                                     // K5+K2+K4a :650-678
+  ++ln.front_launches;
 
   // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
   uint32_t fp_lo = 0, fp_hi = 0;
@@ -691,11 +682,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   for (;;) {
     p.first = 0; p.iter = iter;
     ENQ_BEGIN();
-    {
-      hipEvent_t t = timing_begin(e, ln, 1);
-      BANG_TRY(bang_k_back(&p, ln.s_main));                                  // K3a+K3b :726-738 (overlaps the walker)
-      timing_end(e, ln, t);
-    }
+    BANG_TRY(bang_k_back(&p, ln.s_main));                                    // K3a+K3b :726-738 (overlaps the walker)
     ENQ_END();
     if (!dev_graph) {
       DBG("[lane %d] wait flag %u\n", ln.index, iter);
@@ -721,12 +708,9 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     p.iter = iter; p.done_value = iter;
     if (dev_graph) p.d_active = e->d_active + iter;
     ENQ_BEGIN();
-    {
-      hipEvent_t t = timing_begin(e, ln, 0);
-      BANG_TRY(bang_k_front(&p, ln.s_main));                                 // K5+K2+K4b :855-917 
-      timing_end(e, ln, t);
-      ++ln.front_launches;
-    }
+    p.d_ktime = ktime_slot(e, ln);
+    BANG_TRY(bang_k_front(&p, ln.s_main));                                   // K5+K2+K4b :855-917
+    ++ln.front_launches;
     ENQ_END();
     if (!dev_graph) {
       if (iter == cap_iter) {                                                // :950-956
@@ -761,7 +745,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     LANE_HIP(hipStreamWaitEvent(ln.s_main, ln.ev_fp, 0));
   }
   {
-    hipEvent_t t = timing_begin(e, ln, 2);
     if (dev_graph)
       BANG_TRY(bang_k_rerank_range(e->d_graph, e->entry_len, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids,
                                    nullptr, e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D,
@@ -770,7 +753,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       BANG_TRY(bang_k_rerank_range(e->d_fp, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, e->d_cand_row,
                                    e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k,
                                    dim_adjust, e->d_ids_out, e->d_dists_out, ln.s_main));
-    timing_end(e, ln, t);
   }
   // results D2H (:997-999): ids [Q][k]; dists [k][Q] (rank-major)
   LANE_HIP(hipMemcpyAsync(h_ids + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k,
@@ -781,14 +763,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
   DBG("[lane %d] synced\n", ln.index);
-  ln.front_ms = ln.back_ms = ln.rerank_ms = 0;
-  for (size_t i = 0; i + 1 < ln.tev_used; i += 2) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ln.tev[i], ln.tev[i + 1]) == hipSuccess) {
-      const int kind = ln.tev_kind[i / 2];
-      (kind == 0 ? ln.front_ms : kind == 1 ? ln.back_ms : ln.rerank_ms) += ms;
-    }
-  }
+  ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats
   return BANG_OK;
 }
 
@@ -1007,9 +982,9 @@ static int alloc_buffers(bang_engine* e, int Q) {
     HIP_TRY(hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ln.ev_fp, hipEventDisableTiming));
     if (e->timing) {
-      ln.tev.assign(2 * (2 * rows + 4), nullptr);
-      ln.tev_kind.assign(ln.tev.size() / 2, 0);
-      for (hipEvent_t& ev : ln.tev) HIP_TRY(hipEventCreate(&ev));
+      ln.kt_launches = rows + 4;
+      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));
+      HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 16));
     }
   }
   start_threads(e);
@@ -1109,9 +1084,33 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   return rc;
 }
 
+// reduce the in-kernel stamps of a lane: per launch max(end) - min(start) over the workgroups that ran
+static int reduce_ktimes(Lane& ln) {
+  if (!ln.d_ktime || ln.kt_used == 0) return BANG_OK;
+  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * 2);
+  HIP_TRY(hipMemcpy(kt.data(), ln.d_ktime, kt.size() * 8, hipMemcpyDeviceToHost));
+  ln.front_ms = 0;
+  for (size_t l = 0; l < ln.kt_used; ++l) {
+    unsigned long long lo = ~0ull, hi = 0;
+    for (size_t w = 0; w < KT_WGS; ++w) {
+      const unsigned long long a = kt[(l * KT_WGS + w) * 2], b = kt[(l * KT_WGS + w) * 2 + 1];
+      if (a == 0 || b == 0) continue;                  // workgroup slot not used by this launch
+      lo = std::min(lo, a);
+      hi = std::max(hi, b);
+    }
+    if (hi > lo) ln.front_ms += (double)(hi - lo) * 1e-5;   // 100 MHz ticks -> ms
+  }
+  HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16));
+  ln.kt_used = 0;
+  return BANG_OK;
+}
+
 extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   if (!e || !out) return BANG_ERR_ARG;
   bang_stats& s = e->stats;
+  if (e->allocated && e->timing && s.front_ms == 0) {
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp)); s.front_ms += lp->front_ms; }
+  }
   if (e->allocated && e->Qcur > 0 && s.candidates == 0) {   // device-side counters are fetched lazily
     std::vector<uint32_t> qs((size_t)e->Qcur * 2);
     HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));

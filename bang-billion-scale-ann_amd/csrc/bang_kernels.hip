@@ -49,6 +49,10 @@ __device__ __forceinline__ uint32_t hash2(uint32_t x) {  // hashFn2_d :1180-1189
   return (uint32_t)(h % BANG_BF_ENTRIES);
 }
 
+__device__ __forceinline__ void bloom_set(uint32_t* w, uint32_t bit) {
+  (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_sync() {
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const bang_iter_params& p = a.p;
   float* piv_lds = lds;
   uint32_t* scratch_all = (uint32_t*)(lds + a.lds_piv_floats);
+  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const bool do_filter = ALL || (a.stages & 1u);
   const bool do_dist = ALL || (a.stages & 2u);
   const bool do_parent = ALL || (a.stages & 4u);
@@ -328,8 +333,11 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
         // the filter updates are issued AFTER everything the distance stage needs from LDS; they are
         // fire-and-forget (no return value)
         if (!(a.debug & 1u)) {
-          if (pass0) { atomicOr(&bloom[h0a[u] >> 5], 1u << (h0a[u] & 31)); atomicOr(&bloom[h0b[u] >> 5], 1u << (h0b[u] & 31)); }
-          if (pass1) { atomicOr(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); atomicOr(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
+          // A query's filter is touched by exactly one wave per launch and kernel boundaries publish it, so the
+          // ORs only need WORKGROUP scope: they are resolved in the XCD's L2 instead of at the memory side
+          // (device-scope atomics to 64 different lines per wave run at ~20 G/s chip-wide).
+          if (pass0) { bloom_set(&bloom[h0a[u] >> 5], 1u << (h0a[u] & 31)); bloom_set(&bloom[h0b[u] >> 5], 1u << (h0b[u] & 31)); }
+          if (pass1) { bloom_set(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); bloom_set(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
         }
       }
 #pragma unroll
@@ -494,6 +502,11 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
 
   // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
   if (lane == 0 && p.d_active && n_active) *p.d_active = 1u;
+
+  if (p.d_ktime) {
+    __syncthreads();
+    if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // Completion signal for the host walker, without any L2-wide fence (a release fence writes back every dirty
   // line of the XCD's L2: measured +85 us per launch when every wave issued one).  Parents are stored
@@ -980,9 +993,13 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   const int per_wg = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
   // interleaving 4 queries per wave did not pay on SIFT1M-like data (the kernel is bound by random-access
   // throughput of the visited filter, not by dependent latency); kept selectable for other shapes
-  int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : 1);
+  // Layouts with >= 32 chunk-dwords x floats per entry (m = 64..76 at 2 floats per entry: SIFT1B, DEEP100M) need more
+  // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
+  // queries in flight per wave instead of 16 waves x 1 query.
+  const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) >= 32u;
+  int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
   nqw = (nqw >= 2) ? 4 : 1;
-  int max_waves = env_waves > 0 ? env_waves : 16;
+  int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
   if (max_waves > 16) max_waves = 16;
   int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;

@@ -64,7 +64,7 @@ int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   
  *   "threads" : host walker threads per lane (>=1)
  *   "device"  : HIP device ordinal
  *   "pq"      : 0 = pivot-stationary fused distance (default when it fits LDS), 1 = LUT path (K1+K2)
- *   "timing"  : 1 = record per-launch HIP events for bang_get_stats */
+ *   "timing"  : 1 = stamp every front-kernel launch in-kernel (s_memrealtime) for bang_get_stats */
 int bang_set_option(bang_engine_t* e, const char* key, long value);
 
 /* bang_load, bang.h:51 / bang_search.cu:138-362 */
@@ -101,8 +101,9 @@ typedef struct {
   uint64_t fetched;           /* total adjacency ids offered to the filter */
   uint64_t candidates;        /* total expanded nodes re-ranked */
   uint64_t front_launches;    /* launches of the filter+distance+parent kernel */
-  double front_ms;            /* sum of their HIP-event durations ("timing"=1, else 0) */
-  double back_ms;             /* sort+merge launches */
+  double front_ms;            /* sum of their durations from in-kernel s_memrealtime stamps ("timing"=1, else 0):
+                                 per launch max(end) - min(start) over its workgroups */
+  double back_ms;             /* unused (kept for layout; rocprofv3 reports the sort+merge kernel) */
   double rerank_ms;
   double walker_ms;           /* host time in the adjacency gather, summed over lanes */
   double sync_ms;             /* host time blocked waiting for the parents of an iteration, summed over lanes */
@@ -193,6 +194,7 @@ typedef struct {
    * walker thread can spin on it instead of calling into the HIP runtime.  d_done_count is a zero-initialised device word. NULL = off. */
   uint32_t* d_done_count;
   uint32_t* h_done_flag;
+  unsigned long long* d_ktime;         /* [gridDim.x][2] per-workgroup {start,end} s_memrealtime stamps (100 MHz) of this launch, or NULL */
   uint32_t* h_parents;                 /* mapped pinned [Q]: the last workgroup copies d_parents there (coalesced) before the flag */
   uint32_t done_value;
 } bang_iter_params;

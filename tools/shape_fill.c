@@ -1,0 +1,63 @@
+/* shape_fill.c -- fills a BANG graph file image ([T vec[D]][u32 deg][u32 nbr[R]] per node) with SHAPE-ONLY data for
+ * throughput runs at billion scale (SURVEY 8(d) Tier B): uniform random vector bytes, degree = R, and R sorted distinct
+ * neighbour ids drawn by stratified sampling (nbr_j uniform in [j*N/R, (j+1)*N/R)).  Multi-threaded, one pass, so a
+ * 388 GB SIFT1B-shape image is produced at memory speed.  Benchmark tooling only (not part of libbang). */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <omp.h>
+
+static inline uint64_t splitmix(uint64_t *s) {
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+/* returns a page-aligned anonymous mapping with transparent huge pages requested, or NULL */
+void *shape_alloc(size_t bytes) {
+  void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (p == MAP_FAILED) return NULL;
+  madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
+}
+void shape_free(void *p, size_t bytes) { if (p) munmap(p, bytes); }
+
+void shape_fill_graph(uint8_t *graph, uint64_t N, uint32_t vec_bytes, uint32_t R, uint64_t seed, int nthreads) {
+  const uint64_t entry = (uint64_t)vec_bytes + 4 + 4ull * R;
+  uint64_t lo_[64], w_[64];
+  if (R > 64) return;
+  for (uint32_t j = 0; j < R; ++j) { lo_[j] = N * j / R; w_[j] = N * (j + 1) / R - lo_[j]; if (w_[j] == 0) w_[j] = 1; }
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)N; ++i) {
+    uint64_t s = seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull);
+    uint8_t *e = graph + (uint64_t)i * entry;
+    uint32_t k = 0;
+    for (; k + 8 <= vec_bytes; k += 8) { uint64_t r = splitmix(&s); memcpy(e + k, &r, 8); }
+    for (; k < vec_bytes; ++k) e[k] = (uint8_t)splitmix(&s);
+    uint32_t deg = R;
+    memcpy(e + vec_bytes, &deg, 4);
+    uint32_t *nb = (uint32_t *)(e + vec_bytes + 4);
+    for (uint32_t j = 0; j < R; ++j) {
+      const uint64_t lo = lo_[j], hi = lo + w_[j];                /* strata are disjoint: ids come out sorted & distinct */
+      uint64_t id = lo + (uint64_t)(((unsigned __int128)splitmix(&s) * w_[j]) >> 64);
+      if (id == (uint64_t)i) id = (id + 1 < hi) ? id + 1 : lo;   /* no self loop */
+      nb[j] = (uint32_t)id;
+    }
+  }
+}
+
+void shape_fill_bytes(uint8_t *dst, uint64_t n, uint64_t seed, int nthreads) {
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const uint64_t blocks = (n + 4095) / 4096;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)blocks; ++b) {
+    uint64_t s = seed ^ ((uint64_t)b * 0xA24BAED4963EE407ull);
+    const uint64_t lo = (uint64_t)b * 4096, hi = lo + 4096 < n ? lo + 4096 : n;
+    uint64_t k = lo;
+    for (; k + 8 <= hi; k += 8) { uint64_t r = splitmix(&s); memcpy(dst + k, &r, 8); }
+    for (; k < hi; ++k) dst[k] = (uint8_t)splitmix(&s);
+  }
+}

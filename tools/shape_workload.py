@@ -1,0 +1,148 @@
+"""Shape-only workloads (SURVEY 8(d) Tier B) for throughput at the BASELINE.json scales:
+
+  sift1b_shape   : N = 1e9, uint8, D = 128, R = 64, m = 70 -- graph + vectors (388 GB) in HOST RAM, PQ codes (70 GB) in HBM
+  deep100m_shape : N = 1e8, float32, D = 96, R = 64, m = 74 -- graph + vectors (64.4 GB) and codes (7.4 GB) in HBM
+
+Uniform random vectors / codes, random sorted R-regular adjacency, N(0,1)-scaled pivots: recall is NOT meaningful, the
+per-query work (L = 152, iteration cap L+49, ~64 neighbours per expansion) and every memory footprint are.  N is scaled
+down automatically to fit 75 % of the memory the box lets this process use (and says so)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
+
+SHAPES = {
+    "sift1b_shape": dict(N=1_000_000_000, D=128, dtype="uint8", R=64, m=70, graph="host"),
+    "deep100m_shape": dict(N=100_000_000, D=96, dtype="float", R=64, m=74, graph="device"),
+}
+
+
+def _lib():
+    so = os.path.join(HERE, "_build", "libshape_fill.so")
+    src = os.path.join(HERE, "shape_fill.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.shape_alloc.restype = C.c_void_p
+    lib.shape_alloc.argtypes = [C.c_size_t]
+    lib.shape_free.argtypes = [C.c_void_p, C.c_size_t]
+    lib.shape_fill_graph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+    lib.shape_fill_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    return lib
+
+
+def usable_cpus() -> int:
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def usable_host_bytes() -> int:
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) * 1024
+    try:
+        m = open("/sys/fs/cgroup/memory.max").read().strip()
+        if m != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(m) - used)
+    except Exception:
+        pass
+    return avail
+
+
+class ShapeIndex:
+    """Duck-types bang_amd.formats.Index for Engine.load_index (graph is a numpy view of the mmap'ed image)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def entry_len(self):
+        return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
+
+
+def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print):
+    import torch
+    from bang_amd.synth import chunk_offsets
+    sh = dict(SHAPES[name])
+    isz = 4 if sh["dtype"] == "float" else 1
+    D, R, m = sh["D"], sh["R"], sh["m"]
+    entry = D * isz + 4 + 4 * R
+    N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
+    lib = _lib()
+    ncpu = usable_cpus()
+    note = ""
+    if sh["graph"] == "host":
+        budget = int(usable_host_bytes() * 0.75)
+        if N * entry > budget:
+            N2 = budget // entry
+            note = f" (N scaled {N} -> {N2}: host memory budget {budget / 2**30:.0f} GiB)"
+            N = N2
+    else:
+        free, _total = torch.cuda.mem_get_info(dev)
+        budget = int(free * 0.85) - (8 << 30)
+        if N * (entry + m) > budget:
+            N2 = budget // (entry + m)
+            note = f" (N scaled {N} -> {N2}: HBM budget {budget / 2**30:.0f} GiB)"
+            N = N2
+        host_budget = int(usable_host_bytes() * 0.75)
+        if N * entry > host_budget:
+            N2 = host_budget // entry
+            note += f" (N scaled to {N2}: host staging budget)"
+            N = N2
+    t0 = time.time()
+    gbytes = N * entry
+    ptr = lib.shape_alloc(gbytes)
+    if not ptr:
+        raise MemoryError(f"cannot map {gbytes} bytes")
+    lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu)
+    graph = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(gbytes,)).reshape(N, entry)
+    if sh["dtype"] == "float":          # random bytes are not sane floats: overwrite the vector part block-wise with N(0,1)
+        rng = np.random.default_rng(seed)
+        step = 1 << 20
+        for a in range(0, N, step):
+            b = min(N, a + step)
+            v = rng.standard_normal((b - a, D), dtype=np.float32)
+            graph[a:b, : D * 4] = v.view(np.uint8).reshape(b - a, D * 4)
+    log(f"[shape] graph image {gbytes / 2**30:.1f} GiB filled in {time.time() - t0:.1f}s with {ncpu} threads{note}")
+    # PQ codes straight on the device
+    t0 = time.time()
+    codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 7)
+    for a in range(0, N * m, step):
+        b = min(N * m, a + step)
+        codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
+    codes[N * m:] = 0
+    torch.cuda.synchronize()
+    log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated on the device in {time.time() - t0:.1f}s")
+    rng = np.random.default_rng(seed + 1)
+    scale = 40.0 if sh["dtype"] == "uint8" else 0.5
+    pivots = (rng.standard_normal((256, D)) * scale).astype(np.float32)
+    centroid = (np.full(D, 127.5) if sh["dtype"] == "uint8" else np.zeros(D)).astype(np.float32)
+    if sh["dtype"] == "uint8":
+        queries = rng.integers(0, 256, (Q, D), dtype=np.uint8)
+    else:
+        queries = rng.standard_normal((Q, D)).astype(np.float32)
+    ix = ShapeIndex(dtype=sh["dtype"], N=N, D=D, R=R, m=m, medoid=int(N // 2), graph=graph,
+                    codes=np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
+                    chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib)
+    name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
+              f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * m / 1e9:.0f} GB in HBM{note}")
+    return ix, queries, None, None, codes.data_ptr(), name_s, sh["graph"]
