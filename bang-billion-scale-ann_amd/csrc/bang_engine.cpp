@@ -606,7 +606,8 @@ int wait_flag(bang_engine* e, Lane& ln, uint32_t value) {
   uint32_t spins = 0;
   while (*flag != value) {
     _mm_pause();
-    if ((++spins & 0xFFFFF) == 0) {
+    if ((++spins & 0x3FF) == 0) std::this_thread::yield();   // stay polite under a CPU quota (8 ranks x lanes may exceed it)
+    if ((spins & 0xFFFFF) == 0) {
       if (ms_since(t0) > 20000.0) {
         bang_set_error("timeout waiting for the front kernel of iteration %u (lane %d)", value, ln.index);
         return BANG_ERR_HIP;

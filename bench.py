@@ -116,7 +116,14 @@ def main():
     Qr = q1 - q0
 
     graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
-    eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=args.lanes,
+    lanes, threads = args.lanes, 2
+    if world > 1 and graph_mode == bang_amd.GRAPH_HOST:
+        # all ranks of the node share one CPU quota: keep (lanes x walker threads) x ranks within it
+        cpus = usable_cpus()
+        threads = 1
+        if not lanes:
+            lanes = max(1, min(4, cpus // (2 * world)))
+    eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=lanes, threads=threads,
                           timing=0 if args.no_events else 1)
     eng.load_index(ix, d_codes=d_codes)
 
@@ -260,7 +267,7 @@ def main():
             "ms_per_step": round(1e3 * total / args.steps, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_name, "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None), "graph": args.graph,
-                       "lanes": args.lanes, "iterations": agg["iterations"],
+                       "lanes": lanes, "walker_threads_per_lane": threads, "iterations": agg["iterations"],
                        "qps_incl_init": round(Q * args.steps / total_incl_init, 1),
                        "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
                        "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
