@@ -846,6 +846,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_GRAPH")) e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
   if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(1, atoi(v));
+  if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
@@ -973,7 +974,8 @@ static int alloc_buffers(bang_engine* e, int Q) {
     int dev_id = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess) cus = prop.multiProcessorCount;
-    e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::max(1, cus / nl) : 0);
+    // lanes are rarely all in their kernel phase at once: give each up to twice its fair share of the CUs
+    e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::min(cus, std::max(1, 2 * cus / nl)) : 0);
   }
   for (int i = 0; i < nl; ++i) {
     Lane& ln = *e->lanes[(size_t)i];

@@ -993,10 +993,10 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   const int per_wg = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
   // interleaving 4 queries per wave did not pay on SIFT1M-like data (the kernel is bound by random-access
   // throughput of the visited filter, not by dependent latency); kept selectable for other shapes
-  // Layouts with >= 32 chunk-dwords x floats per entry (m = 64..76 at 2 floats per entry: SIFT1B, DEEP100M) need more
+  // Layouts with > 32 chunk-dwords x floats per entry (m = 68..76 at 2 floats per entry: SIFT1B, DEEP100M) need more
   // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
   // queries in flight per wave instead of 16 waves x 1 query.
-  const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) >= 32u;
+  const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) > 32u;
   int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
   nqw = (nqw >= 2) ? 4 : 1;
   int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
