@@ -1088,7 +1088,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
 }
 
 // reduce the in-kernel stamps of a lane: per launch max(end) - min(start) over the workgroups that ran
-static int reduce_ktimes(Lane& ln) {
+static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals) {
   if (!ln.d_ktime || ln.kt_used == 0) return BANG_OK;
   std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * 2);
   HIP_TRY(hipMemcpy(kt.data(), ln.d_ktime, kt.size() * 8, hipMemcpyDeviceToHost));
@@ -1101,7 +1101,7 @@ static int reduce_ktimes(Lane& ln) {
       lo = std::min(lo, a);
       hi = std::max(hi, b);
     }
-    if (hi > lo) ln.front_ms += (double)(hi - lo) * 1e-5;   // 100 MHz ticks -> ms
+    if (hi > lo) { ln.front_ms += (double)(hi - lo) * 1e-5; intervals.emplace_back(lo, hi); }   // 100 MHz ticks -> ms
   }
   HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16));
   ln.kt_used = 0;
@@ -1112,7 +1112,16 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   if (!e || !out) return BANG_ERR_ARG;
   bang_stats& s = e->stats;
   if (e->allocated && e->timing && s.front_ms == 0) {
-    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp)); s.front_ms += lp->front_ms; }
+    std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv)); s.front_ms += lp->front_ms; }
+    std::sort(iv.begin(), iv.end());                   // the stamps of all lanes share one 100 MHz clock: merge the intervals
+    unsigned long long cur_lo = 0, cur_hi = 0, busy = 0;
+    for (auto& p : iv) {
+      if (p.first > cur_hi) { busy += cur_hi - cur_lo; cur_lo = p.first; cur_hi = p.second; }
+      else cur_hi = std::max(cur_hi, p.second);
+    }
+    busy += cur_hi - cur_lo;
+    s.front_busy_ms = (double)busy * 1e-5;
   }
   if (e->allocated && e->Qcur > 0 && s.candidates == 0) {   // device-side counters are fetched lazily
     std::vector<uint32_t> qs((size_t)e->Qcur * 2);

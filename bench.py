@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--recall-target", type=float, default=90.0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events in the timed steps")
     args = ap.parse_args()
 
@@ -78,11 +80,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libbang has no CPU fallback)")
+    if os.environ.get("BANG_BENCH_SHARE_GPU"):          # dry run of the N>1 logic on a 1-GPU box: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import bang_amd
     from bang_amd import shard, synth
@@ -136,7 +144,7 @@ def main():
         t_a = time.perf_counter()
         ids, dists = eng.query(my_q)
         if world > 1:                                    # the single RCCL collective of the job
-            shard.gather_ids(ids, Q, k, rank, world, device=dev)
+            shard.gather_ids(ids, Q, k, rank, world, device=cdev)
         if timed:
             torch.cuda.synchronize()
             if world > 1:
@@ -159,7 +167,7 @@ def main():
             eng.free()
             r = recall_of(ids)
             if world > 1:
-                t = torch.tensor([r], device=dev, dtype=torch.float64)
+                t = torch.tensor([r], device=cdev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 r = float(t.item())
             log(f"[bench] L={cand:3d} recall={r:.2f}")
@@ -178,7 +186,7 @@ def main():
     for _ in range(args.warmup):
         run_once(L, timed=True)
     step_s, init_s = [], []
-    agg = dict(front_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
+    agg = dict(front_ms=0.0, front_busy_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
                fetched=0, candidates=0)
     ids = None
     for _ in range(args.steps):
@@ -191,10 +199,10 @@ def main():
             agg[key] = agg[key] + st[key] if key != "iterations" else max(agg[key], st[key])
     if gt_i is not None:
         recall = recall_of(ids)
-    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=dev)
+    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-        rc = torch.tensor([recall], dtype=torch.float64, device=dev)
+        rc = torch.tensor([recall], dtype=torch.float64, device=cdev)
         dist.all_reduce(rc, op=dist.ReduceOp.MIN)
         recall = float(rc.item())
     total = float(times[0].sum().item())
@@ -245,6 +253,11 @@ def main():
                     "algorithmic_bytes_per_launch": round(evals_per_launch * bytes_per_eval, 1),
                     "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches,
                     "bytes_per_distance_eval": bytes_per_eval,
+                    "achieved_all_lanes": round(agg["dist_evals"] * bytes_per_eval / (agg["front_busy_ms"] * 1e-3) / 1e9, 3)
+                    if agg["front_busy_ms"] > 0 else None,
+                    "note": "achieved = algorithmic bytes of ONE launch / its duration (a lane's launch covers Q/lanes queries and "
+                            "overlaps the other lanes' launches); achieved_all_lanes = all algorithmic bytes / time during which "
+                            "any front kernel was running",
                     "timer": "in-kernel s_memrealtime stamps (100 MHz): per launch max(end) - min(start) over its workgroups, "
                              "every launch of the timed steps; cross-checked against rocprofv3 --kernel-trace in profiles/"}
         cpu = None
@@ -271,8 +284,7 @@ def main():
                        "qps_incl_init": round(Q * args.steps / total_incl_init, 1),
                        "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
                        "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
-                       "back_ms_per_step": round(agg["back_ms"] / args.steps, 3),
-                       "rerank_ms_per_step": round(agg["rerank_ms"] / args.steps, 3),
+                       "front_busy_ms_per_step": round(agg["front_busy_ms"] / args.steps, 3),
                        "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
                        "sync_ms_per_step": round(agg["sync_ms"] / args.steps, 3),
                        "enqueue_ms_per_step": round(agg["enqueue_ms"] / args.steps, 3),

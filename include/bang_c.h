@@ -108,6 +108,8 @@ typedef struct {
   double walker_ms;           /* host time in the adjacency gather, summed over lanes */
   double sync_ms;             /* host time blocked waiting for the parents of an iteration, summed over lanes */
   double enqueue_ms;          /* host time spent inside launch / memcpy-enqueue calls, summed over lanes */
+  double front_busy_ms;       /* length of the UNION of the front-kernel launch intervals of all lanes ("timing"=1): the time
+                                 during which at least one front kernel was running (lanes overlap) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 

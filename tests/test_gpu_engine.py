@@ -80,3 +80,58 @@ def test_engine_recall_is_meaningful(request, libbang, small_u8):
     ix, q, gt_i, gt_d = small_u8
     ids, _, _ = _run_engine(ix, q, 10, 100)
     assert O.recall(gt_i, gt_d, ids, 10) >= 90.0
+
+
+@pytest.mark.parametrize("opts", [dict(use_flag=0), dict(stage_zero_copy=0), dict(threads=1), dict(threads=3, lanes=2),
+                                  dict(fp_batch=1), dict(front_wgs=7, lanes=3), dict(timing=1)])
+def test_engine_host_loop_options_do_not_change_results(request, libbang, small_u8, opts):
+    """Every host-loop mechanism (in-kernel completion flag vs runtime sync, zero-copy vs copied adjacency rows, walker
+    team size, vector-copy batching, CU share per lane, in-kernel timing) is a pure performance knob."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 33)
+    with bang_amd.Engine(ix.dtype, graph=0) as e:
+        for k, v in opts.items():
+            if k == "use_flag":
+                continue
+            e.set_option(k, v)
+        if "use_flag" in opts:
+            import os
+            os.environ["BANG_USE_FLAG"] = "0"
+        try:
+            e2 = bang_amd.Engine(ix.dtype, graph=0) if "use_flag" in opts else e
+            e2.load_index(ix)
+            e2.set_searchparams(10, 33)
+            e2.alloc(q.shape[0])
+            for _ in range(2):
+                e2.init(q.shape[0])
+                ids, dists = e2.query(q)
+                assert np.array_equal(ids, ids_o)
+                assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            if opts.get("timing"):
+                st = e2.stats()
+                assert st["front_ms"] > 0 and 0 < st["front_busy_ms"] <= st["front_ms"] + 1e-9
+            e2.free()
+            e2.unload()
+            if e2 is not e:
+                e2.close()
+        finally:
+            os_env = __import__("os").environ
+            os_env.pop("BANG_USE_FLAG", None)
+
+
+def test_query_smaller_than_allocation(request, libbang, small_f32):
+    """bang_alloc(Q) then bang_query on fewer queries (the vector log and the rank-major distance matrix re-stride)."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_f32
+    ids_o, dists_o = O.Oracle(ix).search(q[:17], 10, 30)
+    for graph in (0, 1):
+        with bang_amd.Engine(ix.dtype, graph=graph, lanes=2) as e:
+            e.load_index(ix)
+            e.set_searchparams(10, 30)
+            e.alloc(q.shape[0])
+            e.init(17)
+            ids, dists = e.query(q[:17])
+            assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
