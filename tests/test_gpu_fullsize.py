@@ -1,0 +1,57 @@
+"""BASELINE.json configs[1] at FULL size on the GPU (N = 1 M, uint8, D = 128, R = 64, m = 32, Q = 10 000): too big for
+the oracle to cross-check every query in seconds, so the whole batch is checked through size-independent properties
+and a 128-query sample against the oracle.  The index is built on the GPU with torch (plumbing only)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sift1m_like():
+    import torch
+    from bang_amd import synth
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return synth.make_index(1_000_000, 128, "uint8", 64, 32, 10_000, K=10, n_clusters=256, device="cuda")
+
+
+def _search(ix, q, graph, L=70):
+    import bang_amd
+    with bang_amd.Engine(ix.dtype, graph=graph) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, L)
+        e.alloc(q.shape[0])
+        e.init(q.shape[0])
+        ids, dists = e.query(q)
+        st = e.stats()
+        e.free()
+        e.unload()
+    return ids, dists, st
+
+
+def test_full_size_properties_and_sample_parity(libbang, sift1m_like):
+    from oracle import oracle as O
+    ix, q, gt_i, gt_d = sift1m_like
+    ids_h, dists_h, st_h = _search(ix, q, 0)
+    ids_d, dists_d, st_d = _search(ix, q, 1)
+    # 1. graph placement does not change a single bit of the result
+    assert np.array_equal(ids_h, ids_d) and np.array_equal(dists_h.view(np.uint32), dists_d.view(np.uint32))
+    assert st_h["dist_evals"] == st_d["dist_evals"] and st_h["candidates"] == st_d["candidates"]
+    # 2. size-independent properties over the WHOLE batch
+    assert ids_h.shape == (10_000, 10) and (ids_h < ix.N).all()
+    srt = np.sort(ids_h, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                                  # 10 distinct neighbours per query
+    assert (np.diff(dists_h, axis=0) >= 0).all()                              # ascending exact distances ([rank][Q])
+    vec = ix.vectors()
+    for a in range(0, 10_000, 2000):                                          # returned distance == exact squared L2 (integers: exact)
+        blk = vec[ids_h[a:a + 2000].astype(np.int64)].astype(np.int32) - q[a:a + 2000, None, :].astype(np.int32)
+        assert np.array_equal((blk * blk).sum(axis=2).T.astype(np.float32), dists_h[:, a:a + 2000])
+    assert O.recall(gt_i, gt_d, ids_h, 10) >= 88.0
+    # 3. a sample against the oracle, bit for bit
+    sel = np.arange(0, 10_000, 79)[:128]
+    ids_o, dists_o = O.Oracle(ix).search(q[sel], 10, 70)
+    assert np.array_equal(ids_h[sel], ids_o)
+    assert np.array_equal(dists_h[:, sel].view(np.uint32), dists_o.view(np.uint32))
+    # 4. iteration accounting: nobody exceeds the cap (bang_search.cu:950), and the worklist length bounds the candidates
+    assert st_h["iterations"] <= 70 + 49 and st_h["candidates"] <= 10_000 * (70 + 50)
