@@ -34,6 +34,7 @@
 #include <memory>
 #include <string>
 #include <immintrin.h>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -145,13 +146,13 @@ struct bang_engine {
   // options
   int graph_mode = BANG_GRAPH_HOST;
   int lanes_opt = 0;      // 0 = auto
-  int threads_opt = 2;    // walker threads per lane (lane thread + helpers)
+  int threads_opt = 0;    // walker threads per lane (lane thread + helpers); 0 = auto from the CPU quota
   int device = 0;
   int pq_mode = 0;        // 0 auto (pivot-stationary if possible), 1 force LUT path
   int timing = 0;
   int front_wgs_opt = -1; // -1 auto
   int front_wgs = 0;      // workgroups per front-kernel launch (0 = all CUs); set from the lane count
-  int check_every = 4;    // device-graph mode: poll the active counter every N iterations
+  int check_every = 16;   // device-graph mode: poll the active counter every N iterations
   // index
   bool loaded = false;
   uint64_t medoid = 0, entry_len = 0;
@@ -208,8 +209,13 @@ struct bang_engine {
   uint32_t* h_done = nullptr;          // mapped pinned [lanes*16]: completion flags written by the front kernel
   uint32_t* h_done_dev = nullptr;
   uint32_t* d_done_count = nullptr;    // [lanes*16] device arrival counters
-  int stage_zero_copy = 1;             // 1: the front kernel reads the staged rows in place from mapped pinned memory
+  int stage_zero_copy = -1;            // -1: auto (2 on large-BAR devices, else 1)
+                                       // 0: H2D copy of the staged rows per lane and iteration (SDMA)
+                                       // 1: the front kernel reads the staged rows in place from mapped pinned memory
+                                       // 2: the walker writes the rows straight into device memory through the PCIe BAR
+                                       //    (large-BAR systems: hipMalloc'ed memory is CPU-writable; write-combined stores)
   uint32_t* h_stage_dev = nullptr;     // device alias of h_stage
+  int threads_eff = 1, stage_mode_eff = 1;   // resolved at bang_alloc
   int use_flag = 1;                    // 0: wait for the front kernel with hipStreamSynchronize + D2H copy of the parents (debug/ablation)
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
@@ -435,8 +441,8 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   p.Q = ln.nq; p.R = e->R; p.m = e->m; p.L = (uint32_t)e->L; p.medoid = (uint32_t)e->medoid;
   p.psz = e->psz; p.mp = e->mp;
   p.max_wgs = e->front_wgs;
-  p.d_stage = e->stage_zero_copy ? (e->h_stage_dev ? e->h_stage_dev + q0 * BANG_STAGE_STRIDE : nullptr)
-                                 : (e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr);
+  p.d_stage = (e->stage_mode_eff == 1) ? (e->h_stage_dev ? e->h_stage_dev + q0 * BANG_STAGE_STRIDE : nullptr)
+                                        : (e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr);
   p.d_seed = e->d_seed;
   p.d_codes = e->d_codes;
   p.d_pivots_packed = e->d_pivots_packed;
@@ -482,7 +488,8 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   const uint64_t elen = e->entry_len;
   const uint8_t* graph = e->graph;
   const uint32_t* parents = e->h_parents + ln.q0;
-  uint32_t* stage = e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE;
+  // mode 2: the rows go straight to device memory (CPU stores through the BAR; never read back from there)
+  uint32_t* stage = (e->stage_mode_eff == 2 ? e->d_stage : e->h_stage) + (size_t)ln.q0 * BANG_STAGE_STRIDE;
   uint8_t* fp_row = e->h_fp + ((size_t)row * e->Qcur + ln.q0) * vb;
   const uint32_t R = e->R;
   uint32_t active = 0, np = 0;
@@ -521,6 +528,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
       if (par == BANG_IDLE_PARENT) ++active;
     }
   }
+  if (e->stage_mode_eff == 2) _mm_sfence();             // drain the write-combining buffers before the launch
   *n_active = active;
   *n_parents = np;
 }
@@ -699,7 +707,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       }
       if (active == 0) break;                                                // :958
       ENQ_BEGIN();
-      if (!e->stage_zero_copy)
+      if (e->stage_mode_eff == 0)
       LANE_HIP(hipMemcpyAsync((void*)(e->d_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE), e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
                               (size_t)ln.nq * BANG_STAGE_STRIDE * 4, hipMemcpyHostToDevice, ln.s_main));   // :827-833
       ENQ_END();
@@ -805,7 +813,7 @@ void start_threads(bang_engine* e) {
   pool.shutdown = false;
   pool.query_seq = 0;
   const int nl = (int)e->lanes.size();
-  const int T = std::max(1, e->threads_opt);
+  const int T = std::max(1, e->threads_eff);
   for (int i = 0; i < nl; ++i) {
     Lane* ln = e->lanes[(size_t)i].get();
     const uint32_t epoch0 = ln->epoch.load(std::memory_order_acquire);
@@ -845,10 +853,11 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   // BANG_LANES=n, BANG_DEVICE=ordinal, BANG_PQ=0|1, BANG_TIMING=0|1
   if (const char* v = getenv("BANG_GRAPH")) e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
   if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
-  if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(1, atoi(v));
+  if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(0, atoi(v));
+  if (const char* v = getenv("BANG_CHECK_EVERY")) e->check_every = std::max(1, atoi(v));
   if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
-  if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_FP_BATCH")) e->fp_batch = std::max(1, atoi(v));
   if (const char* v = getenv("BANG_DEVICE")) e->device = atoi(v);
@@ -871,11 +880,11 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   const std::string k(key);
   if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE) return BANG_ERR_ARG; e->graph_mode = (int)value; }
   else if (k == "lanes") { if (value < 0 || value > 256) return BANG_ERR_ARG; e->lanes_opt = (int)value; }
-  else if (k == "threads") { if (value < 1) return BANG_ERR_ARG; e->threads_opt = (int)value; }
+  else if (k == "threads") { if (value < 0) return BANG_ERR_ARG; e->threads_opt = (int)value; }
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
   else if (k == "timing") { e->timing = (int)value; }
-  else if (k == "stage_zero_copy") { e->stage_zero_copy = value ? 1 : 0; }
+  else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
@@ -922,6 +931,24 @@ extern "C" int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklis
   return BANG_OK;
 }
 
+// CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the MI355X boxes expose 256 hardware
+// threads but grant 16 CPUs; spinning walker threads beyond the quota only starve each other)
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long quota = atol(q);
+      if (quota > 0) n = std::min<int>(n, (int)std::max<long>(1, quota / period));
+    }
+    fclose(f);
+  }
+  return std::max(1, n);
+}
+
 static int alloc_buffers(bang_engine* e, int Q) {
   const size_t L = (size_t)e->L, nq = (size_t)Q;
   const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
@@ -961,6 +988,15 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
+  if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, usable_cpus() / std::max(1, nl)));
+  else e->threads_eff = e->threads_opt;
+  if (e->stage_zero_copy < 0) {                          // CPU-writable device memory (large BAR)?
+    int large_bar = 0;
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) != hipSuccess) large_bar = 0;
+    e->stage_mode_eff = large_bar ? 2 : 1;
+  } else e->stage_mode_eff = e->stage_zero_copy;
   if (!dev_graph) {
     HIP_TRY(hipHostMalloc((void**)&e->h_done, (size_t)nl * 16 * 4, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_done_dev, e->h_done, 0));

@@ -124,7 +124,7 @@ def main():
     Qr = q1 - q0
 
     graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
-    lanes, threads = args.lanes, 2
+    lanes, threads = args.lanes, 0                 # 0 = engine default (walker threads from the CPU quota)
     if world > 1 and graph_mode == bang_amd.GRAPH_HOST:
         # all ranks of the node share one CPU quota: keep (lanes x walker threads) x ranks within it
         cpus = usable_cpus()
