@@ -988,7 +988,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, usable_cpus() / std::max(1, nl)));
+  if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
   if (e->stage_zero_copy < 0) {                          // CPU-writable device memory (large BAR)?
     int large_bar = 0;

@@ -287,12 +287,14 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
 
     uint32_t n[NQW], sid0[NQW], sid1[NQW];   // survivors; lane's survivor id; survivor 64 (lane 0 only)
+    uint32_t h0a[NQW], h0b[NQW], h1a[NQW], h1b[NQW];   // filter slots of the lane's id / of element 64
+    bool set0[NQW], set1[NQW];                        // slots to set once the query's loads have been issued
 #pragma unroll
-    for (int u = 0; u < NQW; ++u) { n[u] = 0; sid0[u] = 0; sid1[u] = 0; }
+    for (int u = 0; u < NQW; ++u) { n[u] = 0; sid0[u] = 0; sid1[u] = 0; set0[u] = false; set1[u] = false; h0a[u] = h0b[u] = h1a[u] = h1b[u] = 0; }
 
     // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
     if (do_filter) {
-      uint32_t h0a[NQW], h0b[NQW], h1a[NQW], h1b[NQW], w0a[NQW], w0b[NQW], w1a[NQW], w1b[NQW];
+      uint32_t w0a[NQW], w0b[NQW], w1a[NQW], w1b[NQW];
       // ---- round trips B, B': visited-filter words (a hash is always a valid index).
       // CANON: every id is tested against the filter state at entry (all loads before any set)
 #pragma unroll
@@ -337,15 +339,8 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
         wave_sync();
         if ((uint32_t)lane < n[u]) sid0[u] = sc[lane];
         if (lane == 0 && n[u] > 64) sid1[u] = sc[64];
-        // the filter updates are issued AFTER everything the distance stage needs from LDS; they are
-        // fire-and-forget (no return value)
-        if (!(a.debug & 1u)) {
-          // A query's filter is touched by exactly one wave per launch and kernel boundaries publish it, so the
-          // ORs only need WORKGROUP scope: they are resolved in the XCD's L2 instead of at the memory side
-          // (device-scope atomics to 64 different lines per wave run at ~20 G/s chip-wide).
-          if (pass0) { bloom_set(&bloom[h0a[u] >> 5], 1u << (h0a[u] & 31)); bloom_set(&bloom[h0b[u] >> 5], 1u << (h0b[u] & 31)); }
-          if (pass1) { bloom_set(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); bloom_set(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
-        }
+        set0[u] = pass0 && !(a.debug & 1u);
+        set1[u] = pass1 && !(a.debug & 1u);
       }
 #pragma unroll
       for (int u = 0; u < NQW; ++u) {
@@ -503,6 +498,19 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
           }
         }
         if (found || nn > 0) ++n_active;
+      }
+    }
+
+    // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
+    // Issued LAST: vmcnt retires in order, so anything issued after an atomic waits for it (2-3 us under load);
+    // here the ORs are fire-and-forget and overlap the next queries' first round trip.  A query's filter is touched by
+    // exactly one wave per launch and kernel boundaries publish it, so workgroup scope is enough.
+    if (do_filter) {
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
+        uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
+        if (set0[u]) { bloom_set(&bloom[h0a[u] >> 5], 1u << (h0a[u] & 31)); bloom_set(&bloom[h0b[u] >> 5], 1u << (h0b[u] & 31)); }
+        if (set1[u]) { bloom_set(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); bloom_set(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
       }
     }
   }

@@ -288,7 +288,8 @@ def main():
                        "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
                        "sync_ms_per_step": round(agg["sync_ms"] / args.steps, 3),
                        "enqueue_ms_per_step": round(agg["enqueue_ms"] / args.steps, 3),
-                       "dist_evals_per_step": agg["dist_evals"] // args.steps},
+                       "dist_evals_per_step": agg["dist_evals"] // args.steps,
+                       "step_ms_min_max": [round(1e3 * float(times[0].min().item()), 3), round(1e3 * float(times[0].max().item()), 3)]},
             "roofline": roof, "cpu_baseline": cpu,
         }
     eng.free()

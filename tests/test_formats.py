@@ -89,3 +89,21 @@ def test_diskann_index_conversion_sorts_and_compacts(tmp_path, small_i8):
     assert np.array_equal(got, ix.graph)                             # shuffled lists come back sorted, vectors intact
     md = formats.read_graph_metadata(str(tmp_path / "x_disk_metadata.bin"))
     assert md == dict(medoid=ix.medoid, entry_len=ix.entry_len, dtype_code=0, D=ix.D, R=ix.R, N=ix.N)
+
+
+def test_preprocess_cli_matches_reference_usage(tmp_path, small_i8):
+    """`python -m bang_amd.preprocess` takes the same five arguments as the reference's bang_preprocess.py."""
+    import subprocess, sys, os
+    ix = small_i8[0]
+    src = str(tmp_path / "y_disk.index")
+    formats.write_diskann_index(src, ix.vectors(), ix.degrees(), ix.adjacency(), ix.medoid)
+    out = str(tmp_path / "y_disk.bin")
+    env = dict(os.environ, PYTHONPATH=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                   "bang-billion-scale-ann_amd"))
+    r = subprocess.run([sys.executable, "-m", "bang_amd.preprocess", src, out, str(ix.D), "0", str(ix.R)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "Total # of Nodes Discovered = %d" % ix.N in r.stdout
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(ix.N, ix.entry_len), ix.graph)
+    assert formats.read_graph_metadata(str(tmp_path / "y_disk_metadata.bin"))["N"] == ix.N
+    assert subprocess.run([sys.executable, "-m", "bang_amd.preprocess"], capture_output=True, env=env).returncode == 2
