@@ -126,11 +126,11 @@ def main():
     graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
     lanes, threads = args.lanes, 0                 # 0 = engine default (walker threads from the CPU quota)
     if world > 1 and graph_mode == bang_amd.GRAPH_HOST:
-        # all ranks of the node share one CPU quota: keep (lanes x walker threads) x ranks within it
-        cpus = usable_cpus()
-        threads = 1
+        # all ranks of the node share one CPU quota: size (lanes x walker threads) from this rank's share of it
+        share = max(1, usable_cpus() // world)
         if not lanes:
-            lanes = max(1, min(4, cpus // (2 * world)))
+            lanes = max(1, min(4, share // 2, Qr // 512 if Qr >= 512 else 1))
+        threads = max(1, min(4, share // lanes))
     eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=lanes, threads=threads,
                           timing=0 if args.no_events else 1)
     eng.load_index(ix, d_codes=d_codes)
