@@ -981,7 +981,13 @@ static int alloc_buffers(bang_engine* e, int Q) {
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
     HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocMapped));      // :416
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_stage_dev, e->h_stage, 0));
-    BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
+    // The walker may write these rows from the CPU through the PCIe BAR (stage mode 2): ask for fine-grained
+    // (host-coherent) device memory so that visibility does not hinge on kernel-boundary L2 invalidation alone.
+    if (hipExtMallocWithFlags((void**)&e->d_stage, std::max<size_t>(nq * BANG_STAGE_STRIDE * 4, 16), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
+    }
+    HIP_TRY(hipMemset(e->d_stage, 0, nq * BANG_STAGE_STRIDE * 4));
     memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
     HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
   }
