@@ -31,7 +31,7 @@ class BangError(RuntimeError):
 class IterParams(C.Structure):
     _fields_ = [
         ("Q", C.c_uint32), ("R", C.c_uint32), ("m", C.c_uint32), ("L", C.c_uint32), ("medoid", C.c_uint32),
-        ("iter", C.c_uint32), ("psz", C.c_uint32), ("mp", C.c_uint32), ("first", C.c_uint32), ("max_wgs", C.c_uint32),
+        ("iter", C.c_uint32), ("psz", C.c_uint32), ("mp", C.c_uint32), ("first", C.c_uint32), ("max_wgs", C.c_uint32), ("d_qmap", C.c_void_p), ("n_all", C.c_uint32),
         ("d_stage", C.c_void_p), ("d_seed", C.c_void_p), ("d_codes", C.c_void_p), ("d_pivots_packed", C.c_void_p),
         ("d_qc", C.c_void_p), ("d_lut", C.c_void_p), ("d_graph", C.c_void_p), ("entry_len", C.c_uint64),
         ("vec_bytes", C.c_uint32),

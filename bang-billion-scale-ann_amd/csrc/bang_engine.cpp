@@ -114,6 +114,11 @@ struct Lane {
   std::atomic<bool> team_active{false};
   uint32_t job_row = 0;
   bool job_adj = false;
+  // straggler compaction: slot -> query maps (double buffered), CPU-writable (BAR) or mapped pinned
+  uint32_t* qmap_host[2] = {nullptr, nullptr};   // where the CPU writes
+  uint32_t* qmap_dev[2] = {nullptr, nullptr};    // what the kernels read
+  bool qmap_is_device = false;
+  std::vector<uint32_t> parents_tmp;             // device-graph mode: parents fetched at a poll
   std::atomic<uint32_t> job_active{0}, job_parents{0};
   std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
   std::atomic<uint32_t> phase_iter{0};
@@ -217,6 +222,7 @@ struct bang_engine {
   uint32_t* h_stage_dev = nullptr;     // device alias of h_stage
   int threads_eff = 1, stage_mode_eff = 1;   // resolved at bang_alloc
   int use_flag = 1;                    // 0: wait for the front kernel with hipStreamSynchronize + D2H copy of the parents (debug/ablation)
+  int compact = 1;                     // straggler compaction on/off
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
   bang_stats stats{};
@@ -344,6 +350,10 @@ void free_batch(bang_engine* e) {
     if (ln.ev_fp) (void)hipEventDestroy(ln.ev_fp);
     if (ln.d_ktime) (void)hipFree(ln.d_ktime);
     ln.d_ktime = nullptr;
+    for (int b = 0; b < 2; ++b) {
+      if (ln.qmap_host[b]) { if (ln.qmap_is_device) (void)hipFree(ln.qmap_host[b]); else (void)hipHostFree(ln.qmap_host[b]); }
+      ln.qmap_host[b] = ln.qmap_dev[b] = nullptr;
+    }
   }
   e->lanes.clear();
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
@@ -652,6 +662,20 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   bang_iter_params p;
   fill_params(e, ln, p);
   if (!dev_graph) e->h_done[(size_t)ln.index * 16] = 0;
+  p.n_all = ln.nq;
+  // Straggler compaction: most queries finish after ~L+5 iterations but the batch runs until its last query does (up to
+  // L+49).  Once at most half of a lane's queries are active the kernels iterate over a slot -> query map of the active
+  // ones only; finished queries never change state again, so skipping them cannot change any result.
+  auto set_qmap = [&](const uint32_t* parents, uint32_t active, uint32_t buf) {
+    if (!e->compact || active == 0 || active * 2 > ln.nq) { p.d_qmap = nullptr; p.Q = ln.nq; return; }
+    uint32_t* dst = ln.qmap_host[buf];
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < ln.nq; ++i)
+      if (parents[i] != BANG_NO_PARENT) dst[n++] = i;
+    if (ln.qmap_is_device) _mm_sfence();
+    p.d_qmap = ln.qmap_dev[buf];
+    p.Q = n;
+  };
   if (!dev_graph && e->stagger_us > 0 && ln.index > 0) {
     const auto ts = Clock::now();
     while (ms_since(ts) * 1000.0 < (double)(e->stagger_us * ln.index)) _mm_pause();
@@ -706,6 +730,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
         fp_hi = iter;
       }
       if (active == 0) break;                                                // :958
+      set_qmap(e->h_parents + ln.q0, active, (iter + 1) & 1u);
       ENQ_BEGIN();
       if (e->stage_mode_eff == 0)
       LANE_HIP(hipMemcpyAsync((void*)(e->d_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE), e->h_stage + (size_t)ln.q0 * BANG_STAGE_STRIDE,
@@ -740,6 +765,13 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
         LANE_HIP(hipMemcpyAsync(&act, e->d_active + iter, 4, hipMemcpyDeviceToHost, ln.s_main));
         LANE_HIP(hipStreamSynchronize(ln.s_main));
         if (act == 0) break;
+        if (e->compact) {                                                    // refresh the slot -> query map from the parents
+          if (ln.parents_tmp.size() < ln.nq) ln.parents_tmp.resize(ln.nq);
+          LANE_HIP(hipMemcpy(ln.parents_tmp.data(), e->d_parents_dev + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost));
+          uint32_t n_act = 0;
+          for (uint32_t i = 0; i < ln.nq; ++i) n_act += ln.parents_tmp[i] != BANG_NO_PARENT;
+          set_qmap(ln.parents_tmp.data(), n_act, 0);
+        }
       }
     }
   }
@@ -856,6 +888,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_CHECK_EVERY")) e->check_every = std::max(1, atoi(v));
   if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
+  if (const char* v = getenv("BANG_COMPACT")) e->compact = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
@@ -886,6 +919,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "timing") { e->timing = (int)value; }
   else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
+  else if (k == "compact") { e->compact = value ? 1 : 0; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
@@ -1026,6 +1060,19 @@ static int alloc_buffers(bang_engine* e, int Q) {
     HIP_TRY(hipStreamCreateWithFlags(&ln.s_fp, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ln.ev_fp, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) {                          // slot -> query maps for straggler compaction
+      const size_t bytes = std::max<size_t>((size_t)Q * 4, 64);   // a lane never owns more than Q queries
+      if (e->stage_mode_eff == 2 && !dev_graph &&
+          hipExtMallocWithFlags((void**)&ln.qmap_host[b], bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+        ln.qmap_dev[b] = ln.qmap_host[b];
+        ln.qmap_is_device = true;
+      } else {
+        (void)hipGetLastError();
+        if (ln.qmap_is_device) { bang_set_error("qmap allocation failed"); return BANG_ERR_HIP; }
+        HIP_TRY(hipHostMalloc((void**)&ln.qmap_host[b], bytes, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
+      }
+    }
     if (e->timing) {
       ln.kt_launches = rows + 4;
       HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));

@@ -241,9 +241,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     bool valid[NQW];
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
-      const uint32_t qq = g0 + (uint32_t)u * total_waves;
-      valid[u] = qq < p.Q;
-      q[u] = valid[u] ? qq : g0;          // invalid slots shadow slot 0: loads stay legal, every store is guarded
+      const uint32_t slot = g0 + (uint32_t)u * total_waves;
+      valid[u] = slot < p.Q;
+      const uint32_t s_ok = valid[u] ? slot : g0;   // invalid slots shadow slot 0: loads stay legal, every store is guarded
+      q[u] = p.d_qmap ? uni(p.d_qmap[s_ok]) : s_ok;  // straggler compaction: slot -> query
     }
 
     // ---- round trip A: every load that does not depend on another load of the query, issued
@@ -541,7 +542,8 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
     __syncthreads();
     if (*s_last) {
-      for (uint32_t i = threadIdx.x; i < p.Q; i += blockDim.x) {
+      const uint32_t n_par = p.n_all ? p.n_all : p.Q;
+      for (uint32_t i = threadIdx.x; i < n_par; i += blockDim.x) {
         const uint32_t v = __hip_atomic_load(&p.d_parents[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&p.h_parents[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_
   BackLds& s = lds_all[wave];
   const uint32_t L = p.L;
 
-  for (uint32_t q = blockIdx.x * BACK_WAVES + wave; q < p.Q; q += gridDim.x * BACK_WAVES) {
+  for (uint32_t slot = blockIdx.x * BACK_WAVES + wave; slot < p.Q; slot += gridDim.x * BACK_WAVES) {
+    const uint32_t q = p.d_qmap ? uni(p.d_qmap[slot]) : slot;
     const uint32_t n = uni(p.d_cnt[q]);
     if (n == 0) continue;   // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
     const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;

@@ -164,6 +164,10 @@ typedef struct {
   uint32_t psz, mp;                    /* pivot layout (bang_pq_layout); psz == 0 => LUT path */
   uint32_t first;                      /* 1: use the seed list + compute_parent1 semantics */
   uint32_t max_wgs;                    /* cap on workgroups of the front kernel (0 = one per CU); lanes share the GPU */
+  /* straggler compaction: when d_qmap != NULL the kernels iterate over Q SLOTS and slot s works on query d_qmap[s]
+   * (all per-query arrays stay indexed by the query); n_all = number of queries behind the arrays (parents copy). */
+  const uint32_t* d_qmap;
+  uint32_t n_all;
   /* inputs */
   const uint32_t* d_stage;             /* [Q][BANG_STAGE_STRIDE] staged adjacency {count, ids} (first==0) */
   const uint32_t* d_seed;              /* [1 + R+1] {count, MEDOID, adj(MEDOID)...}  (first==1) */
