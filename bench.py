@@ -95,7 +95,11 @@ def main():
     import bang_amd
     from bang_amd import shard, synth
     from oracle import oracle as O           # checker + cpu_baseline leg only
-    bang_amd.build()
+    if rank == 0:                            # one builder per node; the others wait (make is not re-entrant)
+        bang_amd.build()
+        O.build()
+    if world > 1:
+        dist.barrier()
 
     # ------------------------------------------------------------------ workload
     t0 = time.time()
