@@ -119,6 +119,13 @@ struct Lane {
   uint32_t* qmap_dev[2] = {nullptr, nullptr};    // what the kernels read
   bool qmap_is_device = false;
   std::vector<uint32_t> parents_tmp;             // device-graph mode: parents fetched at a poll
+  // persistent lane kernel ("persistent"=1): the word that paces it (CPU-written: BAR or mapped pinned), and its device
+  // arrival counters [0] = gave-up flag, [16 + iter] = workgroups that finished iteration iter
+  uint32_t* go_host = nullptr;
+  uint32_t* go_dev = nullptr;
+  bool go_is_device = false;
+  uint32_t* d_pcnt = nullptr;
+  size_t pcnt_words = 0;
   std::atomic<uint32_t> job_active{0}, job_parents{0};
   std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
   std::atomic<uint32_t> phase_iter{0};
@@ -223,6 +230,8 @@ struct bang_engine {
   int threads_eff = 1, stage_mode_eff = 1;   // resolved at bang_alloc
   int use_flag = 1;                    // 0: wait for the front kernel with hipStreamSynchronize + D2H copy of the parents (debug/ablation)
   int compact = 1;                     // straggler compaction on/off
+  int persistent = 0;                  // 1: host-graph mode runs ONE front+back kernel per lane and batch, paced by a host-written word
+  int persist_wgs = 0;                 // workgroups of a lane's persistent kernel (all resident: CUs / lanes)
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
   bang_stats stats{};
@@ -350,6 +359,10 @@ void free_batch(bang_engine* e) {
     if (ln.ev_fp) (void)hipEventDestroy(ln.ev_fp);
     if (ln.d_ktime) (void)hipFree(ln.d_ktime);
     ln.d_ktime = nullptr;
+    if (ln.d_pcnt) (void)hipFree(ln.d_pcnt);
+    ln.d_pcnt = nullptr;
+    if (ln.go_host) { if (ln.go_is_device) (void)hipFree(ln.go_host); else (void)hipHostFree(ln.go_host); }
+    ln.go_host = ln.go_dev = nullptr; ln.go_is_device = false;
     for (int b = 0; b < 2; ++b) {
       if (ln.qmap_host[b]) { if (ln.qmap_is_device) (void)hipFree(ln.qmap_host[b]); else (void)hipHostFree(ln.qmap_host[b]); }
       ln.qmap_host[b] = ln.qmap_dev[b] = nullptr;
@@ -693,12 +706,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                               e->D, e->m, dim_adjust, ln.s_main));
 
   uint32_t iter = 1;                                                         // :596
-  p.first = 1; p.iter = iter; p.done_value = iter;
-  if (dev_graph) p.d_active = e->d_active + iter;
-  p.d_ktime = ktime_slot(e, ln);
-  BANG_TRY(bang_k_front(&p, ln.s_main));                                     // K5+K2+K4a :650-678
-  ++ln.front_launches;
-
+  const bool persist = ln.d_pcnt != nullptr;
   // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
   uint32_t fp_lo = 0, fp_hi = 0;
   bool fp_pending = false, fp_any = false;
@@ -711,6 +719,46 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     fp_any = true;
     return BANG_OK;
   };
+
+  if (persist) {
+    // ONE launch per lane and batch: the kernel runs front(t) -> completion flag -> back(t) for t = 1..cap, and waits before
+    // every front(t) until this thread has stored t into `go` (after the walker's rows of iteration t-1 are in device memory).
+    auto set_go = [&](uint32_t v) {
+      _mm_sfence();                                   // the staged rows (write-combined BAR stores) before the word
+      *(volatile uint32_t*)ln.go_host = v;
+      _mm_sfence();
+    };
+    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, ln.pcnt_words * 4, ln.s_main));
+    set_go(1);
+    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq;
+    p.max_wgs = (uint32_t)e->persist_wgs;
+    unsigned long long* kt_base = (e->timing && ln.d_ktime && ln.kt_launches >= (size_t)cap_iter + 1) ? ln.d_ktime : nullptr;
+    BANG_TRY(bang_k_lane_persistent(&p, cap_iter, ln.go_dev, ln.d_pcnt + 16, kt_base, ln.d_pcnt, ln.s_main));
+    ++ln.front_launches;
+    for (;;) {
+      const int rc = wait_flag(e, ln, iter);
+      if (rc != BANG_OK) { set_go(0xFFFFFFFFu); return rc; }
+      const auto t0 = Clock::now();
+      uint32_t n_par = 0;
+      const uint32_t active = walk(e, ln, iter, iter < cap_iter, &n_par);
+      ln.walker_ms += ms_since(t0);
+      if (n_par) {
+        if (!fp_pending) { fp_lo = iter; fp_pending = true; }
+        fp_hi = iter;
+      }
+      if (iter == cap_iter) break;                                           // the kernel ends by itself after the cap
+      if (active == 0) { set_go(0xFFFFFFFFu); break; }                       // :958
+      set_go(iter + 1);
+      if (fp_pending && fp_hi - fp_lo + 1 >= (uint32_t)e->fp_batch) { ENQ_BEGIN(); BANG_TRY(flush_fp()); ENQ_END(); }
+      ++iter;
+    }
+    if (kt_base) ln.kt_used = (size_t)iter + 1;
+  } else {
+  p.first = 1; p.iter = iter; p.done_value = iter;
+  if (dev_graph) p.d_active = e->d_active + iter;
+  p.d_ktime = ktime_slot(e, ln);
+  BANG_TRY(bang_k_front(&p, ln.s_main));                                     // K5+K2+K4a :650-678
+  ++ln.front_launches;
 
   for (;;) {
     p.first = 0; p.iter = iter;
@@ -775,6 +823,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       }
     }
   }
+  }
   ln.iterations = iter;
   ln.phase.store(5);
   DBG("[lane %d] loop done iter=%u\n", ln.index, iter);
@@ -800,9 +849,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                           (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
+  uint32_t gave_up = 0;
+  if (persist) LANE_HIP(hipMemcpyAsync(&gave_up, ln.d_pcnt, 4, hipMemcpyDeviceToHost, ln.s_main));
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
+  if (gave_up) { bang_set_error("persistent lane kernel gave up waiting for the host walker (lane %d)", ln.index); return BANG_ERR_HIP; }
   DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats
   return BANG_OK;
@@ -890,6 +942,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
   if (const char* v = getenv("BANG_COMPACT")) e->compact = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_FP_BATCH")) e->fp_batch = std::max(1, atoi(v));
@@ -920,6 +973,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "compact") { e->compact = value ? 1 : 0; }
+  else if (k == "persistent") { e->persistent = value ? 1 : 0; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
@@ -1052,6 +1106,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess) cus = prop.multiProcessorCount;
     // lanes are rarely all in their kernel phase at once: give each up to twice its fair share of the CUs
     e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::min(cus, std::max(1, 2 * cus / nl)) : 0);
+    e->persist_wgs = std::max(1, cus / nl);
   }
   for (int i = 0; i < nl; ++i) {
     Lane& ln = *e->lanes[(size_t)i];
@@ -1071,6 +1126,22 @@ static int alloc_buffers(bang_engine* e, int Q) {
         if (ln.qmap_is_device) { bang_set_error("qmap allocation failed"); return BANG_ERR_HIP; }
         HIP_TRY(hipHostMalloc((void**)&ln.qmap_host[b], bytes, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
+      }
+    }
+    // (PQ layouts that need the 256-VGPR kernel build have no persistent instance: they keep the launch-per-iteration loop)
+    if (e->persistent && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u)) {
+      ln.pcnt_words = 16 + rows + 4;
+      BANG_TRY(dmalloc(&ln.d_pcnt, ln.pcnt_words));
+      HIP_TRY(hipMemset(ln.d_pcnt, 0, ln.pcnt_words * 4));
+      if (e->stage_mode_eff == 2 && hipExtMallocWithFlags((void**)&ln.go_host, 64, hipDeviceMallocFinegrained) == hipSuccess) {
+        HIP_TRY(hipMemset(ln.go_host, 0, 64));
+        ln.go_dev = ln.go_host;
+        ln.go_is_device = true;
+      } else {
+        (void)hipGetLastError();
+        HIP_TRY(hipHostMalloc((void**)&ln.go_host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&ln.go_dev, ln.go_host, 0));
+        memset(ln.go_host, 0, 64);
       }
     }
     if (e->timing) {

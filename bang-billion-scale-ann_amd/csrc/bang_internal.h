@@ -24,6 +24,13 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
+// Persistent lane kernel (host-graph mode, opt-in): ONE launch runs front(t) -> completion flag -> back(t) for
+// t = p->iter .. iter_end on p->max_wgs resident workgroups; before every front(t) it waits until *d_go >= t
+// (0xFFFFFFFF = stop).  d_done_counts: zeroed [iter_end + 2]; d_ktime_base: [iter_end + 1][256][2] or NULL; *d_abort is set
+// when the kernel gave up waiting (3 s).  Needs p->h_done_flag / h_parents / d_stage; no d_qmap, no d_graph.
+int bang_k_lane_persistent(const bang_iter_params* p, uint32_t iter_end, const uint32_t* d_go, uint32_t* d_done_counts,
+                           unsigned long long* d_ktime_base, uint32_t* d_abort, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "bang_c.h"
 #include "bang_internal.h"
@@ -172,6 +173,137 @@ __device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ cod
 }
 
 // ------------------------------------------------------------------------------------------
+// back: K3a stable sort of the survivors + K3b merge into the worklist, one wave per query
+// ------------------------------------------------------------------------------------------
+#define BACK_WAVES 4
+struct BackLds {
+  float sd[BANG_NBR_STRIDE];      // unsorted distances
+  uint32_t si[BANG_NBR_STRIDE];
+  float td[BANG_NBR_STRIDE];      // sorted
+  uint32_t ti[BANG_NBR_STRIDE];
+  float wd[BANG_MAX_L];
+  uint32_t wi[BANG_MAX_L];
+  uint8_t wv[BANG_MAX_L];
+};
+// per-wave LDS view used by back_one_query (static BackLds in back_kernel, carved from dynamic LDS in the persistent kernel)
+struct BackView {
+  float* sd; uint32_t* si; float* td; uint32_t* ti; float* wd; uint32_t* wi; uint8_t* wv;
+};
+// LDS words a wave needs for a BackView at worklist length L (16-byte multiple)
+__host__ __device__ inline uint32_t back_view_words(uint32_t L) { return (4u * BANG_NBR_STRIDE + 2u * L + (L + 3u) / 4u + 3u) & ~3u; }
+__device__ __forceinline__ BackView back_view_at(uint32_t* base, uint32_t L) {
+  BackView v;
+  v.sd = (float*)base; v.si = base + BANG_NBR_STRIDE; v.td = (float*)(base + 2 * BANG_NBR_STRIDE); v.ti = base + 3 * BANG_NBR_STRIDE;
+  v.wd = (float*)(base + 4 * BANG_NBR_STRIDE); v.wi = base + 4 * BANG_NBR_STRIDE + L; v.wv = (uint8_t*)(base + 4 * BANG_NBR_STRIDE + 2 * L);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target <= arr[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t hi, float target) {  // :1735-1749
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target >= arr[mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// sort + merge of one query by one wave (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
+__device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32_t q, uint32_t iter, const BackView& s, int lane) {
+  const uint32_t L = p.L;
+  const uint32_t n = uni(p.d_cnt[q]);
+  if (n == 0) return;     // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
+  const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
+  const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
+  uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
+  float* wl_dist = p.d_wl_dist + (size_t)q * L;
+  uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
+  const uint32_t mark = p.d_mark[q];
+
+  for (uint32_t i = lane; i < n; i += WAVE) { s.sd[i] = dist[i]; s.si[i] = nbrs[i]; }
+  wave_sync();
+  // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    const float d = s.sd[i];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+      const float o = s.sd[j];
+      r += (o < d || (o == d && j < i)) ? 1u : 0u;
+    }
+    s.td[r] = d;
+    s.ti[r] = s.si[i];
+  }
+  wave_sync();
+
+  uint32_t new_n;
+  if (iter == 1) {                                       // :1638-1649
+    new_n = n < L ? n : L;
+    for (uint32_t i = lane; i < new_n; i += WAVE) {
+      const uint32_t id = s.ti[i];
+      wl_ids[i] = id;
+      wl_dist[i] = s.td[i];
+      wl_vis[i] = (id == p.medoid || id == mark) ? 1 : 0;  // + mark step :1711-1714
+    }
+  } else {                                               // :1650-1708
+    const uint32_t w_n = uni(p.d_wl_cnt[q]);
+    for (uint32_t i = lane; i < w_n; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
+    wave_sync();
+    const float worst = s.wd[w_n - 1];
+    const uint32_t lim = L < n ? L : n;
+    // nb = number of leading new entries with dist < worst (stop at the first >=) :1653-1657
+    uint32_t nb = lim;
+    for (uint32_t base = 0; base < lim; base += WAVE) {
+      const uint32_t i = base + lane;
+      const bool ge = (i < lim) && (s.td[i] >= worst);
+      const uint64_t mk = __ballot(ge);
+      if (mk) { nb = base + (uint32_t)__builtin_ctzll(mk); break; }
+    }
+    const uint32_t room = L - w_n;
+    const uint32_t fill = room < n ? room : n;
+    if (fill > nb) nb = fill;                            // :1660
+    new_n = (w_n + nb) < L ? (w_n + nb) : L;             // :1662
+    for (uint32_t i = lane; i < nb; i += WAVE) {         // new entries: lower_bound + i :1675-1677
+      const float d = s.td[i];
+      const uint32_t pos = lower_bound_lds(s.wd, w_n, d) + i;
+      if (pos < new_n) {
+        const uint32_t id = s.ti[i];
+        wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (id == mark) ? 1 : 0;
+      }
+    }
+    for (uint32_t k = lane; k < w_n; k += WAVE) {        // old entries: upper_bound + k :1678-1680
+      const float d = s.wd[k];
+      const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
+      if (pos < new_n) {
+        const uint32_t id = s.wi[k];
+        wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (s.wv[k] || id == mark) ? 1 : 0;
+      }
+    }
+  }
+  if (lane == 0) p.d_wl_cnt[q] = new_n;
+  wave_sync();
+}
+
+__global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_params p) {
+  __shared__ BackLds lds_all[BACK_WAVES];
+  const int lane = lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  BackLds& b = lds_all[wave];
+  BackView s;
+  s.sd = b.sd; s.si = b.si; s.td = b.td; s.ti = b.ti; s.wd = b.wd; s.wi = b.wi; s.wv = b.wv;
+  for (uint32_t slot = blockIdx.x * BACK_WAVES + wave; slot < p.Q; slot += gridDim.x * BACK_WAVES) {
+    const uint32_t q = p.d_qmap ? uni(p.d_qmap[slot]) : slot;
+    back_one_query(p, q, p.iter, s, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // front kernel: K5 filter -> K2 distances -> K4 parent, one wave per query
 // ------------------------------------------------------------------------------------------
 struct FrontArgs {
@@ -179,7 +311,16 @@ struct FrontArgs {
   uint32_t stages;      // bit0 filter, bit1 distance, bit2 parent
   uint32_t debug;       // timing-only ablations (BANG_FRONT_DEBUG): 1 no filter updates, 2 no distance math, 4 no pivot staging
   uint32_t lds_piv_floats;
+  // persistent mode (one launch runs iterations p.iter .. iter_end, paced by the host through `go`)
+  const uint32_t* go;          // device-visible word: the kernel may run iteration t once *go >= t; 0xFFFFFFFF = stop
+  uint32_t iter_end;           // last iteration (the cap)
+  uint32_t scratch_words;      // LDS words per wave (front compaction scratch and back view share them)
+  uint32_t* done_counts;       // [iter_end + 2] arrival counters, one per iteration (zeroed by the host)
+  unsigned long long* ktime_base;   // [iter][KT_WGS][2] stamps or NULL
+  uint32_t* abort_flag;        // set to 1 if the kernel gave up waiting for `go`
 };
+#define KT_WGS_DEV 256u
+#define BANG_GO_STOP 0xFFFFFFFFu
 
 // per-wave LDS scratch (uint32 words): compacted ids [0..71]
 #define FRONT_SCRATCH_WORDS 72
@@ -190,13 +331,13 @@ struct FrontArgs {
 // filter words -> code rows, ~2 us each) with at most 16 waves per CU (the pivot table owns the LDS), so every
 // phase is executed for NQW independent queries back to back: their loads are in flight together and the wave
 // pays each round trip once per NQW queries.
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST>
 __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_iter_params& p = a.p;
   float* piv_lds = lds;
   uint32_t* scratch_all = (uint32_t*)(lds + a.lds_piv_floats);
-  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  if (!PERSIST && p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const bool do_filter = ALL || (a.stages & 1u);
   const bool do_dist = ALL || (a.stages & 2u);
   const bool do_parent = ALL || (a.stages & 4u);
@@ -226,15 +367,45 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const int lane = lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
-  uint32_t* scratch = scratch_all + wave * (FRONT_SCRATCH_WORDS * NQW);
+  uint32_t* scratch = scratch_all + wave * (PERSIST ? a.scratch_words : FRONT_SCRATCH_WORDS * NQW);
   const uint32_t medoid = p.medoid;
   const uint32_t L = p.L;
-  const uint32_t first = p.first ? 1u : 0u;
   const uint32_t lane_l = (uint32_t)lane < L ? (uint32_t)lane : L - 1;
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   uint32_t n_active = 0;
+
+  // PERSIST: one launch runs iterations p.iter .. a.iter_end for the queries its waves own (static ownership: a query is
+  // always handled by the same wave, so no grid-wide barrier is needed); the host paces it through `go`.
+  for (uint32_t cur_iter = p.iter; cur_iter <= (PERSIST ? a.iter_end : p.iter); ++cur_iter) {
+  const uint32_t first = PERSIST ? (cur_iter == 1 ? 1u : 0u) : (p.first ? 1u : 0u);
+  if (PERSIST) {
+    // wait until the host has staged the adjacency rows of this iteration
+    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;    // one LDS word behind the per-wave scratch
+    if (threadIdx.x == 0) {
+      uint32_t v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (v < cur_iter) {                         // BANG_GO_STOP is the largest value: it also ends the wait
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {      // 3 s at 100 MHz: the host is gone
+          v = BANG_GO_STOP;
+          if (a.abort_flag) *a.abort_flag = 1u;
+          break;
+        }
+      }
+      *s_go = v;
+      // everything other agents (the CPU through the BAR) or this kernel's own atomics wrote since the last iteration
+      // must not be served from this CU's L1
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (*s_go == BANG_GO_STOP) break;
+    if (a.ktime_base && threadIdx.x == 0)
+      a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 2] = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (uint32_t g0 = gw; g0 < p.Q; g0 += total_waves * NQW) {
     uint32_t q[NQW];
@@ -275,9 +446,15 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
+      if (PERSIST) {                                     // rows were just written by the CPU: read them at system scope
+        cnt_in[u] = __hip_atomic_load(&row[u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        x0[u] = __hip_atomic_load(&row[u][1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        x1[u] = __hip_atomic_load(&row[u][65u * first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
       cnt_in[u] = row[u][0];
       x0[u] = row[u][1 + lane];                          // in bounds for every row kind (R <= 64)
       x1[u] = row[u][65u * first];                       // 65th id exists only in the seed list
+      }
       cc[u] = p.d_cand_cnt[q[u]];
       w_n[u] = p.d_wl_cnt[q[u]];
       pw_vis[u] = p.d_wl_vis[(size_t)q[u] * L + lane_l];
@@ -490,7 +667,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
             if (from_best) p.d_mark[qq] = parent;
             else p.d_wl_vis[(size_t)qq * L + w_hit] = 1;
             p.d_cand_ids[(size_t)qq * cand_stride + cc[u]] = parent;
-            if (p.d_cand_row) p.d_cand_row[(size_t)qq * cand_stride + cc[u]] = p.iter;
+            if (p.d_cand_row) p.d_cand_row[(size_t)qq * cand_stride + cc[u]] = cur_iter;
             p.d_cand_cnt[qq] = cc[u] + 1;
             __hip_atomic_store(&p.d_parents[qq], parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
           } else {
@@ -519,9 +696,12 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
   if (lane == 0 && p.d_active && n_active) *p.d_active = 1u;
 
-  if (p.d_ktime) {
+  if (p.d_ktime || (PERSIST && a.ktime_base)) {
     __syncthreads();
-    if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      if (PERSIST) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+      else p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
   }
 
   // Completion signal for the host walker, without any L2-wide fence (a release fence writes back every dirty
@@ -529,16 +709,17 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // write-through (agent-scope atomic stores = `sc1`), every wave drains its stores, the workgroup arrives on a
   // device counter; the LAST workgroup re-reads the parents with `sc1` loads, copies them to mapped pinned host
   // memory with system-scope stores (coalesced: one 4-byte PCIe write per query from every wave was measured at
-  // +75 us per launch), drains, and publishes done_value.  The walker thread spins on that word.
+  // +75 us per launch), drains, and publishes the iteration number.  The walker thread spins on that word.
   if (p.h_done_flag) {
     volatile uint32_t* s_last = scratch_all;        // dynamic LDS: no static allocation next to the 160 KB request
+    uint32_t* counter = PERSIST ? a.done_counts + cur_iter : p.d_done_count;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      const uint32_t old = atomicAdd(p.d_done_count, 1u);
+      const uint32_t old = atomicAdd(counter, 1u);
       const uint32_t last = (old + 1 == gridDim.x) ? 1u : 0u;
       *s_last = last;
-      if (last) atomicExch(p.d_done_count, 0u);     // every other workgroup has already arrived
+      if (last && !PERSIST) atomicExch(counter, 0u);   // every other workgroup has already arrived
     }
     __syncthreads();
     if (*s_last) {
@@ -550,122 +731,18 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag must not overtake the stores (MI355X guide)
       __syncthreads();
       if (threadIdx.x == 0)
-        __hip_atomic_store(p.h_done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.h_done_flag, PERSIST ? cur_iter : p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __syncthreads();                                 // s_last lives in wave 0's scratch: nobody may reuse it before all have read it
   }
-}
 
-// ------------------------------------------------------------------------------------------
-// back kernel: K3a stable sort of the survivors + K3b merge into the worklist, one wave per query
-// ------------------------------------------------------------------------------------------
-#define BACK_WAVES 4
-struct BackLds {
-  float sd[BANG_NBR_STRIDE];      // unsorted distances
-  uint32_t si[BANG_NBR_STRIDE];
-  float td[BANG_NBR_STRIDE];      // sorted
-  uint32_t ti[BANG_NBR_STRIDE];
-  float wd[BANG_MAX_L];
-  uint32_t wi[BANG_MAX_L];
-  uint8_t wv[BANG_MAX_L];
-};
-
-__device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732
-  uint32_t lo = 0;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (target <= arr[mid]) hi = mid; else lo = mid + 1;
+  if (PERSIST) {
+    // K3a + K3b for the queries of this wave, while the host walks (the standalone back kernel in the launch-per-iteration mode)
+    const BackView bv = back_view_at(scratch, L);
+    for (uint32_t slot = gw; slot < p.Q; slot += total_waves) back_one_query(p, slot, cur_iter, bv, lane);
+    n_active = 0;
   }
-  return lo;
-}
-__device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t hi, float target) {  // :1735-1749
-  uint32_t lo = 0;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (target >= arr[mid]) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-__global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_params p) {
-  __shared__ BackLds lds_all[BACK_WAVES];
-  const int lane = lane_id();
-  const uint32_t wave = uni(threadIdx.x >> 6);
-  BackLds& s = lds_all[wave];
-  const uint32_t L = p.L;
-
-  for (uint32_t slot = blockIdx.x * BACK_WAVES + wave; slot < p.Q; slot += gridDim.x * BACK_WAVES) {
-    const uint32_t q = p.d_qmap ? uni(p.d_qmap[slot]) : slot;
-    const uint32_t n = uni(p.d_cnt[q]);
-    if (n == 0) continue;   // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
-    const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
-    const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
-    uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
-    float* wl_dist = p.d_wl_dist + (size_t)q * L;
-    uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
-    const uint32_t mark = p.d_mark[q];
-
-    for (uint32_t i = lane; i < n; i += WAVE) { s.sd[i] = dist[i]; s.si[i] = nbrs[i]; }
-    wave_sync();
-    // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
-    for (uint32_t i = lane; i < n; i += WAVE) {
-      const float d = s.sd[i];
-      uint32_t r = 0;
-      for (uint32_t j = 0; j < n; ++j) {
-        const float o = s.sd[j];
-        r += (o < d || (o == d && j < i)) ? 1u : 0u;
-      }
-      s.td[r] = d;
-      s.ti[r] = s.si[i];
-    }
-    wave_sync();
-
-    uint32_t new_n;
-    if (p.iter == 1) {                                     // :1638-1649
-      new_n = n < L ? n : L;
-      for (uint32_t i = lane; i < new_n; i += WAVE) {
-        const uint32_t id = s.ti[i];
-        wl_ids[i] = id;
-        wl_dist[i] = s.td[i];
-        wl_vis[i] = (id == p.medoid || id == mark) ? 1 : 0;  // + mark step :1711-1714
-      }
-    } else {                                               // :1650-1708
-      const uint32_t w_n = uni(p.d_wl_cnt[q]);
-      for (uint32_t i = lane; i < w_n; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
-      wave_sync();
-      const float worst = s.wd[w_n - 1];
-      const uint32_t lim = L < n ? L : n;
-      // nb = number of leading new entries with dist < worst (stop at the first >=) :1653-1657
-      uint32_t nb = lim;
-      for (uint32_t base = 0; base < lim; base += WAVE) {
-        const uint32_t i = base + lane;
-        const bool ge = (i < lim) && (s.td[i] >= worst);
-        const uint64_t mk = __ballot(ge);
-        if (mk) { nb = base + (uint32_t)__builtin_ctzll(mk); break; }
-      }
-      const uint32_t room = L - w_n;
-      const uint32_t fill = room < n ? room : n;
-      if (fill > nb) nb = fill;                            // :1660
-      new_n = (w_n + nb) < L ? (w_n + nb) : L;             // :1662
-      for (uint32_t i = lane; i < nb; i += WAVE) {         // new entries: lower_bound + i :1675-1677
-        const float d = s.td[i];
-        const uint32_t pos = lower_bound_lds(s.wd, w_n, d) + i;
-        if (pos < new_n) {
-          const uint32_t id = s.ti[i];
-          wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (id == mark) ? 1 : 0;
-        }
-      }
-      for (uint32_t k = lane; k < w_n; k += WAVE) {        // old entries: upper_bound + k :1678-1680
-        const float d = s.wd[k];
-        const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
-        if (pos < new_n) {
-          const uint32_t id = s.wi[k];
-          wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (s.wv[k] || id == mark) ? 1 : 0;
-        }
-      }
-    }
-    if (lane == 0) p.d_wl_cnt[q] = new_n;
-    wave_sync();
-  }
+  }   // iterations
 }
 
 // ------------------------------------------------------------------------------------------
@@ -932,15 +1009,15 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
   });
 }
 
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST = false>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT>,
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
@@ -948,6 +1025,10 @@ static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t l
 // nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  if (a.go) {   // persistent lane kernel: one query per wave at a time, 128-VGPR build
+    return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
+                   : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
+  }
   const bool all = (a.stages == 7u);
   if (!all) {
     return aligned ? launch_front_inst<PSZ, NDW, true, false, 1, 1024>(a, grid, block, lds, st)
@@ -965,7 +1046,11 @@ static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid,
 #undef BANG_FRONT_PICK
 }
 
-static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream) {
+struct PersistArgs {
+  const uint32_t* go; uint32_t iter_end; uint32_t* done_counts; unsigned long long* ktime_base; uint32_t* abort_flag;
+};
+
+static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream, const PersistArgs* pa = nullptr) {
   if (!p) return BANG_ERR_ARG;
   if (p->Q == 0) return BANG_OK;
   if (p->R > BANG_MAX_R || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
@@ -979,6 +1064,13 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   FrontArgs a;
   a.p = *p;
   a.stages = stages;
+  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.done_counts = nullptr; a.ktime_base = nullptr; a.abort_flag = nullptr;
+  if (pa) {
+    if (stages != 7u || !pa->go || !pa->done_counts || !p->h_done_flag || p->d_qmap || p->d_graph || !p->d_stage || pa->iter_end < p->iter) {
+      bang_set_error("bad persistent launch arguments"); return BANG_ERR_ARG;
+    }
+    a.go = pa->go; a.iter_end = pa->iter_end; a.done_counts = pa->done_counts; a.ktime_base = pa->ktime_base; a.abort_flag = pa->abort_flag;
+  }
   {
     static int dbg = -1;
     if (dbg < 0) { const char* v = getenv("BANG_FRONT_DEBUG"); dbg = v ? atoi(v) : 0; }
@@ -1015,19 +1107,29 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
   // queries in flight per wave instead of 16 waves x 1 query.
   const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) > 32u;
-  int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
+  if (pa && heavy) { bang_set_error("persistent lane kernel: PQ layout needs the 256-VGPR build"); return BANG_ERR_UNSUPPORTED; }
+  int nqw = (stages != 7u || pa) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
   nqw = (nqw >= 2) ? 4 : 1;
   int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
   if (max_waves > 16) max_waves = 16;
   int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;
   if (waves > max_waves) waves = max_waves;
-  const size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
-  while (waves > 1 && piv_bytes + (size_t)waves * scratch_per_wave > lds_cap) --waves;
-  const size_t lds = piv_bytes + (size_t)waves * scratch_per_wave;
+  size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
+  size_t lds_extra = 0;
+  if (pa) {   // the wave's scratch doubles as its sort/merge view; one more 16-byte slot holds the broadcast `go` word
+    a.scratch_words = std::max<uint32_t>(FRONT_SCRATCH_WORDS, back_view_words(p->L));
+    scratch_per_wave = (size_t)a.scratch_words * 4;
+    lds_extra = 16;
+  }
+  while (waves > 1 && piv_bytes + lds_extra + (size_t)waves * scratch_per_wave > lds_cap) --waves;
+  const size_t lds = piv_bytes + lds_extra + (size_t)waves * scratch_per_wave;
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
   int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
+  // every workgroup of a persistent launch must be resident (they all wait on the same host word): the caller bounds
+  // max_wgs by its share of the CUs, and the LDS request keeps it at one workgroup per CU
+  if (pa && (!p->max_wgs || grid_n > num_cus())) { bang_set_error("persistent launch needs max_wgs"); return BANG_ERR_ARG; }
   const dim3 grid(grid_n), block(waves * WAVE);
   const bool al = (p->m % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1051,6 +1153,11 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
 }
 
 extern "C" int bang_k_front(const bang_iter_params* p, void* stream) { return launch_front(p, 7u, stream); }
+extern "C" int bang_k_lane_persistent(const bang_iter_params* p, uint32_t iter_end, const uint32_t* d_go, uint32_t* d_done_counts,
+                                      unsigned long long* d_ktime_base, uint32_t* d_abort, void* stream) {
+  PersistArgs pa{d_go, iter_end, d_done_counts, d_ktime_base, d_abort};
+  return launch_front(p, 7u, stream, &pa);
+}
 extern "C" int bang_k_filter(const bang_iter_params* p, void* stream) { return launch_front(p, 1u, stream); }
 extern "C" int bang_k_pqdist(const bang_iter_params* p, void* stream) { return launch_front(p, 2u, stream); }
 extern "C" int bang_k_parent(const bang_iter_params* p, void* stream) { return launch_front(p, 4u, stream); }

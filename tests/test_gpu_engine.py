@@ -83,7 +83,9 @@ def test_engine_recall_is_meaningful(request, libbang, small_u8):
 
 
 @pytest.mark.parametrize("opts", [dict(use_flag=0), dict(stage_zero_copy=0), dict(threads=1), dict(threads=3, lanes=2),
-                                  dict(fp_batch=1), dict(front_wgs=7, lanes=3), dict(timing=1)])
+                                  dict(fp_batch=1), dict(front_wgs=7, lanes=3), dict(timing=1), dict(persistent=1),
+                                  dict(persistent=1, lanes=3, threads=2), dict(persistent=1, timing=1),
+                                  dict(persistent=1, stage_zero_copy=1)])
 def test_engine_host_loop_options_do_not_change_results(request, libbang, small_u8, opts):
     """Every host-loop mechanism (in-kernel completion flag vs runtime sync, zero-copy vs copied adjacency rows, walker
     team size, vector-copy batching, CU share per lane, in-kernel timing) is a pure performance knob."""
@@ -119,6 +121,20 @@ def test_engine_host_loop_options_do_not_change_results(request, libbang, small_
         finally:
             os_env = __import__("os").environ
             os_env.pop("BANG_USE_FLAG", None)
+
+
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("L", [10, 152])
+def test_engine_persistent_lane_kernel_matches_oracle(request, libbang, fixture, L):
+    """"persistent"=1: one front+back launch per lane and batch, paced by a host-written word (host-graph mode)."""
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=1)
+    assert np.array_equal(ids, ids_o)
+    assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    assert st["dist_evals"] == int(st_o[:, 2].sum())
+    assert st["fetched"] == int(st_o[:, 3].sum())
 
 
 def test_query_smaller_than_allocation(request, libbang, small_f32):
