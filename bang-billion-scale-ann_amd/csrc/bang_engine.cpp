@@ -106,7 +106,7 @@ struct Lane {
   hipStream_t s_main = nullptr, s_fp = nullptr;
   hipEvent_t ev_front = nullptr, ev_fp = nullptr;
   unsigned long long* d_ktime = nullptr;   // [max launches][KT_WGS][2] in-kernel stamps, "timing"=1
-  size_t kt_launches = 0, kt_used = 0;
+  size_t kt_launches = 0, kt_used = 0, kt_words = 2;
   // walker team of this lane: the lane thread + (threads-1) helpers, spin-synchronised while a query runs
   std::vector<std::thread> helpers;
   std::atomic<uint32_t> epoch{0};
@@ -119,13 +119,16 @@ struct Lane {
   uint32_t* qmap_dev[2] = {nullptr, nullptr};    // what the kernels read
   bool qmap_is_device = false;
   std::vector<uint32_t> parents_tmp;             // device-graph mode: parents fetched at a poll
-  // persistent lane kernel ("persistent"=1): the word that paces it (CPU-written: BAR or mapped pinned), and its device
-  // arrival counters [0] = gave-up flag, [16 + iter] = workgroups that finished iteration iter
+  // persistent search kernel ("persistent"=1): per-workgroup pacing words (CPU-written: BAR or mapped pinned) and the
+  // kernel's gave-up flag
   uint32_t* go_host = nullptr;
   uint32_t* go_dev = nullptr;
   bool go_is_device = false;
   uint32_t* d_pcnt = nullptr;
-  size_t pcnt_words = 0;
+  int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 1 = persistent walk
+  uint32_t pw_groups = 0;                        // workgroups of the running persistent kernel
+  std::atomic<uint32_t> pw_max_iter{0};
+  std::atomic<int> pw_error{0};
   std::atomic<uint32_t> job_active{0}, job_parents{0};
   std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
   std::atomic<uint32_t> phase_iter{0};
@@ -230,8 +233,12 @@ struct bang_engine {
   int threads_eff = 1, stage_mode_eff = 1;   // resolved at bang_alloc
   int use_flag = 1;                    // 0: wait for the front kernel with hipStreamSynchronize + D2H copy of the parents (debug/ablation)
   int compact = 1;                     // straggler compaction on/off
-  int persistent = 0;                  // 1: host-graph mode runs ONE front+back kernel per lane and batch, paced by a host-written word
-  int persist_wgs = 0;                 // workgroups of a lane's persistent kernel (all resident: CUs / lanes)
+  int persistent = -1;                 // host-graph mode: 1 = ONE persistent search kernel per batch, its workgroups paced by the walker threads;
+                                       // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
+  bool persist_on = false;             // resolved at bang_alloc: the persistent kernel is used for this allocation
+  bool stage_local = false;            // rows are staged in local device memory (BAR mode)
+  bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
+  uint32_t pw_B = 0, pw_G = 0;         // queries per workgroup / workgroups at the allocated batch size
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
   bang_stats stats{};
@@ -359,6 +366,7 @@ void free_batch(bang_engine* e) {
     if (ln.ev_fp) (void)hipEventDestroy(ln.ev_fp);
     if (ln.d_ktime) (void)hipFree(ln.d_ktime);
     ln.d_ktime = nullptr;
+    ln.pw_groups = 0;
     if (ln.d_pcnt) (void)hipFree(ln.d_pcnt);
     ln.d_pcnt = nullptr;
     if (ln.go_host) { if (ln.go_is_device) (void)hipFree(ln.go_host); else (void)hipHostFree(ln.go_host); }
@@ -513,7 +521,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   const uint32_t* parents = e->h_parents + ln.q0;
   // mode 2: the rows go straight to device memory (CPU stores through the BAR; never read back from there)
   uint32_t* stage = (e->stage_mode_eff == 2 ? e->d_stage : e->h_stage) + (size_t)ln.q0 * BANG_STAGE_STRIDE;
-  uint8_t* fp_row = e->h_fp + ((size_t)row * e->Qcur + ln.q0) * vb;
+  uint8_t* fp_row = (e->fp_direct ? e->d_fp : e->h_fp) + ((size_t)row * e->Qcur + ln.q0) * vb;
   const uint32_t R = e->R;
   uint32_t active = 0, np = 0;
   const uint32_t PF = 8;                                   // software prefetch distance (entries are 388-644 B)
@@ -561,6 +569,70 @@ inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
   *i1 = (uint32_t)((uint64_t)ln.nq * (uint32_t)(t + 1) / (uint32_t)T);
 }
 
+// Persistent mode: walker thread t of T serves the workgroups [G*t/T, G*(t+1)/T) of the running kernel.  Whenever one of
+// them has published the parents of its iteration, the thread fetches that block's graph entries (rows + vectors), then
+// releases the workgroup into its next iteration -- every block of queries advances at its own pace.
+void pwalk(bang_engine* e, Lane& ln, int t, int T) {
+  const uint32_t G = ln.pw_groups, B = e->pw_B;
+  const uint32_t w0 = (uint32_t)((uint64_t)G * (uint32_t)t / (uint32_t)T), w1 = (uint32_t)((uint64_t)G * (uint32_t)(t + 1) / (uint32_t)T);
+  const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;
+  if (w1 <= w0) return;
+  std::vector<uint32_t> expect(w1 - w0, 1u);
+  uint32_t remaining = w1 - w0, max_iter = 1;
+  volatile uint32_t* done = e->h_done;
+  volatile uint32_t* go = ln.go_host;
+  auto t_last = Clock::now();
+  uint32_t idle = 0;
+  static const bool lockstep = getenv("BANG_PW_LOCKSTEP") != nullptr;   // experiment: release the workgroups together
+  std::vector<std::pair<uint32_t, uint32_t>> deferred;
+  while (remaining) {
+    bool progress = false;
+    if (lockstep) {
+      bool all = true;
+      for (uint32_t w = w0; w < w1; ++w) { const uint32_t it = expect[w - w0]; if (it != 0 && done[(size_t)w * 16] != it) all = false; }
+      if (!all) { _mm_pause(); continue; }
+    }
+    for (uint32_t w = w0; w < w1; ++w) {
+      const uint32_t it = expect[w - w0];
+      if (it == 0 || done[(size_t)w * 16] != it) continue;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      progress = true;
+      const uint32_t i0 = w * B, i1 = std::min(ln.nq, i0 + B);
+      uint32_t active = 0, np = 0;
+      walk_slice(e, ln, i0, i1, it, it < cap_iter, &active, &np);          // ends with an sfence in BAR mode
+      if (it > max_iter) max_iter = it;
+      if (it == cap_iter || active == 0) {
+        if (it < cap_iter) { go[(size_t)w * 16] = 0xFFFFFFFFu; _mm_sfence(); }
+        expect[w - w0] = 0;
+        --remaining;
+      } else {
+        if (lockstep) deferred.emplace_back(w, it + 1);
+        else { go[(size_t)w * 16] = it + 1; _mm_sfence(); }
+        expect[w - w0] = it + 1;
+      }
+    }
+    if (lockstep) {
+      for (auto& d : deferred) go[(size_t)d.first * 16] = d.second;
+      _mm_sfence();
+      deferred.clear();
+    }
+    if (progress) { idle = 0; continue; }
+    _mm_pause();
+    if ((++idle & 0xFFFF) == 0) {
+      if (idle == 0x10000) t_last = Clock::now();
+      else if (ms_since(t_last) > 20000.0 || ln.pw_error.load(std::memory_order_relaxed)) {
+        ln.pw_error.store(1);
+        for (uint32_t w = w0; w < w1; ++w) go[(size_t)w * 16] = 0xFFFFFFFFu;
+        _mm_sfence();
+        break;
+      }
+      std::this_thread::yield();
+    }
+  }
+  uint32_t cur = ln.pw_max_iter.load(std::memory_order_relaxed);
+  while (cur < max_iter && !ln.pw_max_iter.compare_exchange_weak(cur, max_iter, std::memory_order_relaxed)) {}
+}
+
 // helper thread t (1..T-1) of a lane's walker team
 // `seen` = the lane's job epoch at the time the thread was CREATED (captured by the creator: reading it here
 // would race with a first job posted before this thread gets to run, and that job would never be done)
@@ -576,11 +648,15 @@ void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
       const uint32_t ep = ln->epoch.load(std::memory_order_acquire);
       if (ep != seen) {
         seen = ep;
-        uint32_t i0, i1, a = 0, np = 0;
-        slice_of(*ln, t, T, &i0, &i1);
-        walk_slice(e, *ln, i0, i1, ln->job_row, ln->job_adj, &a, &np);
-        ln->job_active.fetch_add(a, std::memory_order_relaxed);
-        ln->job_parents.fetch_add(np, std::memory_order_relaxed);
+        if (ln->job_kind == 1) {
+          pwalk(e, *ln, t, T);
+        } else {
+          uint32_t i0, i1, a = 0, np = 0;
+          slice_of(*ln, t, T, &i0, &i1);
+          walk_slice(e, *ln, i0, i1, ln->job_row, ln->job_adj, &a, &np);
+          ln->job_active.fetch_add(a, std::memory_order_relaxed);
+          ln->job_parents.fetch_add(np, std::memory_order_relaxed);
+        }
         ln->pending.fetch_sub(1, std::memory_order_release);
       } else {
         _mm_pause();
@@ -593,6 +669,7 @@ void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
 uint32_t walk(bang_engine* e, Lane& ln, uint32_t row, bool adjacency, uint32_t* n_parents) {
   ln.phase.store(2);
   const int T = 1 + (int)ln.helpers.size();
+  ln.job_kind = 0;
   ln.job_row = row;
   ln.job_adj = adjacency;
   ln.job_active.store(0, std::memory_order_relaxed);
@@ -667,7 +744,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t qbytes = qdim * e->tsize;
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
-  if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16); ln.kt_used = 0; }   // stats not collected
+  if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words); ln.kt_used = 0; }   // stats not collected
   ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
   auto t_enq = Clock::now();
 #define ENQ_BEGIN() (t_enq = Clock::now())
@@ -706,7 +783,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                               e->D, e->m, dim_adjust, ln.s_main));
 
   uint32_t iter = 1;                                                         // :596
-  const bool persist = ln.d_pcnt != nullptr;
+  const bool persist = e->persist_on;
   // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
   uint32_t fp_lo = 0, fp_hi = 0;
   bool fp_pending = false, fp_any = false;
@@ -721,37 +798,33 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   };
 
   if (persist) {
-    // ONE launch per lane and batch: the kernel runs front(t) -> completion flag -> back(t) for t = 1..cap, and waits before
-    // every front(t) until this thread has stored t into `go` (after the walker's rows of iteration t-1 are in device memory).
-    auto set_go = [&](uint32_t v) {
-      _mm_sfence();                                   // the staged rows (write-combined BAR stores) before the word
-      *(volatile uint32_t*)ln.go_host = v;
-      _mm_sfence();
-    };
-    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, ln.pcnt_words * 4, ln.s_main));
-    set_go(1);
-    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq;
-    p.max_wgs = (uint32_t)e->persist_wgs;
+    // ONE launch per batch: every workgroup owns a block of pw_B queries and runs front(t) -> parents + flag -> back(t) for
+    // t = 1..cap on its own clock; before front(t) it waits until a walker thread has stored t into its `go` word (after that
+    // block's rows of iteration t-1 are in device memory).  No lanes, no per-iteration launches, no batch-wide step.
+    const uint32_t B = e->pw_B, G = (ln.nq + B - 1) / B;
+    ln.pw_groups = G;
+    ln.pw_max_iter.store(1);
+    ln.pw_error.store(0);
+    for (uint32_t w = 0; w < G; ++w) { e->h_done[(size_t)w * 16] = 0; ln.go_host[(size_t)w * 16] = 1; }
+    _mm_sfence();
+    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
+    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq; p.max_wgs = 0;
     unsigned long long* kt_base = (e->timing && ln.d_ktime && ln.kt_launches >= (size_t)cap_iter + 1) ? ln.d_ktime : nullptr;
-    BANG_TRY(bang_k_lane_persistent(&p, cap_iter, ln.go_dev, ln.d_pcnt + 16, kt_base, ln.d_pcnt, ln.s_main));
+    BANG_TRY(bang_k_search_persistent(&p, cap_iter, B, ln.go_dev, kt_base, ln.d_pcnt, (e->stage_mode_eff == 2) ? 1u : 0u, ln.s_main));
     ++ln.front_launches;
-    for (;;) {
-      const int rc = wait_flag(e, ln, iter);
-      if (rc != BANG_OK) { set_go(0xFFFFFFFFu); return rc; }
-      const auto t0 = Clock::now();
-      uint32_t n_par = 0;
-      const uint32_t active = walk(e, ln, iter, iter < cap_iter, &n_par);
-      ln.walker_ms += ms_since(t0);
-      if (n_par) {
-        if (!fp_pending) { fp_lo = iter; fp_pending = true; }
-        fp_hi = iter;
-      }
-      if (iter == cap_iter) break;                                           // the kernel ends by itself after the cap
-      if (active == 0) { set_go(0xFFFFFFFFu); break; }                       // :958
-      set_go(iter + 1);
-      if (fp_pending && fp_hi - fp_lo + 1 >= (uint32_t)e->fp_batch) { ENQ_BEGIN(); BANG_TRY(flush_fp()); ENQ_END(); }
-      ++iter;
+    const auto t0 = Clock::now();
+    const int T = 1 + (int)ln.helpers.size();
+    ln.job_kind = 1;
+    if (T > 1) {
+      ln.pending.store((uint32_t)(T - 1), std::memory_order_relaxed);
+      ln.epoch.fetch_add(1, std::memory_order_release);
     }
+    pwalk(e, ln, 0, T);
+    if (T > 1) while (ln.pending.load(std::memory_order_acquire) != 0) _mm_pause();
+    ln.walker_ms += ms_since(t0);
+    iter = ln.pw_max_iter.load();
+    if (ln.pw_error.load()) { bang_set_error("timeout waiting for the persistent search kernel"); (void)hipStreamSynchronize(ln.s_main); return BANG_ERR_HIP; }
+    if (!e->fp_direct) { fp_lo = 1; fp_hi = iter; fp_pending = true; }       // staged vectors: one copy of all rows
     if (kt_base) ln.kt_used = (size_t)iter + 1;
   } else {
   p.first = 1; p.iter = iter; p.done_value = iter;
@@ -854,7 +927,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
-  if (gave_up) { bang_set_error("persistent lane kernel gave up waiting for the host walker (lane %d)", ln.index); return BANG_ERR_HIP; }
+  if (gave_up) { bang_set_error("persistent search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
   DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats
   return BANG_OK;
@@ -942,7 +1015,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
   if (const char* v = getenv("BANG_COMPACT")) e->compact = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
-  if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_FP_BATCH")) e->fp_batch = std::max(1, atoi(v));
@@ -973,7 +1046,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "compact") { e->compact = value ? 1 : 0; }
-  else if (k == "persistent") { e->persistent = value ? 1 : 0; }
+  else if (k == "persistent") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->persistent = (int)value; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
@@ -1042,6 +1115,25 @@ static int alloc_buffers(bang_engine* e, int Q) {
   const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
   const size_t vb = vec_bytes(e);
   const bool dev_graph = (e->graph_mode == BANG_GRAPH_DEVICE);
+  if (e->stage_zero_copy < 0) {                          // CPU-writable device memory (large BAR)?
+    int large_bar = 0;
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) != hipSuccess) large_bar = 0;
+    e->stage_mode_eff = large_bar ? 2 : 1;
+  } else e->stage_mode_eff = e->stage_zero_copy;
+  // persistent search kernel: host graph, in-kernel completion flags, rows readable in place (BAR or zero-copy), and a PQ
+  // layout whose kernel fits the 128-VGPR build (the others keep the launch-per-iteration loop)
+  // (mapped-host rows need cache-bypassing loads, which are issued per lane: measured 2x slower than the per-iteration loop,
+  // so "auto" takes the persistent kernel only in BAR mode)
+  const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);
+  e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u);
+  e->fp_direct = false;
+  if (e->persist_on) {
+    const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
+    e->pw_B = std::max<uint32_t>(16u, ((uint32_t)Q + cus - 1) / cus);
+    e->pw_G = ((uint32_t)Q + e->pw_B - 1) / e->pw_B;
+  }
   HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));
   else BANG_TRY(dmalloc(&e->d_lut, nq * e->m * 256));                       // :380
@@ -1064,13 +1156,20 @@ static int alloc_buffers(bang_engine* e, int Q) {
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {
     BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
-    HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                    // :398
+    if (e->persist_on && e->stage_mode_eff == 2 &&
+        hipExtMallocWithFlags((void**)&e->d_fp, rows * nq * vb, hipDeviceMallocFinegrained) == hipSuccess) {
+      e->fp_direct = true;                                                   // walker threads write the vector log through the BAR
+    } else {
+      (void)hipGetLastError();
+      HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                  // :398
+    }
     HIP_TRY(hipHostMalloc((void**)&e->h_parents, nq * 4, hipHostMallocMapped));              // :419
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
     HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocMapped));      // :416
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_stage_dev, e->h_stage, 0));
     // The walker may write these rows from the CPU through the PCIe BAR (stage mode 2): ask for fine-grained
     // (host-coherent) device memory so that visibility does not hinge on kernel-boundary L2 invalidation alone.
+    e->stage_local = true;
     if (hipExtMallocWithFlags((void**)&e->d_stage, std::max<size_t>(nq * BANG_STAGE_STRIDE * 4, 16), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
@@ -1082,19 +1181,15 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
+  if (e->persist_on) nl = 1;                             // the persistent kernel's workgroups are the unit of overlap, not lanes
+  if (e->persist_on && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
+  else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
-  if (e->stage_zero_copy < 0) {                          // CPU-writable device memory (large BAR)?
-    int large_bar = 0;
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) != hipSuccess) large_bar = 0;
-    e->stage_mode_eff = large_bar ? 2 : 1;
-  } else e->stage_mode_eff = e->stage_zero_copy;
   if (!dev_graph) {
-    HIP_TRY(hipHostMalloc((void**)&e->h_done, (size_t)nl * 16 * 4, hipHostMallocMapped));
+    const size_t n_flags = std::max<size_t>((size_t)nl, e->persist_on ? e->pw_G : 0);
+    HIP_TRY(hipHostMalloc((void**)&e->h_done, n_flags * 16 * 4, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_done_dev, e->h_done, 0));
-    memset(e->h_done, 0, (size_t)nl * 16 * 4);
+    memset(e->h_done, 0, n_flags * 16 * 4);
     BANG_TRY(dmalloc(&e->d_done_count, (size_t)nl * 16));
     HIP_TRY(hipMemset(e->d_done_count, 0, (size_t)nl * 16 * 4));
   }
@@ -1106,7 +1201,6 @@ static int alloc_buffers(bang_engine* e, int Q) {
     if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess) cus = prop.multiProcessorCount;
     // lanes are rarely all in their kernel phase at once: give each up to twice its fair share of the CUs
     e->front_wgs = e->front_wgs_opt >= 0 ? e->front_wgs_opt : (nl > 1 ? std::min(cus, std::max(1, 2 * cus / nl)) : 0);
-    e->persist_wgs = std::max(1, cus / nl);
   }
   for (int i = 0; i < nl; ++i) {
     Lane& ln = *e->lanes[(size_t)i];
@@ -1128,28 +1222,31 @@ static int alloc_buffers(bang_engine* e, int Q) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
       }
     }
-    // (PQ layouts that need the 256-VGPR kernel build have no persistent instance: they keep the launch-per-iteration loop)
-    if (e->persistent && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u)) {
-      ln.pcnt_words = 16 + rows + 4;
-      BANG_TRY(dmalloc(&ln.d_pcnt, ln.pcnt_words));
-      HIP_TRY(hipMemset(ln.d_pcnt, 0, ln.pcnt_words * 4));
-      if (e->stage_mode_eff == 2 && hipExtMallocWithFlags((void**)&ln.go_host, 64, hipDeviceMallocFinegrained) == hipSuccess) {
-        HIP_TRY(hipMemset(ln.go_host, 0, 64));
+    if (e->persist_on) {
+      const size_t go_bytes = (size_t)e->pw_G * 64;
+      BANG_TRY(dmalloc(&ln.d_pcnt, 16));
+      HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
+      if (e->stage_mode_eff == 2 && hipExtMallocWithFlags((void**)&ln.go_host, go_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+        HIP_TRY(hipMemset(ln.go_host, 0, go_bytes));
         ln.go_dev = ln.go_host;
         ln.go_is_device = true;
       } else {
         (void)hipGetLastError();
-        HIP_TRY(hipHostMalloc((void**)&ln.go_host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&ln.go_host, go_bytes, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.go_dev, ln.go_host, 0));
-        memset(ln.go_host, 0, 64);
+        memset(ln.go_host, 0, go_bytes);
       }
     }
     if (e->timing) {
       ln.kt_launches = rows + 4;
-      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));
-      HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 16));
+      ln.kt_words = e->persist_on ? 4 : 2;                   // stamps per workgroup and launch/iteration
+      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
+      HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
     }
   }
+  if (getenv("BANG_DEBUG"))
+    fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d persist=%d B=%u G=%u fp_direct=%d\n", Q, nl, e->threads_eff,
+            e->stage_mode_eff, (int)e->persist_on, e->pw_B, e->pw_G, (int)e->fp_direct);
   start_threads(e);
   return BANG_OK;
 }
@@ -1248,11 +1345,41 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
 }
 
 // reduce the in-kernel stamps of a lane: per launch max(end) - min(start) over the workgroups that ran
-static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals) {
+static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals, bool persist) {
   if (!ln.d_ktime || ln.kt_used == 0) return BANG_OK;
-  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * 2);
+  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * ln.kt_words);
   HIP_TRY(hipMemcpy(kt.data(), ln.d_ktime, kt.size() * 8, hipMemcpyDeviceToHost));
   ln.front_ms = 0;
+  if (persist) {
+    // persistent kernel: slot [iteration][workgroup]; workgroups are not in step, so the figure is the mean over the
+    // workgroups of the time each spent in its front phases (waiting for the walker and sort/merge excluded)
+    unsigned long long sum = 0;
+    size_t wgs = 0;
+    for (size_t w = 0; w < KT_WGS; ++w) {
+      unsigned long long busy = 0;
+      for (size_t l = 0; l < ln.kt_used; ++l) {
+        const unsigned long long a = kt[(l * KT_WGS + w) * 4], b = kt[(l * KT_WGS + w) * 4 + 1];
+        if (a != 0 && b > a) busy += b - a;
+      }
+      if (busy) { sum += busy; ++wgs; }
+    }
+    if (wgs) {
+      const unsigned long long mean = sum / wgs;
+      ln.front_ms = (double)mean * 1e-5;
+      intervals.emplace_back(1ull, 1ull + mean);
+    }
+    if (const char* path = getenv("BANG_PW_TRACE")) {          // raw stamps for offline analysis (tools/dev/pw_trace.py)
+      if (FILE* f = fopen(path, "wb")) {
+        const uint64_t hdr[2] = {(uint64_t)ln.kt_used, (uint64_t)KT_WGS};
+        fwrite(hdr, 8, 2, f);
+        fwrite(kt.data(), 8, kt.size(), f);
+        fclose(f);
+      }
+    }
+    HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words));
+    ln.kt_used = 0;
+    return BANG_OK;
+  }
   for (size_t l = 0; l < ln.kt_used; ++l) {
     unsigned long long lo = ~0ull, hi = 0;
     for (size_t w = 0; w < KT_WGS; ++w) {
@@ -1262,6 +1389,14 @@ static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, uns
       hi = std::max(hi, b);
     }
     if (hi > lo) { ln.front_ms += (double)(hi - lo) * 1e-5; intervals.emplace_back(lo, hi); }   // 100 MHz ticks -> ms
+  }
+  if (const char* path = getenv("BANG_KT_TRACE")) {            // raw stamps of lane 0 for offline analysis
+    if (ln.index == 0) if (FILE* f = fopen(path, "wb")) {
+      const uint64_t hdr[2] = {(uint64_t)ln.kt_used, (uint64_t)KT_WGS};
+      fwrite(hdr, 8, 2, f);
+      fwrite(kt.data(), 8, kt.size(), f);
+      fclose(f);
+    }
   }
   HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16));
   ln.kt_used = 0;
@@ -1273,7 +1408,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   bang_stats& s = e->stats;
   if (e->allocated && e->timing && s.front_ms == 0) {
     std::vector<std::pair<unsigned long long, unsigned long long>> iv;
-    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv)); s.front_ms += lp->front_ms; }
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv, e->persist_on)); s.front_ms += lp->front_ms; }
     std::sort(iv.begin(), iv.end());                   // the stamps of all lanes share one 100 MHz clock: merge the intervals
     unsigned long long cur_lo = 0, cur_hi = 0, busy = 0;
     for (auto& p : iv) {

@@ -311,13 +311,15 @@ struct FrontArgs {
   uint32_t stages;      // bit0 filter, bit1 distance, bit2 parent
   uint32_t debug;       // timing-only ablations (BANG_FRONT_DEBUG): 1 no filter updates, 2 no distance math, 4 no pivot staging
   uint32_t lds_piv_floats;
-  // persistent mode (one launch runs iterations p.iter .. iter_end, paced by the host through `go`)
-  const uint32_t* go;          // device-visible word: the kernel may run iteration t once *go >= t; 0xFFFFFFFF = stop
+  // persistent mode: one launch runs iterations p.iter .. iter_end.  Every workgroup owns a contiguous block of wg_queries
+  // queries and is paced on its own by the host walker (no grid-wide step): before front(t) it waits until go[16*wg] >= t.
+  const uint32_t* go;          // [gridDim.x * 16] words written by the host (64 B apart); 0xFFFFFFFF = stop
   uint32_t iter_end;           // last iteration (the cap)
   uint32_t scratch_words;      // LDS words per wave (front compaction scratch and back view share them)
-  uint32_t* done_counts;       // [iter_end + 2] arrival counters, one per iteration (zeroed by the host)
-  unsigned long long* ktime_base;   // [iter][KT_WGS][2] stamps or NULL
-  uint32_t* abort_flag;        // set to 1 if the kernel gave up waiting for `go`
+  uint32_t wg_queries;         // queries per workgroup
+  unsigned long long* ktime_base;   // [iter][KT_WGS][4] stamps {go seen, front end, flag published, sort/merge end} or NULL
+  uint32_t* abort_flag;        // set to 1 if a workgroup gave up waiting for `go`
+  uint32_t rows_uncached;      // 1: d_stage is LOCAL device memory written by the CPU through the BAR -> plain coalesced loads (see the row loads)
 };
 #define KT_WGS_DEV 256u
 #define BANG_GO_STOP 0xFFFFFFFFu
@@ -373,6 +375,13 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const uint32_t lane_l = (uint32_t)lane < L ? (uint32_t)lane : L - 1;
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
+  // slots of this wave: q_begin, q_begin + q_step, ... < q_end (persistent: inside the workgroup's own block of queries)
+  const bool own_blk = PERSIST && !(a.debug & 128u);     // debug bit 128: strided ownership (timing experiments only)
+  const uint32_t wg_q0 = PERSIST ? blockIdx.x * a.wg_queries : 0u;
+  const uint32_t wg_q1 = PERSIST ? (wg_q0 + a.wg_queries < p.Q ? wg_q0 + a.wg_queries : p.Q) : p.Q;
+  const uint32_t q_end = own_blk ? wg_q1 : p.Q;
+  const uint32_t q_begin = own_blk ? wg_q0 + wave : gw;
+  const uint32_t q_step = own_blk ? nwaves : total_waves;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   uint32_t n_active = 0;
 
@@ -381,14 +390,15 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   for (uint32_t cur_iter = p.iter; cur_iter <= (PERSIST ? a.iter_end : p.iter); ++cur_iter) {
   const uint32_t first = PERSIST ? (cur_iter == 1 ? 1u : 0u) : (p.first ? 1u : 0u);
   if (PERSIST) {
-    // wait until the host has staged the adjacency rows of this iteration
+    // wait until the host walker has staged this workgroup's adjacency rows of this iteration
     uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;    // one LDS word behind the per-wave scratch
+    const uint32_t* go = a.go + (size_t)blockIdx.x * 16;
     if (threadIdx.x == 0) {
-      uint32_t v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      uint32_t v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (v < cur_iter) {                         // BANG_GO_STOP is the largest value: it also ends the wait
         __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {      // 3 s at 100 MHz: the host is gone
           v = BANG_GO_STOP;
           if (a.abort_flag) *a.abort_flag = 1u;
@@ -398,22 +408,24 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       *s_go = v;
       // everything other agents (the CPU through the BAR) or this kernel's own atomics wrote since the last iteration
       // must not be served from this CU's L1
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(a.debug & 64u)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     if (*s_go == BANG_GO_STOP) break;
     if (a.ktime_base && threadIdx.x == 0)
-      a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 2] = __builtin_amdgcn_s_memrealtime();
+      a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4] = __builtin_amdgcn_s_memrealtime();
   }
 
-  for (uint32_t g0 = gw; g0 < p.Q; g0 += total_waves * NQW) {
+  for (uint32_t g0 = q_begin; g0 < q_end; g0 += q_step * NQW) {
     uint32_t q[NQW];
     bool valid[NQW];
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
-      const uint32_t slot = g0 + (uint32_t)u * total_waves;
-      valid[u] = slot < p.Q;
+      const uint32_t slot = g0 + (uint32_t)u * q_step;
+      valid[u] = slot < q_end;
       const uint32_t s_ok = valid[u] ? slot : g0;   // invalid slots shadow slot 0: loads stay legal, every store is guarded
       q[u] = p.d_qmap ? uni(p.d_qmap[s_ok]) : s_ok;  // straggler compaction: slot -> query
     }
@@ -446,7 +458,11 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
-      if (PERSIST) {                                     // rows were just written by the CPU: read them at system scope
+      if (PERSIST && !a.rows_uncached) {
+        // Rows in mapped HOST memory, re-read without a kernel boundary in between: L2 copies of remote lines are not probed,
+        // so every load bypasses the caches.  (Such loads are issued per lane, not coalesced: measured 2x the whole front
+        // phase.)  Rows in LOCAL device memory take the plain path below: this CU's L1 was invalidated after `go` was seen,
+        // and L2 copies of local memory are invalidated by the fabric's probes when the CPU's PCIe writes land.
         cnt_in[u] = __hip_atomic_load(&row[u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         x0[u] = __hip_atomic_load(&row[u][1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         x1[u] = __hip_atomic_load(&row[u][65u * first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   if (p.d_ktime || (PERSIST && a.ktime_base)) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (PERSIST) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+      if (PERSIST) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
       else p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
   }
@@ -710,16 +726,32 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // device counter; the LAST workgroup re-reads the parents with `sc1` loads, copies them to mapped pinned host
   // memory with system-scope stores (coalesced: one 4-byte PCIe write per query from every wave was measured at
   // +75 us per launch), drains, and publishes the iteration number.  The walker thread spins on that word.
-  if (p.h_done_flag) {
+  if (PERSIST) {
+    // every workgroup reports on its own: its waves drain their write-through parent stores, the block's parents go to
+    // mapped pinned host memory in one coalesced store, and the iteration number is published behind them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (uint32_t i = wg_q0 + threadIdx.x; i < wg_q1; i += blockDim.x) {
+      const uint32_t v = __hip_atomic_load(&p.d_parents[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.h_parents[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag must not overtake the stores (MI355X guide)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // relaxed: everything the host reads was stored write-through and drained above; a release here would write back the whole L2 of this XCD once per workgroup and iteration
+      __hip_atomic_store(p.h_done_flag + (size_t)blockIdx.x * 16, cur_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.ktime_base) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+  } else if (p.h_done_flag) {
     volatile uint32_t* s_last = scratch_all;        // dynamic LDS: no static allocation next to the 160 KB request
-    uint32_t* counter = PERSIST ? a.done_counts + cur_iter : p.d_done_count;
+    uint32_t* counter = p.d_done_count;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t old = atomicAdd(counter, 1u);
       const uint32_t last = (old + 1 == gridDim.x) ? 1u : 0u;
       *s_last = last;
-      if (last && !PERSIST) atomicExch(counter, 0u);   // every other workgroup has already arrived
+      if (last) atomicExch(counter, 0u);   // every other workgroup has already arrived
     }
     __syncthreads();
     if (*s_last) {
@@ -731,7 +763,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag must not overtake the stores (MI355X guide)
       __syncthreads();
       if (threadIdx.x == 0)
-        __hip_atomic_store(p.h_done_flag, PERSIST ? cur_iter : p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.h_done_flag, p.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();                                 // s_last lives in wave 0's scratch: nobody may reuse it before all have read it
   }
@@ -739,8 +771,12 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   if (PERSIST) {
     // K3a + K3b for the queries of this wave, while the host walks (the standalone back kernel in the launch-per-iteration mode)
     const BackView bv = back_view_at(scratch, L);
-    for (uint32_t slot = gw; slot < p.Q; slot += total_waves) back_one_query(p, slot, cur_iter, bv, lane);
+    for (uint32_t slot = q_begin; slot < q_end; slot += q_step) back_one_query(p, slot, cur_iter, bv, lane);
     n_active = 0;
+    if (a.ktime_base) {
+      __syncthreads();
+      if (threadIdx.x == 0) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
   }
   }   // iterations
 }
@@ -1047,7 +1083,7 @@ static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid,
 }
 
 struct PersistArgs {
-  const uint32_t* go; uint32_t iter_end; uint32_t* done_counts; unsigned long long* ktime_base; uint32_t* abort_flag;
+  const uint32_t* go; uint32_t iter_end; uint32_t wg_queries; unsigned long long* ktime_base; uint32_t* abort_flag; uint32_t rows_uncached;
 };
 
 static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream, const PersistArgs* pa = nullptr) {
@@ -1058,18 +1094,20 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_seed) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
   if ((stages & 4u) && (!p->d_wl_ids || !p->d_wl_dist || !p->d_wl_vis || !p->d_wl_cnt || !p->d_mark || !p->d_parents ||
                         !p->d_cand_ids || !p->d_cand_cnt)) { bang_set_error("null worklist/candidate buffer"); return BANG_ERR_ARG; }
-  if (p->h_done_flag && (!p->d_done_count || !p->h_parents)) { bang_set_error("completion flag needs d_done_count and h_parents"); return BANG_ERR_ARG; }
+  if (p->h_done_flag && !pa && (!p->d_done_count || !p->h_parents)) { bang_set_error("completion flag needs d_done_count and h_parents"); return BANG_ERR_ARG; }
   if ((stages & 1u) && (!p->d_bloom || (!p->first && !p->d_stage && !p->d_graph))) { bang_set_error("null filter buffer"); return BANG_ERR_ARG; }
   if ((stages & 2u) && (p->psz ? (!p->d_pivots_packed || !p->d_qc) : !p->d_lut)) { bang_set_error("null PQ buffer"); return BANG_ERR_ARG; }
   FrontArgs a;
   a.p = *p;
   a.stages = stages;
-  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.done_counts = nullptr; a.ktime_base = nullptr; a.abort_flag = nullptr;
+  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.wg_queries = 0; a.ktime_base = nullptr; a.abort_flag = nullptr; a.rows_uncached = 0;
   if (pa) {
-    if (stages != 7u || !pa->go || !pa->done_counts || !p->h_done_flag || p->d_qmap || p->d_graph || !p->d_stage || pa->iter_end < p->iter) {
+    if (stages != 7u || !pa->go || !pa->wg_queries || !p->h_done_flag || !p->h_parents || p->d_qmap || p->d_graph || !p->d_stage ||
+        pa->iter_end < p->iter) {
       bang_set_error("bad persistent launch arguments"); return BANG_ERR_ARG;
     }
-    a.go = pa->go; a.iter_end = pa->iter_end; a.done_counts = pa->done_counts; a.ktime_base = pa->ktime_base; a.abort_flag = pa->abort_flag;
+    a.go = pa->go; a.iter_end = pa->iter_end; a.wg_queries = pa->wg_queries; a.ktime_base = pa->ktime_base; a.abort_flag = pa->abort_flag;
+    a.rows_uncached = pa->rows_uncached;
   }
   {
     static int dbg = -1;
@@ -1100,7 +1138,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (env_waves < 0) { const char* v = getenv("BANG_FRONT_WAVES"); env_waves = v ? atoi(v) : 0; }
   int wgs = need_piv ? num_cus() : num_cus() * 8;
   if (p->max_wgs && (int)p->max_wgs < wgs) wgs = (int)p->max_wgs;
-  const int per_wg = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
+  const int per_wg = pa ? (int)pa->wg_queries : (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
   // interleaving 4 queries per wave did not pay on SIFT1M-like data (the kernel is bound by random-access
   // throughput of the visited filter, not by dependent latency); kept selectable for other shapes
   // Layouts with > 32 chunk-dwords x floats per entry (m = 68..76 at 2 floats per entry: SIFT1B, DEEP100M) need more
@@ -1127,9 +1165,12 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
   int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
-  // every workgroup of a persistent launch must be resident (they all wait on the same host word): the caller bounds
-  // max_wgs by its share of the CUs, and the LDS request keeps it at one workgroup per CU
-  if (pa && (!p->max_wgs || grid_n > num_cus())) { bang_set_error("persistent launch needs max_wgs"); return BANG_ERR_ARG; }
+  if (pa) {
+    // one workgroup per block of wg_queries queries; every one of them must be resident (each waits for the host, which
+    // waits for all of them): at most one per CU
+    grid_n = (int)((p->Q + pa->wg_queries - 1) / pa->wg_queries);
+    if (grid_n > num_cus() || grid_n > (int)KT_WGS_DEV) { bang_set_error("persistent launch: %d workgroups exceed the CU count", grid_n); return BANG_ERR_ARG; }
+  }
   const dim3 grid(grid_n), block(waves * WAVE);
   const bool al = (p->m % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1153,11 +1194,12 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
 }
 
 extern "C" int bang_k_front(const bang_iter_params* p, void* stream) { return launch_front(p, 7u, stream); }
-extern "C" int bang_k_lane_persistent(const bang_iter_params* p, uint32_t iter_end, const uint32_t* d_go, uint32_t* d_done_counts,
-                                      unsigned long long* d_ktime_base, uint32_t* d_abort, void* stream) {
-  PersistArgs pa{d_go, iter_end, d_done_counts, d_ktime_base, d_abort};
+extern "C" int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
+                                        unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_uncached, void* stream) {
+  PersistArgs pa{d_go, iter_end, wg_queries, d_ktime_base, d_abort, rows_uncached};
   return launch_front(p, 7u, stream, &pa);
 }
+extern "C" int bang_num_cus(void) { return num_cus(); }
 extern "C" int bang_k_filter(const bang_iter_params* p, void* stream) { return launch_front(p, 1u, stream); }
 extern "C" int bang_k_pqdist(const bang_iter_params* p, void* stream) { return launch_front(p, 2u, stream); }
 extern "C" int bang_k_parent(const bang_iter_params* p, void* stream) { return launch_front(p, 4u, stream); }

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="override the batch size of the workload")
     ap.add_argument("--recall-target", type=float, default=90.0)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0, help="walker threads per lane; 0 = engine default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
@@ -128,13 +129,16 @@ def main():
     Qr = q1 - q0
 
     graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
-    lanes, threads = args.lanes, 0                 # 0 = engine default (walker threads from the CPU quota)
+    # 0 = engine default (lanes from the batch size, walker threads from the CPU quota)
+    lanes = args.lanes or int(os.environ.get("BANG_LANES", "0"))
+    threads = args.threads or int(os.environ.get("BANG_THREADS", "0"))
     if world > 1 and graph_mode == bang_amd.GRAPH_HOST:
         # all ranks of the node share one CPU quota: size (lanes x walker threads) from this rank's share of it
         share = max(1, usable_cpus() // world)
         if not lanes:
             lanes = max(1, min(4, share // 2, Qr // 512 if Qr >= 512 else 1))
-        threads = max(1, min(4, share // lanes))
+        if not threads:
+            threads = max(1, min(4, share // lanes))
     eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=lanes, threads=threads,
                           timing=0 if args.no_events else 1)
     eng.load_index(ix, d_codes=d_codes)

@@ -58,7 +58,7 @@ def test_engine_lanes_do_not_change_results(request, libbang, small_u8, lanes):
     from oracle import oracle as O
     ix, q, _, _ = small_u8
     ids_o, dists_o = O.Oracle(ix).search(q, 10, 48)
-    ids, dists, _ = _run_engine(ix, q, 10, 48, lanes=lanes)
+    ids, dists, _ = _run_engine(ix, q, 10, 48, lanes=lanes, persistent=0)
     assert np.array_equal(ids, ids_o)
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
 
@@ -82,13 +82,15 @@ def test_engine_recall_is_meaningful(request, libbang, small_u8):
     assert O.recall(gt_i, gt_d, ids, 10) >= 90.0
 
 
-@pytest.mark.parametrize("opts", [dict(use_flag=0), dict(stage_zero_copy=0), dict(threads=1), dict(threads=3, lanes=2),
-                                  dict(fp_batch=1), dict(front_wgs=7, lanes=3), dict(timing=1), dict(persistent=1),
-                                  dict(persistent=1, lanes=3, threads=2), dict(persistent=1, timing=1),
-                                  dict(persistent=1, stage_zero_copy=1)])
+@pytest.mark.parametrize("opts", [dict(use_flag=0), dict(stage_zero_copy=0), dict(threads=1), dict(threads=3, lanes=2, persistent=0),
+                                  dict(fp_batch=1, persistent=0), dict(front_wgs=7, lanes=3, persistent=0), dict(timing=1),
+                                  dict(timing=1, persistent=0), dict(persistent=0), dict(persistent=1),
+                                  dict(persistent=1, lanes=3, threads=2), dict(persistent=1, timing=1), dict(persistent=1, threads=1),
+                                  dict(persistent=1, stage_zero_copy=1), dict(persistent=0, stage_zero_copy=1)])
 def test_engine_host_loop_options_do_not_change_results(request, libbang, small_u8, opts):
-    """Every host-loop mechanism (in-kernel completion flag vs runtime sync, zero-copy vs copied adjacency rows, walker
-    team size, vector-copy batching, CU share per lane, in-kernel timing) is a pure performance knob."""
+    """Every host-loop mechanism (persistent search kernel vs a launch per iteration, in-kernel completion flag vs runtime
+    sync, BAR vs zero-copy vs copied adjacency rows, walker team size, vector-copy batching, CU share per lane, in-kernel
+    timing) is a pure performance knob."""
     import bang_amd
     from oracle import oracle as O
     ix, q, _, _ = small_u8
@@ -125,12 +127,14 @@ def test_engine_host_loop_options_do_not_change_results(request, libbang, small_
 
 @pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
 @pytest.mark.parametrize("L", [10, 152])
-def test_engine_persistent_lane_kernel_matches_oracle(request, libbang, fixture, L):
-    """"persistent"=1: one front+back launch per lane and batch, paced by a host-written word (host-graph mode)."""
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_engine_host_loop_variants_match_oracle(request, libbang, fixture, L, persistent):
+    """Host-graph mode, both loop forms: "persistent"=1 = ONE search kernel per batch whose workgroups are paced one by one
+    by the walker threads; "persistent"=0 = a front and a back launch per iteration and lane."""
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
-    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=1)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=persistent)
     assert np.array_equal(ids, ids_o)
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
     assert st["dist_evals"] == int(st_o[:, 2].sum())

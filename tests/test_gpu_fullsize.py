@@ -16,9 +16,9 @@ def sift1m_like():
     return synth.make_index(1_000_000, 128, "uint8", 64, 32, 10_000, K=10, n_clusters=256, device="cuda")
 
 
-def _search(ix, q, graph, L=70):
+def _search(ix, q, graph, L=70, **opts):
     import bang_amd
-    with bang_amd.Engine(ix.dtype, graph=graph) as e:
+    with bang_amd.Engine(ix.dtype, graph=graph, **opts) as e:
         e.load_index(ix)
         e.set_searchparams(10, L)
         e.alloc(q.shape[0])
@@ -35,9 +35,12 @@ def test_full_size_properties_and_sample_parity(libbang, sift1m_like):
     ix, q, gt_i, gt_d = sift1m_like
     ids_h, dists_h, st_h = _search(ix, q, 0)
     ids_d, dists_d, st_d = _search(ix, q, 1)
-    # 1. graph placement does not change a single bit of the result
+    ids_l, dists_l, st_l = _search(ix, q, 0, persistent=0)      # host graph, a launch per iteration and lane
+    # 1. neither graph placement nor the form of the host loop changes a single bit of the result
     assert np.array_equal(ids_h, ids_d) and np.array_equal(dists_h.view(np.uint32), dists_d.view(np.uint32))
-    assert st_h["dist_evals"] == st_d["dist_evals"] and st_h["candidates"] == st_d["candidates"]
+    assert np.array_equal(ids_h, ids_l) and np.array_equal(dists_h.view(np.uint32), dists_l.view(np.uint32))
+    assert st_h["dist_evals"] == st_d["dist_evals"] == st_l["dist_evals"] and st_h["candidates"] == st_d["candidates"] == st_l["candidates"]
+    assert st_h["fetched"] == st_l["fetched"]
     # 2. size-independent properties over the WHOLE batch
     assert ids_h.shape == (10_000, 10) and (ids_h < ix.N).all()
     srt = np.sort(ids_h, axis=1)
