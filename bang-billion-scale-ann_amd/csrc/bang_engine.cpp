@@ -128,6 +128,7 @@ struct Lane {
   int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 1 = persistent walk
   uint32_t pw_groups = 0;                        // workgroups of the running persistent kernel
   std::atomic<uint32_t> pw_max_iter{0};
+  std::atomic<uint64_t> h2d_bytes{0};
   std::atomic<int> pw_error{0};
   std::atomic<uint32_t> job_active{0}, job_parents{0};
   std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
@@ -237,6 +238,11 @@ struct bang_engine {
                                        // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
   bool persist_on = false;             // resolved at bang_alloc: the persistent kernel is used for this allocation
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
+  int vectors_opt = -1;                // host-graph mode, where the full-precision vectors for the re-rank live: 0 = host (the walker ships
+                                       // every expanded node's vector, as the reference does), 1 = a packed copy [N][vec_bytes] in HBM (the
+                                       // walker ships adjacency rows only), -1 = auto (1 if the copy takes at most 40 % of the free HBM)
+  bool vec_on_device = false;          // resolved at load
+  uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
   uint32_t pw_B = 0, pw_G = 0;         // queries per workgroup / workgroups at the allocated batch size
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
@@ -327,6 +333,32 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   HIP_TRY(hipMemcpy(e->d_seed, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&e->d_medoid_vec, (vec_bytes(e) + 15) & ~(size_t)15));
   HIP_TRY(hipMemcpy(e->d_medoid_vec, me, vec_bytes(e), hipMemcpyHostToDevice));
+  e->vec_on_device = false;
+  if (e->graph_mode != BANG_GRAPH_DEVICE && e->vectors_opt != 0) {
+    // 288 GB of HBM hold the full-precision vectors of a billion uint8 points next to their PQ codes: keep a packed copy on
+    // the device for the re-rank, so that the walker ships adjacency rows only (a third less PCIe traffic per expanded node)
+    const size_t vb = vec_bytes(e), need = (size_t)e->N * vb;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (e->vectors_opt == 1 || (double)need <= 0.4 * (double)free_b) {
+      HIP_TRY(hipMalloc((void**)&e->d_vecs, need + 256));
+      const size_t rows_per = std::max<size_t>(1, ((size_t)32 << 20) / vb);
+      uint8_t* stage[2] = {nullptr, nullptr};
+      hipEvent_t ev[2];
+      for (int b = 0; b < 2; ++b) { HIP_TRY(hipHostMalloc((void**)&stage[b], rows_per * vb, hipHostMallocDefault)); HIP_TRY(hipEventCreate(&ev[b])); }
+      int b = 0;
+      for (size_t r0 = 0; r0 < e->N; r0 += rows_per, b ^= 1) {
+        const size_t nr = std::min(rows_per, (size_t)e->N - r0);
+        HIP_TRY(hipEventSynchronize(ev[b]));               // the previous copy out of this buffer has finished
+        for (size_t r = 0; r < nr; ++r) memcpy(stage[b] + r * vb, e->graph + (r0 + r) * e->entry_len, vb);
+        HIP_TRY(hipMemcpyAsync(e->d_vecs + r0 * vb, stage[b], nr * vb, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipEventRecord(ev[b], nullptr));
+      }
+      HIP_TRY(hipDeviceSynchronize());
+      for (int i = 0; i < 2; ++i) { (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
+      e->vec_on_device = true;
+    }
+  }
   if (e->graph_mode == BANG_GRAPH_DEVICE) {
     const size_t gbytes = (size_t)e->N * e->entry_len;
     HIP_TRY(hipMalloc((void**)&e->d_graph, gbytes + 256));
@@ -348,6 +380,8 @@ void unload_index(bang_engine* e) {
   dfree(e->d_seed);
   dfree(e->d_medoid_vec);
   dfree(e->d_graph);
+  dfree(e->d_vecs);
+  e->vec_on_device = false;
   free(e->graph_owned);
   e->graph_owned = nullptr;
   e->graph = nullptr;
@@ -521,9 +555,11 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   const uint32_t* parents = e->h_parents + ln.q0;
   // mode 2: the rows go straight to device memory (CPU stores through the BAR; never read back from there)
   uint32_t* stage = (e->stage_mode_eff == 2 ? e->d_stage : e->h_stage) + (size_t)ln.q0 * BANG_STAGE_STRIDE;
-  uint8_t* fp_row = (e->fp_direct ? e->d_fp : e->h_fp) + ((size_t)row * e->Qcur + ln.q0) * vb;
+  const bool ship_vec = !e->vec_on_device;
+  uint8_t* fp_row = ship_vec ? (e->fp_direct ? e->d_fp : e->h_fp) + ((size_t)row * e->Qcur + ln.q0) * vb : nullptr;
   const uint32_t R = e->R;
   uint32_t active = 0, np = 0;
+  uint64_t bytes = 0;
   const uint32_t PF = 8;                                   // software prefetch distance (entries are 388-644 B)
   for (uint32_t i = i0; i < i1 && i < i0 + PF; ++i) {
     const uint32_t par = parents[i];
@@ -544,14 +580,16 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
     uint32_t* srow = stage + (size_t)i * BANG_STAGE_STRIDE;
     if (par < BANG_IDLE_PARENT) {
       const uint8_t* ent = graph + (uint64_t)par * elen;
-      memcpy(fp_row + (size_t)i * vb, ent, vb);                       // :796-798
+      if (ship_vec) memcpy(fp_row + (size_t)i * vb, ent, vb);         // :796-798
       if (adjacency) {
         uint32_t deg;
         memcpy(&deg, ent + vb, 4);                                    // :801
         if (deg > R) deg = R;
         srow[0] = deg;
         memcpy(srow + 1, ent + vb + 4, (size_t)deg * 4);              // :809-810
+        bytes += 4 + (uint64_t)deg * 4;
       }
+      if (ship_vec) bytes += vb;
       ++active;
       ++np;
     } else {
@@ -562,6 +600,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   if (e->stage_mode_eff == 2) _mm_sfence();             // drain the write-combining buffers before the launch
   *n_active = active;
   *n_parents = np;
+  if (bytes) const_cast<Lane&>(ln).h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
 }
 
 inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
@@ -745,7 +784,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
   if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words); ln.kt_used = 0; }   // stats not collected
-  ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
+  ln.h2d_bytes.store(0); ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
   auto t_enq = Clock::now();
 #define ENQ_BEGIN() (t_enq = Clock::now())
 #define ENQ_END() (ln.enqueue_ms += ms_since(t_enq))
@@ -824,7 +863,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     ln.walker_ms += ms_since(t0);
     iter = ln.pw_max_iter.load();
     if (ln.pw_error.load()) { bang_set_error("timeout waiting for the persistent search kernel"); (void)hipStreamSynchronize(ln.s_main); return BANG_ERR_HIP; }
-    if (!e->fp_direct) { fp_lo = 1; fp_hi = iter; fp_pending = true; }       // staged vectors: one copy of all rows
+    if (!e->fp_direct && !e->vec_on_device) { fp_lo = 1; fp_hi = iter; fp_pending = true; }   // staged vectors: one copy of all rows
     if (kt_base) ln.kt_used = (size_t)iter + 1;
   } else {
   p.first = 1; p.iter = iter; p.done_value = iter;
@@ -846,7 +885,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       uint32_t n_par = 0;
       const uint32_t active = walk(e, ln, iter, true, &n_par);               // CPU walker :771-813
       ln.walker_ms += ms_since(t0);
-      if (n_par) {
+      if (n_par && !e->vec_on_device) {
         if (!fp_pending) { fp_lo = iter; fp_pending = true; }
         fp_hi = iter;
       }
@@ -873,7 +912,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
         BANG_TRY(wait_flag(e, ln, iter));
         uint32_t n_par = 0;
         (void)walk(e, ln, iter, false, &n_par);
-        if (n_par) {
+        if (n_par && !e->vec_on_device) {
           if (!fp_pending) { fp_lo = iter; fp_pending = true; }
           fp_hi = iter;
         }
@@ -912,6 +951,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       BANG_TRY(bang_k_rerank_range(e->d_graph, e->entry_len, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids,
                                    nullptr, e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D,
                                    (uint32_t)e->k, dim_adjust, e->d_ids_out, e->d_dists_out, ln.s_main));
+    else if (e->vec_on_device)
+      BANG_TRY(bang_k_rerank_range(e->d_vecs, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, nullptr, e->d_cand_cnt,
+                                   e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k, dim_adjust, e->d_ids_out,
+                                   e->d_dists_out, ln.s_main));
     else
       BANG_TRY(bang_k_rerank_range(e->d_fp, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, e->d_cand_row,
                                    e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k,
@@ -1022,6 +1065,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_DEVICE")) e->device = atoi(v);
   if (const char* v = getenv("BANG_PQ")) e->pq_mode = atoi(v);
   if (const char* v = getenv("BANG_TIMING")) e->timing = atoi(v);
+  if (const char* v = getenv("BANG_VECTORS")) e->vectors_opt = std::min(1, std::max(-1, atoi(v)));
   *out = e;
   return BANG_OK;
 }
@@ -1043,6 +1087,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
   else if (k == "timing") { e->timing = (int)value; }
+  else if (k == "vectors") { if (value < -1 || value > 1 || e->loaded) return BANG_ERR_ARG; e->vectors_opt = (int)value; }
   else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "compact") { e->compact = value ? 1 : 0; }
@@ -1156,7 +1201,9 @@ static int alloc_buffers(bang_engine* e, int Q) {
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {
     BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
-    if (e->persist_on && e->stage_mode_eff == 2 &&
+    if (e->vec_on_device) {
+      e->d_fp = nullptr;                                                     // the re-rank reads d_vecs
+    } else if (e->persist_on && e->stage_mode_eff == 2 &&
         hipExtMallocWithFlags((void**)&e->d_fp, rows * nq * vb, hipDeviceMallocFinegrained) == hipSuccess) {
       e->fp_direct = true;                                                   // walker threads write the vector log through the BAR
     } else {
@@ -1176,7 +1223,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     }
     HIP_TRY(hipMemset(e->d_stage, 0, nq * BANG_STAGE_STRIDE * 4));
     memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
-    HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
+    if (!e->vec_on_device) HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
   }
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
@@ -1245,8 +1292,8 @@ static int alloc_buffers(bang_engine* e, int Q) {
     }
   }
   if (getenv("BANG_DEBUG"))
-    fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d persist=%d B=%u G=%u fp_direct=%d\n", Q, nl, e->threads_eff,
-            e->stage_mode_eff, (int)e->persist_on, e->pw_B, e->pw_G, (int)e->fp_direct);
+    fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d persist=%d B=%u G=%u fp_direct=%d vec_on_device=%d\n", Q, nl,
+            e->threads_eff, e->stage_mode_eff, (int)e->persist_on, e->pw_B, e->pw_G, (int)e->fp_direct, (int)e->vec_on_device);
   start_threads(e);
   return BANG_OK;
 }
@@ -1340,7 +1387,9 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.front_launches += ln.front_launches;
     s.front_ms += ln.front_ms; s.back_ms += ln.back_ms; s.rerank_ms += ln.rerank_ms; s.walker_ms += ln.walker_ms;
     s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
+    s.h2d_bytes += ln.h2d_bytes.load();
   }
+  s.persistent = e->persist_on ? 1 : 0;
   return rc;
 }
 
@@ -1364,9 +1413,10 @@ static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, uns
       if (busy) { sum += busy; ++wgs; }
     }
     if (wgs) {
-      const unsigned long long mean = sum / wgs;
-      ln.front_ms = (double)mean * 1e-5;
-      intervals.emplace_back(1ull, 1ull + mean);
+      ln.front_ms = (double)(sum / wgs) * 1e-5;
+      unsigned long long lo = ~0ull, hi = 0;               // the launch: first go-seen stamp .. last stamp of any workgroup
+      for (unsigned long long v : kt) if (v) { lo = std::min(lo, v); hi = std::max(hi, v); }
+      if (hi > lo) intervals.emplace_back(lo, hi);
     }
     if (const char* path = getenv("BANG_PW_TRACE")) {          // raw stamps for offline analysis (tools/dev/pw_trace.py)
       if (FILE* f = fopen(path, "wb")) {

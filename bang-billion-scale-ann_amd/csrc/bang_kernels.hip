@@ -218,16 +218,26 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t h
 // sort + merge of one query by one wave (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
 __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32_t q, uint32_t iter, const BackView& s, int lane) {
   const uint32_t L = p.L;
-  const uint32_t n = uni(p.d_cnt[q]);
-  if (n == 0) return;     // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
   const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
   const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
   uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
   float* wl_dist = p.d_wl_dist + (size_t)q * L;
   uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
+  // ONE memory round trip: every load below depends on q only and is issued before the first result is used (the survivor
+  // row always holds BANG_NBR_STRIDE words and the worklist arrays L words, whatever the counters say)
+  const uint32_t n_raw = p.d_cnt[q];
+  const uint32_t w_raw = p.d_wl_cnt[q];
   const uint32_t mark = p.d_mark[q];
-
-  for (uint32_t i = lane; i < n; i += WAVE) { s.sd[i] = dist[i]; s.si[i] = nbrs[i]; }
+  const float d_lo = dist[lane];
+  const uint32_t i_lo = nbrs[lane];
+  const uint32_t hi_at = WAVE + ((uint32_t)lane & (BANG_NBR_STRIDE - WAVE - 1));     // entries 64..71 (a row holds at most R + 1 = 65)
+  const float d_hi = dist[hi_at];
+  const uint32_t i_hi = nbrs[hi_at];
+  for (uint32_t i = lane; i < L; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
+  const uint32_t n = uni(n_raw);
+  if (n == 0) { wave_sync(); return; }     // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
+  s.sd[lane] = d_lo; s.si[lane] = i_lo;
+  if ((uint32_t)lane < BANG_NBR_STRIDE - WAVE) { s.sd[hi_at] = d_hi; s.si[hi_at] = i_hi; }
   wave_sync();
   // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
   for (uint32_t i = lane; i < n; i += WAVE) {
@@ -252,9 +262,7 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
       wl_vis[i] = (id == p.medoid || id == mark) ? 1 : 0;  // + mark step :1711-1714
     }
   } else {                                               // :1650-1708
-    const uint32_t w_n = uni(p.d_wl_cnt[q]);
-    for (uint32_t i = lane; i < w_n; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
-    wave_sync();
+    const uint32_t w_n = uni(w_raw);
     const float worst = s.wd[w_n - 1];
     const uint32_t lim = L < n ? L : n;
     // nb = number of leading new entries with dist < worst (stop at the first >=) :1653-1657
@@ -1061,7 +1069,8 @@ static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t l
 // nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  if (a.go) {   // persistent lane kernel: one query per wave at a time, 128-VGPR build
+  if (a.go) {   // persistent search kernel: 16 waves x 1 query each (128-VGPR build).  8 waves x 4 queries in flight (the
+                // 256-VGPR build) was measured slower here: front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us
     return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
                    : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
   }
@@ -1145,7 +1154,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
   // queries in flight per wave instead of 16 waves x 1 query.
   const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) > 32u;
-  if (pa && heavy) { bang_set_error("persistent lane kernel: PQ layout needs the 256-VGPR build"); return BANG_ERR_UNSUPPORTED; }
+  if (pa && heavy) { bang_set_error("persistent search kernel: this PQ layout needs the 256-VGPR build"); return BANG_ERR_UNSUPPORTED; }
   int nqw = (stages != 7u || pa) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
   nqw = (nqw >= 2) ? 4 : 1;
   int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
@@ -1156,7 +1165,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
   size_t lds_extra = 0;
   if (pa) {   // the wave's scratch doubles as its sort/merge view; one more 16-byte slot holds the broadcast `go` word
-    a.scratch_words = std::max<uint32_t>(FRONT_SCRATCH_WORDS, back_view_words(p->L));
+    a.scratch_words = std::max<uint32_t>(FRONT_SCRATCH_WORDS * (uint32_t)nqw, back_view_words(p->L));
     scratch_per_wave = (size_t)a.scratch_words * 4;
     lds_extra = 16;
   }

@@ -110,6 +110,10 @@ typedef struct {
   double enqueue_ms;          /* host time spent inside launch / memcpy-enqueue calls, summed over lanes */
   double front_busy_ms;       /* length of the UNION of the front-kernel launch intervals of all lanes ("timing"=1): the time
                                  during which at least one front kernel was running (lanes overlap) */
+  uint64_t persistent;        /* 1: the batch ran as ONE persistent search kernel (host-graph mode, "persistent" option).  Then
+                                 front_launches = 1, front_busy_ms = duration of that launch (first to last in-kernel stamp) and
+                                 front_ms = time a workgroup spent in its front phases, mean over the workgroups */
+  uint64_t h2d_bytes;         /* host-graph mode: bytes the walker handed to the device (adjacency rows + full-precision vectors) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 

@@ -128,13 +128,15 @@ def test_engine_host_loop_options_do_not_change_results(request, libbang, small_
 @pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
 @pytest.mark.parametrize("L", [10, 152])
 @pytest.mark.parametrize("persistent", [0, 1])
-def test_engine_host_loop_variants_match_oracle(request, libbang, fixture, L, persistent):
+@pytest.mark.parametrize("vectors", [0, 1])
+def test_engine_host_loop_variants_match_oracle(request, libbang, fixture, L, persistent, vectors):
     """Host-graph mode, both loop forms: "persistent"=1 = ONE search kernel per batch whose workgroups are paced one by one
-    by the walker threads; "persistent"=0 = a front and a back launch per iteration and lane."""
+    by the walker threads; "persistent"=0 = a front and a back launch per iteration and lane.  "vectors"=0: the walker ships
+    every expanded node's full-precision vector (the reference's data flow); 1: the re-rank reads a packed copy in HBM."""
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
-    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=persistent)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=persistent, vectors=vectors)
     assert np.array_equal(ids, ids_o)
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
     assert st["dist_evals"] == int(st_o[:, 2].sum())

@@ -35,7 +35,9 @@ def test_full_size_properties_and_sample_parity(libbang, sift1m_like):
     ix, q, gt_i, gt_d = sift1m_like
     ids_h, dists_h, st_h = _search(ix, q, 0)
     ids_d, dists_d, st_d = _search(ix, q, 1)
-    ids_l, dists_l, st_l = _search(ix, q, 0, persistent=0)      # host graph, a launch per iteration and lane
+    ids_l, dists_l, st_l = _search(ix, q, 0, persistent=0, vectors=0)   # host graph, a launch per iteration and lane, vectors shipped by the walker
+    ids_v, dists_v, st_v = _search(ix, q, 0, vectors=0)                 # persistent kernel, vectors shipped by the walker
+    assert np.array_equal(ids_h, ids_v) and np.array_equal(dists_h.view(np.uint32), dists_v.view(np.uint32))
     # 1. neither graph placement nor the form of the host loop changes a single bit of the result
     assert np.array_equal(ids_h, ids_d) and np.array_equal(dists_h.view(np.uint32), dists_d.view(np.uint32))
     assert np.array_equal(ids_h, ids_l) and np.array_equal(dists_h.view(np.uint32), dists_l.view(np.uint32))
