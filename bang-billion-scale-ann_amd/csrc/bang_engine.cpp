@@ -236,7 +236,8 @@ struct bang_engine {
   int compact = 1;                     // straggler compaction on/off
   int persistent = -1;                 // host-graph mode: 1 = ONE persistent search kernel per batch, its workgroups paced by the walker threads;
                                        // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
-  bool persist_on = false;             // resolved at bang_alloc: the persistent kernel is used for this allocation
+  bool persist_on = false;             // resolved at bang_alloc: the host-paced persistent kernel is used for this allocation
+  bool persist_dev = false;            // resolved at bang_alloc: device-graph mode runs as ONE self-paced persistent kernel
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
   int vectors_opt = -1;                // host-graph mode, where the full-precision vectors for the re-rank live: 0 = host (the walker ships
                                        // every expanded node's vector, as the reference does), 1 = a packed copy [N][vec_bytes] in HBM (the
@@ -836,7 +837,19 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     return BANG_OK;
   };
 
-  if (persist) {
+  uint32_t pw_stats[2] = {0, 0};
+  if (e->persist_dev) {
+    // graph resident in HBM: the whole search is ONE self-paced launch, no host involvement until the re-rank
+    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
+    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq; p.max_wgs = 0; p.d_active = nullptr;
+    unsigned long long* kt_base = (e->timing && ln.d_ktime && ln.kt_launches >= (size_t)cap_iter + 1) ? ln.d_ktime : nullptr;
+    ENQ_BEGIN();
+    BANG_TRY(bang_k_search_persistent(&p, cap_iter, e->pw_B, nullptr, kt_base, ln.d_pcnt, 1u, ln.s_main));
+    ENQ_END();
+    ++ln.front_launches;
+    iter = cap_iter;                                                         // refined from the kernel's own count below
+    if (kt_base) ln.kt_used = (size_t)cap_iter + 1;
+  } else if (persist) {
     // ONE launch per batch: every workgroup owns a block of pw_B queries and runs front(t) -> parents + flag -> back(t) for
     // t = 1..cap on its own clock; before front(t) it waits until a walker thread has stored t into its `go` word (after that
     // block's rows of iteration t-1 are in device memory).  No lanes, no per-iteration launches, no batch-wide step.
@@ -965,12 +978,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                           (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
-  uint32_t gave_up = 0;
-  if (persist) LANE_HIP(hipMemcpyAsync(&gave_up, ln.d_pcnt, 4, hipMemcpyDeviceToHost, ln.s_main));
+  if (persist || e->persist_dev) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt, 8, hipMemcpyDeviceToHost, ln.s_main));
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
-  if (gave_up) { bang_set_error("persistent search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
+  if (pw_stats[0]) { bang_set_error("persistent search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
+  if (e->persist_dev && pw_stats[1]) ln.iterations = pw_stats[1];
   DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats
   return BANG_OK;
@@ -1173,8 +1186,9 @@ static int alloc_buffers(bang_engine* e, int Q) {
   // so "auto" takes the persistent kernel only in BAR mode)
   const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);
   e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u);
+  e->persist_dev = dev_graph && e->persistent != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u);
   e->fp_direct = false;
-  if (e->persist_on) {
+  if (e->persist_on || e->persist_dev) {
     const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
     e->pw_B = std::max<uint32_t>(16u, ((uint32_t)Q + cus - 1) / cus);
     e->pw_G = ((uint32_t)Q + e->pw_B - 1) / e->pw_B;
@@ -1228,7 +1242,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->persist_on) nl = 1;                             // the persistent kernel's workgroups are the unit of overlap, not lanes
+  if (e->persist_on || e->persist_dev) nl = 1;           // the persistent kernel's workgroups are the unit of overlap, not lanes
   if (e->persist_on && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
   else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
@@ -1269,6 +1283,10 @@ static int alloc_buffers(bang_engine* e, int Q) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
       }
     }
+    if (e->persist_dev) {
+      BANG_TRY(dmalloc(&ln.d_pcnt, 16));
+      HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
+    }
     if (e->persist_on) {
       const size_t go_bytes = (size_t)e->pw_G * 64;
       BANG_TRY(dmalloc(&ln.d_pcnt, 16));
@@ -1286,7 +1304,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     }
     if (e->timing) {
       ln.kt_launches = rows + 4;
-      ln.kt_words = e->persist_on ? 4 : 2;                   // stamps per workgroup and launch/iteration
+      ln.kt_words = (e->persist_on || e->persist_dev) ? 4 : 2;                   // stamps per workgroup and launch/iteration
       HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
       HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
     }
@@ -1389,7 +1407,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
     s.h2d_bytes += ln.h2d_bytes.load();
   }
-  s.persistent = e->persist_on ? 1 : 0;
+  s.persistent = (e->persist_on || e->persist_dev) ? 1 : 0;
   return rc;
 }
 
@@ -1458,7 +1476,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   bang_stats& s = e->stats;
   if (e->allocated && e->timing && s.front_ms == 0) {
     std::vector<std::pair<unsigned long long, unsigned long long>> iv;
-    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv, e->persist_on)); s.front_ms += lp->front_ms; }
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv, e->persist_on || e->persist_dev)); s.front_ms += lp->front_ms; }
     std::sort(iv.begin(), iv.end());                   // the stamps of all lanes share one 100 MHz clock: merge the intervals
     unsigned long long cur_lo = 0, cur_hi = 0, busy = 0;
     for (auto& p : iv) {

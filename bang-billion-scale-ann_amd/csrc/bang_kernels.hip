@@ -327,6 +327,7 @@ struct FrontArgs {
   uint32_t wg_queries;         // queries per workgroup
   unsigned long long* ktime_base;   // [iter][KT_WGS][4] stamps {go seen, front end, flag published, sort/merge end} or NULL
   uint32_t* abort_flag;        // set to 1 if a workgroup gave up waiting for `go`
+  uint32_t persist;            // host side: pick the persistent instance
   uint32_t rows_uncached;      // 1: d_stage is LOCAL device memory written by the CPU through the BAR -> plain coalesced loads (see the row loads)
 };
 #define KT_WGS_DEV 256u
@@ -398,10 +399,20 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   for (uint32_t cur_iter = p.iter; cur_iter <= (PERSIST ? a.iter_end : p.iter); ++cur_iter) {
   const uint32_t first = PERSIST ? (cur_iter == 1 ? 1u : 0u) : (p.first ? 1u : 0u);
   if (PERSIST) {
-    // wait until the host walker has staged this workgroup's adjacency rows of this iteration
-    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;    // one LDS word behind the per-wave scratch
+    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;    // LDS words behind the per-wave scratch: [0] go, [1..2] any-active
+    if (a.go == nullptr) {
+      // self-paced (graph resident in HBM): nothing to wait for; the parents this workgroup stored write-through in its last
+      // iteration must not be read from a stale L1 line
+      if (threadIdx.x == 0) {
+        s_go[1 + (cur_iter & 1u)] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_go = cur_iter;
+      }
+    }
+    // host-paced: wait until the host walker has staged this workgroup's adjacency rows of this iteration
     const uint32_t* go = a.go + (size_t)blockIdx.x * 16;
-    if (threadIdx.x == 0) {
+    if (a.go != nullptr && threadIdx.x == 0) {
       uint32_t v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (v < cur_iter) {                         // BANG_GO_STOP is the largest value: it also ends the wait
@@ -734,7 +745,11 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // device counter; the LAST workgroup re-reads the parents with `sc1` loads, copies them to mapped pinned host
   // memory with system-scope stores (coalesced: one 4-byte PCIe write per query from every wave was measured at
   // +75 us per launch), drains, and publishes the iteration number.  The walker thread spins on that word.
-  if (PERSIST) {
+  if (PERSIST && a.go == nullptr) {
+    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;
+    if (lane == 0 && n_active) s_go[1 + (cur_iter & 1u)] = 1u;
+    __syncthreads();
+  } else if (PERSIST) {
     // every workgroup reports on its own: its waves drain their write-through parent stores, the block's parents go to
     // mapped pinned host memory in one coalesced store, and the iteration number is published behind them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -779,11 +794,19 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   if (PERSIST) {
     // K3a + K3b for the queries of this wave, while the host walks (the standalone back kernel in the launch-per-iteration mode)
     const BackView bv = back_view_at(scratch, L);
-    for (uint32_t slot = q_begin; slot < q_end; slot += q_step) back_one_query(p, slot, cur_iter, bv, lane);
+    // self-paced: a block none of whose queries has a parent or unmerged survivors is finished (every wave reads the word
+    // of THIS iteration; the other one is reset at the start of the next iteration, behind a workgroup barrier)
+    const bool block_done = (a.go == nullptr) && (scratch_all[(size_t)nwaves * a.scratch_words + 1 + (cur_iter & 1u)] == 0u);
+    if (cur_iter < a.iter_end || a.go != nullptr)
+      for (uint32_t slot = q_begin; slot < q_end; slot += q_step) back_one_query(p, slot, cur_iter, bv, lane);
     n_active = 0;
     if (a.ktime_base) {
       __syncthreads();
       if (threadIdx.x == 0) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (block_done || cur_iter == a.iter_end) {
+      if (a.abort_flag && threadIdx.x == 0) atomicMax(a.abort_flag + 1, cur_iter);   // statistics: iterations of the slowest block
+      break;
     }
   }
   }   // iterations
@@ -1069,7 +1092,7 @@ static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t l
 // nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  if (a.go) {   // persistent search kernel: 16 waves x 1 query each (128-VGPR build).  8 waves x 4 queries in flight (the
+  if (a.persist) {   // persistent search kernel: 16 waves x 1 query each (128-VGPR build).  8 waves x 4 queries in flight (the
                 // 256-VGPR build) was measured slower here: front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us
     return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
                    : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
@@ -1109,14 +1132,15 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   FrontArgs a;
   a.p = *p;
   a.stages = stages;
-  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.wg_queries = 0; a.ktime_base = nullptr; a.abort_flag = nullptr; a.rows_uncached = 0;
+  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.wg_queries = 0; a.ktime_base = nullptr; a.abort_flag = nullptr; a.rows_uncached = 0; a.persist = pa ? 1u : 0u;
   if (pa) {
-    if (stages != 7u || !pa->go || !pa->wg_queries || !p->h_done_flag || !p->h_parents || p->d_qmap || p->d_graph || !p->d_stage ||
-        pa->iter_end < p->iter) {
+    const bool host_paced = pa->go != nullptr;
+    if (stages != 7u || !pa->wg_queries || p->d_qmap || pa->iter_end < p->iter ||
+        (host_paced ? (!p->h_done_flag || !p->h_parents || !p->d_stage || p->d_graph) : !p->d_graph)) {
       bang_set_error("bad persistent launch arguments"); return BANG_ERR_ARG;
     }
     a.go = pa->go; a.iter_end = pa->iter_end; a.wg_queries = pa->wg_queries; a.ktime_base = pa->ktime_base; a.abort_flag = pa->abort_flag;
-    a.rows_uncached = pa->rows_uncached;
+    a.rows_uncached = host_paced ? pa->rows_uncached : 1u;
   }
   {
     static int dbg = -1;

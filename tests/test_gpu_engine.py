@@ -143,6 +143,23 @@ def test_engine_host_loop_variants_match_oracle(request, libbang, fixture, L, pe
     assert st["fetched"] == int(st_o[:, 3].sum())
 
 
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("persistent", [0, 1])
+@pytest.mark.parametrize("L", [10, 64])
+def test_engine_device_loop_variants_match_oracle(request, libbang, fixture, persistent, L):
+    """Graph resident in HBM, both loop forms: ONE self-paced persistent search kernel per batch ("persistent"=1, the default)
+    or a front and a back launch per iteration with the termination flag polled every 16 iterations ("persistent"=0)."""
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=1, persistent=persistent, timing=1)
+    assert np.array_equal(ids, ids_o)
+    assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    assert st["dist_evals"] == int(st_o[:, 2].sum())
+    assert st["candidates"] == int(st_o[:, 1].sum())
+    assert st["persistent"] in (0, persistent)          # PQ layouts that need the 256-VGPR build keep the launch-per-iteration loop
+
+
 def test_query_smaller_than_allocation(request, libbang, small_f32):
     """bang_alloc(Q) then bang_query on fewer queries (the vector log and the rank-major distance matrix re-stride)."""
     import bang_amd
