@@ -16,5 +16,6 @@ python3 tools/summarize_profile.py "$OUT" "$TTAG" > "$OUT/summary.md" 2> "$OUT/s
 mkdir -p gpurun_out/profiles_out
 cp "$OUT/summary.md" gpurun_out/profiles_out/${TAG}_summary.md
 cp profiles/traffic_${TTAG}.json gpurun_out/profiles_out/ 2>/dev/null
+cp "$OUT/bench_trace.json" gpurun_out/profiles_out/${TAG}_bench_under_trace.json 2>/dev/null
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|front_kernel|back_kernel|rerank_kernel|center_queries|init_state" "$f" > gpurun_out/profiles_out/${TAG}_kernel_stats.csv
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write"

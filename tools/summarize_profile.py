@@ -89,7 +89,9 @@ for t, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 if tag and per:
     fetch, write = per.get("FETCH_SIZE", 0.0), per.get("WRITE_SIZE", 0.0)
     rf = (bench.get("trace") or {}).get("roofline") or {}
-    js = {"front_kernel_hbm_bytes_per_launch": round(fetch + write),
+    persistent = "PERSIST" in str(rf.get("kernel", ""))
+    js = {("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch"): round(fetch + write),
+          "host_loop": "persistent search kernel (one launch per batch)" if persistent else "launch per iteration",
           "fetch_bytes_per_launch_raw": round(fetch), "fetch_bytes_per_launch_x2_upper_bound": round(2 * fetch),
           "write_bytes_per_launch": round(write),
           "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
