@@ -54,7 +54,7 @@ class Stats(C.Structure):
                 ("fetched", C.c_uint64), ("candidates", C.c_uint64), ("front_launches", C.c_uint64),
                 ("front_ms", C.c_double), ("back_ms", C.c_double), ("rerank_ms", C.c_double),
                 ("walker_ms", C.c_double), ("sync_ms", C.c_double), ("enqueue_ms", C.c_double), ("front_busy_ms", C.c_double),
-                ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64)]
+                ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64)]
 
 
 def lib_path() -> str:

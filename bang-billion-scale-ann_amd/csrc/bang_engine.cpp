@@ -1408,6 +1408,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.h2d_bytes += ln.h2d_bytes.load();
   }
   s.persistent = (e->persist_on || e->persist_dev) ? 1 : 0;
+  s.vectors_on_device = e->vec_on_device ? 1 : 0;
   return rc;
 }
 

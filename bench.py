@@ -138,7 +138,8 @@ def main():
         if not lanes:
             lanes = max(1, min(4, share // 2, Qr // 512 if Qr >= 512 else 1))
         if not threads:
-            threads = max(1, min(4, share // lanes))
+            # (the persistent kernel ignores lanes: its one walker team gets the whole share)
+            threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // lanes))
     eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=lanes, threads=threads,
                           timing=0 if args.no_events else 1)
     eng.load_index(ix, d_codes=d_codes)
@@ -195,7 +196,7 @@ def main():
         run_once(L, timed=True)
     step_s, init_s = [], []
     agg = dict(front_ms=0.0, front_busy_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
-               fetched=0, candidates=0, h2d_bytes=0, persistent=0)
+               fetched=0, candidates=0, h2d_bytes=0, persistent=0, vectors_on_device=0)
     ids = None
     for _ in range(args.steps):
         ti = time.perf_counter()
@@ -204,7 +205,7 @@ def main():
         step_s.append(el)
         st = eng.stats()
         for key in agg:
-            agg[key] = agg[key] + st[key] if key not in ("iterations", "persistent") else max(agg[key], st[key])
+            agg[key] = agg[key] + st[key] if key not in ("iterations", "persistent", "vectors_on_device") else max(agg[key], st[key])
     if gt_i is not None:
         recall = recall_of(ids)
     times = torch.tensor([step_s, init_s], dtype=torch.float64, device=cdev)
@@ -310,6 +311,9 @@ def main():
             "config": {"workload": wl_name, "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None), "graph": args.graph,
                        "lanes": lanes, "walker_threads_per_lane": threads, "iterations": agg["iterations"],
                        "host_loop": "persistent search kernel" if agg["persistent"] else "launch per iteration",
+                       "rerank_vectors": ("graph entries in HBM" if args.graph == "device" else
+                                          "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
+                       "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
                        "qps_incl_init": round(Q * args.steps / total_incl_init, 1),
                        "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
                        "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),

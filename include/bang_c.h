@@ -114,6 +114,8 @@ typedef struct {
                                  front_launches = 1, front_busy_ms = duration of that launch (first to last in-kernel stamp) and
                                  front_ms = time a workgroup spent in its front phases, mean over the workgroups */
   uint64_t h2d_bytes;         /* host-graph mode: bytes the walker handed to the device (adjacency rows + full-precision vectors) */
+  uint64_t vectors_on_device; /* host-graph mode: 1 = the re-rank read a packed copy of the vectors in HBM ("vectors" option),
+                                 0 = the walker shipped every expanded node's vector (the reference's data flow) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 
