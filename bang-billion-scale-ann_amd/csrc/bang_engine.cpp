@@ -562,11 +562,12 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   uint32_t active = 0, np = 0;
   uint64_t bytes = 0;
   const uint32_t PF = 8;                                   // software prefetch distance (entries are 388-644 B)
+  const uint64_t pf0 = ship_vec ? 0 : (vb & ~(uint64_t)63);  // resident vectors: only the adjacency part of an entry is touched
   for (uint32_t i = i0; i < i1 && i < i0 + PF; ++i) {
     const uint32_t par = parents[i];
     if (par < BANG_IDLE_PARENT) {
       const uint8_t* ent = graph + (uint64_t)par * elen;
-      for (uint64_t o = 0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+      for (uint64_t o = pf0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
     }
   }
   for (uint32_t i = i0; i < i1; ++i) {
@@ -574,7 +575,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
       const uint32_t par = parents[i + PF];
       if (par < BANG_IDLE_PARENT) {
         const uint8_t* ent = graph + (uint64_t)par * elen;
-        for (uint64_t o = 0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+        for (uint64_t o = pf0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
       }
     }
     const uint32_t par = parents[i];
@@ -623,15 +624,8 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
   volatile uint32_t* go = ln.go_host;
   auto t_last = Clock::now();
   uint32_t idle = 0;
-  static const bool lockstep = getenv("BANG_PW_LOCKSTEP") != nullptr;   // experiment: release the workgroups together
-  std::vector<std::pair<uint32_t, uint32_t>> deferred;
   while (remaining) {
     bool progress = false;
-    if (lockstep) {
-      bool all = true;
-      for (uint32_t w = w0; w < w1; ++w) { const uint32_t it = expect[w - w0]; if (it != 0 && done[(size_t)w * 16] != it) all = false; }
-      if (!all) { _mm_pause(); continue; }
-    }
     for (uint32_t w = w0; w < w1; ++w) {
       const uint32_t it = expect[w - w0];
       if (it == 0 || done[(size_t)w * 16] != it) continue;
@@ -646,15 +640,10 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
         expect[w - w0] = 0;
         --remaining;
       } else {
-        if (lockstep) deferred.emplace_back(w, it + 1);
-        else { go[(size_t)w * 16] = it + 1; _mm_sfence(); }
+        go[(size_t)w * 16] = it + 1;
+        _mm_sfence();
         expect[w - w0] = it + 1;
       }
-    }
-    if (lockstep) {
-      for (auto& d : deferred) go[(size_t)d.first * 16] = d.second;
-      _mm_sfence();
-      deferred.clear();
     }
     if (progress) { idle = 0; continue; }
     _mm_pause();
@@ -1180,13 +1169,14 @@ static int alloc_buffers(bang_engine* e, int Q) {
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) != hipSuccess) large_bar = 0;
     e->stage_mode_eff = large_bar ? 2 : 1;
   } else e->stage_mode_eff = e->stage_zero_copy;
-  // persistent search kernel: host graph, in-kernel completion flags, rows readable in place (BAR or zero-copy), and a PQ
-  // layout whose kernel fits the 128-VGPR build (the others keep the launch-per-iteration loop)
+  // persistent search kernel: host graph, in-kernel completion flags, rows readable in place (BAR or zero-copy), and room in
+  // LDS for the pivot table plus the merge scratch of all waves (otherwise: the launch-per-iteration loop)
   // (mapped-host rows need cache-bypassing loads, which are issued per lane: measured 2x slower than the per-iteration loop,
   // so "auto" takes the persistent kernel only in BAR mode)
   const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);
-  e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u);
-  e->persist_dev = dev_graph && e->persistent != 0 && !(e->psz != 0 && e->psz * (e->mp / 4u) > 32u);
+  const bool persist_fits = bang_persistent_supported(e->psz, e->mp, (uint32_t)e->L) != 0;
+  e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && persist_fits;
+  e->persist_dev = dev_graph && e->persistent != 0 && persist_fits;
   e->fp_direct = false;
   if (e->persist_on || e->persist_dev) {
     const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));

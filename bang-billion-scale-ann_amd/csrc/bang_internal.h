@@ -36,6 +36,8 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
 int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
                              unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_uncached, void* stream);
 int bang_num_cus(void);
+// 1 if the persistent search kernel can run this PQ layout at worklist length L with all its waves (LDS budget)
+int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t L);
 
 #ifdef __cplusplus
 }

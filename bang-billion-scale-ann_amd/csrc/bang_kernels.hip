@@ -176,25 +176,29 @@ __device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ cod
 // back: K3a stable sort of the survivors + K3b merge into the worklist, one wave per query
 // ------------------------------------------------------------------------------------------
 #define BACK_WAVES 4
+#define BACK_WL_REGS (BANG_MAX_L / WAVE)   // worklist entries a lane owns: k = lane + 64 j
+#define BACK_WI_REGS 4                     // ... whose ids are kept in registers across the sort (the rest is parked in LDS)
 struct BackLds {
   float sd[BANG_NBR_STRIDE];      // unsorted distances
   uint32_t si[BANG_NBR_STRIDE];
   float td[BANG_NBR_STRIDE];      // sorted
   uint32_t ti[BANG_NBR_STRIDE];
-  float wd[BANG_MAX_L];
-  uint32_t wi[BANG_MAX_L];
-  uint8_t wv[BANG_MAX_L];
+  float wd[BANG_MAX_L];           // worklist distances (binary-searched); its flags and the first 256 ids stay in registers
+  uint32_t wi_hi[BANG_MAX_L - BACK_WI_REGS * WAVE];   // ids of entries 256.. (L > 256 only)
 };
 // per-wave LDS view used by back_one_query (static BackLds in back_kernel, carved from dynamic LDS in the persistent kernel)
 struct BackView {
-  float* sd; uint32_t* si; float* td; uint32_t* ti; float* wd; uint32_t* wi; uint8_t* wv;
+  float* sd; uint32_t* si; float* td; uint32_t* ti; float* wd; uint32_t* wi_hi;
 };
 // LDS words a wave needs for a BackView at worklist length L (16-byte multiple)
-__host__ __device__ inline uint32_t back_view_words(uint32_t L) { return (4u * BANG_NBR_STRIDE + 2u * L + (L + 3u) / 4u + 3u) & ~3u; }
+__host__ __device__ inline uint32_t back_view_words(uint32_t L) {
+  return (4u * BANG_NBR_STRIDE + L + (L > BACK_WI_REGS * WAVE ? L - BACK_WI_REGS * WAVE : 0u) + 3u) & ~3u;
+}
 __device__ __forceinline__ BackView back_view_at(uint32_t* base, uint32_t L) {
   BackView v;
   v.sd = (float*)base; v.si = base + BANG_NBR_STRIDE; v.td = (float*)(base + 2 * BANG_NBR_STRIDE); v.ti = base + 3 * BANG_NBR_STRIDE;
-  v.wd = (float*)(base + 4 * BANG_NBR_STRIDE); v.wi = base + 4 * BANG_NBR_STRIDE + L; v.wv = (uint8_t*)(base + 4 * BANG_NBR_STRIDE + 2 * L);
+  v.wd = (float*)(base + 4 * BANG_NBR_STRIDE);
+  v.wi_hi = base + 4 * BANG_NBR_STRIDE + L;
   return v;
 }
 
@@ -215,29 +219,75 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t h
   return lo;
 }
 
-// sort + merge of one query by one wave (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
-__device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32_t q, uint32_t iter, const BackView& s, int lane) {
+// Everything back_one_query reads from global memory: depends on the query only, so a wave can have the NEXT query's loads
+// in flight while it sorts and merges the current one.
+struct BackIn {
+  uint32_t n_raw, w_raw, mark, i_lo, i_hi;
+  float d_lo, d_hi;
+  float wd_r[BACK_WL_REGS];          // short lived: parked in LDS before the sort
+  uint32_t wi_r[BACK_WL_REGS];       // ids of the worklist entries this lane owns (k = lane + 64 j); j >= BACK_WI_REGS parked in LDS
+  uint32_t wv_bits;                  // their visited flags, bit j
+};
+#define BACK_HI_AT(lane) (WAVE + ((uint32_t)(lane) & (BANG_NBR_STRIDE - WAVE - 1)))   // entries 64..71 (a row holds at most R + 1 = 65)
+
+// ONE memory round trip: every load depends on q only and is issued before the first result is used (the survivor row always
+// holds BANG_NBR_STRIDE words and the worklist arrays L words, whatever the counters say)
+__device__ __forceinline__ void back_load(const bang_iter_params& p, uint32_t q, int lane, BackIn& in) {
   const uint32_t L = p.L;
   const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
   const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
+  const uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
+  const float* wl_dist = p.d_wl_dist + (size_t)q * L;
+  const uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
+  in.n_raw = p.d_cnt[q];
+  in.w_raw = p.d_wl_cnt[q];
+  in.mark = p.d_mark[q];
+  in.d_lo = dist[lane];
+  in.i_lo = nbrs[lane];
+  in.d_hi = dist[BACK_HI_AT(lane)];
+  in.i_hi = nbrs[BACK_HI_AT(lane)];
+  uint32_t vis[BACK_WL_REGS];
+#pragma unroll
+  for (int j = 0; j < BACK_WL_REGS; ++j) {
+    in.wd_r[j] = 0.0f; vis[j] = 0u;
+    in.wi_r[j] = 0u;
+    if ((uint32_t)j * WAVE < L) {                       // uniform: only the ceil(L / 64) entries a lane can own are loaded
+      const uint32_t i = (uint32_t)lane + (uint32_t)j * WAVE;
+      const uint32_t ic = i < L ? i : 0u;               // lanes past the end re-read entry 0 (never used)
+      in.wd_r[j] = wl_dist[ic]; vis[j] = wl_vis[ic];
+      in.wi_r[j] = wl_ids[ic];
+    }
+  }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < BACK_WL_REGS; ++j) bits |= (vis[j] ? 1u : 0u) << j;
+  in.wv_bits = bits;
+}
+
+// sort + merge of one query by one wave (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
+__device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32_t q, uint32_t iter, const BackView& s, int lane,
+                                               const BackIn& in) {
+  const uint32_t L = p.L;
   uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
   float* wl_dist = p.d_wl_dist + (size_t)q * L;
   uint8_t* wl_vis = p.d_wl_vis + (size_t)q * L;
-  // ONE memory round trip: every load below depends on q only and is issued before the first result is used (the survivor
-  // row always holds BANG_NBR_STRIDE words and the worklist arrays L words, whatever the counters say)
-  const uint32_t n_raw = p.d_cnt[q];
-  const uint32_t w_raw = p.d_wl_cnt[q];
-  const uint32_t mark = p.d_mark[q];
-  const float d_lo = dist[lane];
-  const uint32_t i_lo = nbrs[lane];
-  const uint32_t hi_at = WAVE + ((uint32_t)lane & (BANG_NBR_STRIDE - WAVE - 1));     // entries 64..71 (a row holds at most R + 1 = 65)
-  const float d_hi = dist[hi_at];
-  const uint32_t i_hi = nbrs[hi_at];
-  for (uint32_t i = lane; i < L; i += WAVE) { s.wd[i] = wl_dist[i]; s.wi[i] = wl_ids[i]; s.wv[i] = wl_vis[i]; }
+  const uint32_t n_raw = in.n_raw, w_raw = in.w_raw, mark = in.mark;
+  const float d_lo = in.d_lo, d_hi = in.d_hi;
+  const uint32_t i_lo = in.i_lo, i_hi = in.i_hi;
+  const uint32_t hi_at = BACK_HI_AT(lane);
+  const float* wd_r = in.wd_r;
   const uint32_t n = uni(n_raw);
   if (n == 0) { wave_sync(); return; }     // :1547 / :1636 -- nothing to sort or merge (mark step is a no-op then)
   s.sd[lane] = d_lo; s.si[lane] = i_lo;
   if ((uint32_t)lane < BANG_NBR_STRIDE - WAVE) { s.sd[hi_at] = d_hi; s.si[hi_at] = i_hi; }
+#pragma unroll
+  for (int j = 0; j < BACK_WL_REGS; ++j) {
+    const uint32_t i = (uint32_t)lane + (uint32_t)j * WAVE;
+    if (i < L) {
+      s.wd[i] = wd_r[j];
+      if (j >= BACK_WI_REGS) s.wi_hi[i - BACK_WI_REGS * WAVE] = in.wi_r[j];
+    }
+  }
   wave_sync();
   // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
   for (uint32_t i = lane; i < n; i += WAVE) {
@@ -285,12 +335,16 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
         wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (id == mark) ? 1 : 0;
       }
     }
-    for (uint32_t k = lane; k < w_n; k += WAVE) {        // old entries: upper_bound + k :1678-1680
-      const float d = s.wd[k];
-      const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
-      if (pos < new_n) {
-        const uint32_t id = s.wi[k];
-        wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (s.wv[k] || id == mark) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < BACK_WL_REGS; ++j) {             // old entries: upper_bound + k :1678-1680
+      const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
+      if (k < w_n) {
+        const float d = s.wd[k];
+        const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
+        if (pos < new_n) {
+          const uint32_t id = (j < BACK_WI_REGS) ? in.wi_r[j] : s.wi_hi[k - BACK_WI_REGS * WAVE];
+          wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (((in.wv_bits >> j) & 1u) || id == mark) ? 1 : 0;
+        }
       }
     }
   }
@@ -304,10 +358,12 @@ __global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_
   const uint32_t wave = uni(threadIdx.x >> 6);
   BackLds& b = lds_all[wave];
   BackView s;
-  s.sd = b.sd; s.si = b.si; s.td = b.td; s.ti = b.ti; s.wd = b.wd; s.wi = b.wi; s.wv = b.wv;
+  s.sd = b.sd; s.si = b.si; s.td = b.td; s.ti = b.ti; s.wd = b.wd; s.wi_hi = b.wi_hi;
   for (uint32_t slot = blockIdx.x * BACK_WAVES + wave; slot < p.Q; slot += gridDim.x * BACK_WAVES) {
     const uint32_t q = p.d_qmap ? uni(p.d_qmap[slot]) : slot;
-    back_one_query(p, q, p.iter, s, lane);
+    BackIn in;
+    back_load(p, q, lane, in);
+    back_one_query(p, q, p.iter, s, lane, in);
   }
 }
 
@@ -385,7 +441,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
   // slots of this wave: q_begin, q_begin + q_step, ... < q_end (persistent: inside the workgroup's own block of queries)
-  const bool own_blk = PERSIST && !(a.debug & 128u);     // debug bit 128: strided ownership (timing experiments only)
+  const bool own_blk = PERSIST;
   const uint32_t wg_q0 = PERSIST ? blockIdx.x * a.wg_queries : 0u;
   const uint32_t wg_q1 = PERSIST ? (wg_q0 + a.wg_queries < p.Q ? wg_q0 + a.wg_queries : p.Q) : p.Q;
   const uint32_t q_end = own_blk ? wg_q1 : p.Q;
@@ -427,10 +483,8 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       *s_go = v;
       // everything other agents (the CPU through the BAR) or this kernel's own atomics wrote since the last iteration
       // must not be served from this CU's L1
-      if (!(a.debug & 64u)) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (*s_go == BANG_GO_STOP) break;
@@ -798,7 +852,13 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     // of THIS iteration; the other one is reset at the start of the next iteration, behind a workgroup barrier)
     const bool block_done = (a.go == nullptr) && (scratch_all[(size_t)nwaves * a.scratch_words + 1 + (cur_iter & 1u)] == 0u);
     if (cur_iter < a.iter_end || a.go != nullptr)
-      for (uint32_t slot = q_begin; slot < q_end; slot += q_step) back_one_query(p, slot, cur_iter, bv, lane);
+      for (uint32_t slot = q_begin; slot < q_end; slot += q_step) {
+        // (prefetching the next query's BackIn while this one is merged was tried: the two live register sets pushed the
+        // kernel into scratch spills and doubled the phase)
+        BackIn in;
+        back_load(p, slot, lane, in);
+        back_one_query(p, slot, cur_iter, bv, lane, in);
+      }
     n_active = 0;
     if (a.ktime_base) {
       __syncthreads();
@@ -1092,10 +1152,17 @@ static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t l
 // nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  if (a.persist) {   // persistent search kernel: 16 waves x 1 query each (128-VGPR build).  8 waves x 4 queries in flight (the
-                // 256-VGPR build) was measured slower here: front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us
-    return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
-                   : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
+  if (a.persist) {
+    // persistent search kernel: 16 waves x 1 query each (128-VGPR build); for the SIFT1M-like layout 8 waves x 4 queries in
+    // flight (the 256-VGPR build) was measured slower (front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us).
+    // Layouts whose straight-line distance code does not fit 128 VGPRs only have the 8-wave build.
+    if constexpr (PSZ * NDW > 32) {
+      return aligned ? launch_front_inst<PSZ, NDW, true, true, 4, 512, true>(a, grid, block, lds, st)
+                     : launch_front_inst<PSZ, NDW, false, true, 4, 512, true>(a, grid, block, lds, st);
+    } else {
+      return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
+                     : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
+    }
   }
   const bool all = (a.stages == 7u);
   if (!all) {
@@ -1178,10 +1245,9 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
   // queries in flight per wave instead of 16 waves x 1 query.
   const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) > 32u;
-  if (pa && heavy) { bang_set_error("persistent search kernel: this PQ layout needs the 256-VGPR build"); return BANG_ERR_UNSUPPORTED; }
-  int nqw = (stages != 7u || pa) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
+  int nqw = (stages != 7u) ? 1 : (pa ? (heavy ? 4 : 1) : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1)));
   nqw = (nqw >= 2) ? 4 : 1;
-  int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
+  int max_waves = (env_waves > 0 && !pa) ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
   if (max_waves > 16) max_waves = 16;
   int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;
@@ -1193,9 +1259,15 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
     scratch_per_wave = (size_t)a.scratch_words * 4;
     lds_extra = 16;
   }
+  const int waves_wanted = waves;
   while (waves > 1 && piv_bytes + lds_extra + (size_t)waves * scratch_per_wave > lds_cap) --waves;
   const size_t lds = piv_bytes + lds_extra + (size_t)waves * scratch_per_wave;
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
+  // a persistent launch that had to give up waves to make room for the merge scratch is slower than the per-iteration loop
+  if (pa && waves < waves_wanted && waves < (heavy ? 6 : 12)) {
+    bang_set_error("persistent search kernel: %d of %d waves fit beside the pivot table at L=%u", waves, waves_wanted, p->L);
+    return BANG_ERR_UNSUPPORTED;
+  }
   int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
   if (pa) {
@@ -1233,6 +1305,16 @@ extern "C" int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter
   return launch_front(p, 7u, stream, &pa);
 }
 extern "C" int bang_num_cus(void) { return num_cus(); }
+
+// Does the persistent search kernel have room for enough waves (pivot table + per-wave front/merge scratch within 160 KB of
+// LDS) for this PQ layout and worklist length?  Mirrors the launcher's arithmetic.
+extern "C" int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t L) {
+  const bool heavy = psz != 0 && psz * (mp / 4u) > 32u;
+  const uint32_t nqw = heavy ? 4u : 1u, waves = heavy ? 6u : 12u;      // at least three quarters of the waves must fit
+  const size_t piv_bytes = (size_t)mp * 256u * psz * 4u;
+  const size_t per_wave = (size_t)std::max<uint32_t>(FRONT_SCRATCH_WORDS * nqw, back_view_words(L)) * 4u;
+  return piv_bytes + 16 + waves * per_wave <= (size_t)160 * 1024 ? 1 : 0;
+}
 extern "C" int bang_k_filter(const bang_iter_params* p, void* stream) { return launch_front(p, 1u, stream); }
 extern "C" int bang_k_pqdist(const bang_iter_params* p, void* stream) { return launch_front(p, 2u, stream); }
 extern "C" int bang_k_parent(const bang_iter_params* p, void* stream) { return launch_front(p, 4u, stream); }
