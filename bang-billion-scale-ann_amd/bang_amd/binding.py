@@ -40,6 +40,7 @@ class IterParams(C.Structure):
         ("d_mark", C.c_void_p), ("d_parents", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_row", C.c_void_p),
         ("d_cand_cnt", C.c_void_p), ("d_active", C.c_void_p), ("d_qstats", C.c_void_p),
         ("d_done_count", C.c_void_p), ("h_done_flag", C.c_void_p), ("d_ktime", C.c_void_p), ("h_parents", C.c_void_p), ("done_value", C.c_uint32),
+        ("pq_nhi", C.c_uint32),
     ]
 
 
@@ -235,6 +236,19 @@ def pq_layout(chunk_off: np.ndarray, D: int, m: int):
     return psz.value, mp.value
 
 
+def pack_pivots_ragged(pivots: np.ndarray, chunk_off: np.ndarray, D: int, m: int, mp: int):
+    """(nhi, table) for the exact-size 2-float layout, or (0, None) if the chunk sizes are not 2,..,2,1,..,1."""
+    pv = np.ascontiguousarray(pivots, dtype=np.float32)
+    co = np.ascontiguousarray(chunk_off, dtype=np.uint32)
+    nhi, nfl = C.c_uint32(0), C.c_uint64(0)
+    _check(lib().bang_pack_pivots_ragged(None, _vp(co), D, m, mp, C.byref(nhi), None, C.byref(nfl)), "bang_pack_pivots_ragged")
+    if nhi.value == 0:
+        return 0, None
+    out = np.zeros(nfl.value, np.float32)
+    _check(lib().bang_pack_pivots_ragged(_vp(pv), _vp(co), D, m, mp, C.byref(nhi), _vp(out), C.byref(nfl)), "bang_pack_pivots_ragged")
+    return int(nhi.value), out
+
+
 def pack_pivots(pivots: np.ndarray, chunk_off: np.ndarray, D: int, m: int, psz: int, mp: int) -> np.ndarray:
     out = np.empty((mp, 256, psz), dtype=np.float32)
     pv = np.ascontiguousarray(pivots, dtype=np.float32)
@@ -250,7 +264,7 @@ class IterState:
     otherwise the pivot-stationary path is used when the index layout allows it."""
 
     def __init__(self, ix, queries: np.ndarray, L: int, use_lut: bool = False, dim_adjust: int = 0,
-                 device_graph: bool = False):
+                 device_graph: bool = False, ragged: bool = False):
         self.ix, self.L = ix, L
         self.Q = Q = queries.shape[0]
         self.dim_adjust = dim_adjust
@@ -268,8 +282,14 @@ class IterState:
             psz, mp = 0, ix.m
         self.psz, self.mp = psz, mp
         self.d_pivots_packed = self.d_qc = self.d_lut = None
+        self.pq_nhi = 0
+        if psz == 2 and ragged:      # exact-size table (chunks 2,..,2,1,..,1 dims wide), if the layout has that form
+            self.pq_nhi, table = pack_pivots_ragged(ix.pivots, ix.chunk_off, ix.D, ix.m, mp)
+            if self.pq_nhi:
+                self.d_pivots_packed = DeviceBuffer.from_numpy(table)
         if psz:
-            self.d_pivots_packed = DeviceBuffer.from_numpy(pack_pivots(ix.pivots, ix.chunk_off, ix.D, ix.m, psz, mp))
+            if not self.pq_nhi:
+                self.d_pivots_packed = DeviceBuffer.from_numpy(pack_pivots(ix.pivots, ix.chunk_off, ix.D, ix.m, psz, mp))
             self.d_qc = DeviceBuffer(Q * mp * psz * 4)
             _check(lib().bang_k_center_queries(C.c_void_p(self.d_queries.ptr), self.dtype_code,
                                                C.c_void_p(self.d_centroid.ptr), C.c_void_p(self.d_chunk_off.ptr),
@@ -330,6 +350,7 @@ class IterState:
         p = IterParams()
         p.Q, p.R, p.m, p.L, p.medoid, p.iter = self.Q, ix.R, ix.m, self.L, ix.medoid, self.iter
         p.psz, p.mp, p.first = self.psz, self.mp, self.first
+        p.pq_nhi = self.pq_nhi
         p.d_stage, p.d_seed, p.d_codes = self.d_stage.ptr, self.d_seed.ptr, self.d_codes.ptr
         p.d_pivots_packed = self.d_pivots_packed.ptr if self.d_pivots_packed else None
         p.d_qc = self.d_qc.ptr if self.d_qc else None

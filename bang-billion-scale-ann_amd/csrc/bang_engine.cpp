@@ -239,6 +239,10 @@ struct bang_engine {
   bool persist_on = false;             // resolved at bang_alloc: the host-paced persistent kernel is used for this allocation
   bool persist_dev = false;            // resolved at bang_alloc: device-graph mode runs as ONE self-paced persistent kernel
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
+  int pq_ragged = 1;                   // 2-float PQ layouts: exact-size pivot table where possible (0 = always the padded table)
+  uint32_t pq_nhi_avail = 0;           // resolved at load: leading 2-dim chunks of the exact-size table in d_pivots_ragged, 0 = none
+  uint32_t pq_nhi = 0;                 // resolved at bang_alloc: the table the kernels of this allocation use (0 = padded)
+  float* d_pivots_ragged = nullptr;
   int vectors_opt = -1;                // host-graph mode, where the full-precision vectors for the re-rank live: 0 = host (the walker ships
                                        // every expanded node's vector, as the reference does), 1 = a packed copy [N][vec_bytes] in HBM (the
                                        // walker ships adjacency rows only), -1 = auto (1 if the copy takes at most 40 % of the free HBM)
@@ -315,6 +319,21 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   if (e->pq_mode == 1) { psz = 0; mp = m; }
   e->psz = psz;
   e->mp = mp;
+  // 2-float layouts whose chunks are 2,..,2,1,..,1 dims wide also get the exact-size table (if a kernel instance exists for it);
+  // bang_alloc picks it when only it leaves room for the persistent kernel's merge scratch at the requested L
+  e->pq_nhi = 0; e->pq_nhi_avail = 0;
+  if (psz == 2 && e->pq_ragged) {
+    uint32_t nhi = 0;
+    uint64_t nfl = 0;
+    BANG_TRY(bang_pack_pivots_ragged(nullptr, chunk_off, D, m, mp, &nhi, nullptr, &nfl));
+    if (nhi && bang_ragged_supported(psz, mp, nhi, m)) {
+      std::vector<float> packed((size_t)nfl);
+      BANG_TRY(bang_pack_pivots_ragged(pivots, chunk_off, D, m, mp, &nhi, packed.data(), &nfl));
+      BANG_TRY(dmalloc(&e->d_pivots_ragged, packed.size()));
+      HIP_TRY(hipMemcpy(e->d_pivots_ragged, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      e->pq_nhi_avail = nhi;
+    }
+  }
   if (psz) {
     std::vector<float> packed((size_t)mp * 256 * psz);
     BANG_TRY(bang_pack_pivots(pivots, chunk_off, D, m, psz, mp, packed.data()));
@@ -376,6 +395,8 @@ void unload_index(bang_engine* e) {
   e->d_codes = nullptr;
   dfree(e->d_pivots_T);
   dfree(e->d_pivots_packed);
+  dfree(e->d_pivots_ragged);
+  e->pq_nhi = e->pq_nhi_avail = 0;
   dfree(e->d_centroid);
   dfree(e->d_chunk_off);
   dfree(e->d_seed);
@@ -505,13 +526,13 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
   const size_t q0 = ln.q0;
   memset(&p, 0, sizeof(p));
   p.Q = ln.nq; p.R = e->R; p.m = e->m; p.L = (uint32_t)e->L; p.medoid = (uint32_t)e->medoid;
-  p.psz = e->psz; p.mp = e->mp;
+  p.psz = e->psz; p.mp = e->mp; p.pq_nhi = e->pq_nhi;
   p.max_wgs = e->front_wgs;
   p.d_stage = (e->stage_mode_eff == 1) ? (e->h_stage_dev ? e->h_stage_dev + q0 * BANG_STAGE_STRIDE : nullptr)
                                         : (e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr);
   p.d_seed = e->d_seed;
   p.d_codes = e->d_codes;
-  p.d_pivots_packed = e->d_pivots_packed;
+  p.d_pivots_packed = e->pq_nhi ? e->d_pivots_ragged : e->d_pivots_packed;
   p.d_qc = e->d_qc ? e->d_qc + q0 * e->mp * e->psz : nullptr;
   p.d_lut = e->d_lut ? e->d_lut + q0 * e->m * 256 : nullptr;
   p.d_graph = (e->graph_mode == BANG_GRAPH_DEVICE) ? e->d_graph : nullptr;
@@ -1067,6 +1088,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_DEVICE")) e->device = atoi(v);
   if (const char* v = getenv("BANG_PQ")) e->pq_mode = atoi(v);
   if (const char* v = getenv("BANG_TIMING")) e->timing = atoi(v);
+  if (const char* v = getenv("BANG_PQ_RAGGED")) e->pq_ragged = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_VECTORS")) e->vectors_opt = std::min(1, std::max(-1, atoi(v)));
   *out = e;
   return BANG_OK;
@@ -1089,6 +1111,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
   else if (k == "timing") { e->timing = (int)value; }
+  else if (k == "pq_ragged") { if (e->loaded) return BANG_ERR_ARG; e->pq_ragged = value ? 1 : 0; }
   else if (k == "vectors") { if (value < -1 || value > 1 || e->loaded) return BANG_ERR_ARG; e->vectors_opt = (int)value; }
   else if (k == "stage_zero_copy") { if (value < -1 || value > 2) return BANG_ERR_ARG; e->stage_zero_copy = (int)value; }
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
@@ -1174,7 +1197,12 @@ static int alloc_buffers(bang_engine* e, int Q) {
   // (mapped-host rows need cache-bypassing loads, which are issued per lane: measured 2x slower than the per-iteration loop,
   // so "auto" takes the persistent kernel only in BAR mode)
   const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);
-  const bool persist_fits = bang_persistent_supported(e->psz, e->mp, (uint32_t)e->L) != 0;
+  e->pq_nhi = 0;
+  bool persist_fits = bang_persistent_supported(e->psz, e->mp, 0, (uint32_t)e->L) != 0;
+  if (!persist_fits && e->pq_nhi_avail && bang_persistent_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L)) {
+    persist_fits = true;                                  // only the exact-size pivot table leaves room for the merge scratch
+    e->pq_nhi = e->pq_nhi_avail;
+  }
   e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && persist_fits;
   e->persist_dev = dev_graph && e->persistent != 0 && persist_fits;
   e->fp_direct = false;

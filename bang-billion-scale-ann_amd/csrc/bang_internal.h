@@ -37,7 +37,9 @@ int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint3
                              unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_uncached, void* stream);
 int bang_num_cus(void);
 // 1 if the persistent search kernel can run this PQ layout at worklist length L with all its waves (LDS budget)
-int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t L);
+int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
+// 1 if the fused kernel has an instance for the exact-size ("ragged") pivot table of this layout
+int bang_ragged_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t m);
 
 #ifdef __cplusplus
 }

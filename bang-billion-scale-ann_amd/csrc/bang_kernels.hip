@@ -72,10 +72,27 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of
 // s_l = (((0 + t_l) + t_{l+8}) + ...), then ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)).
 // t_c = LUT[c][code_c] is recomputed as the fmaf chain of populate_pqDist_par (:1118-1128);
 // zero padding of a chunk to PSZ dims adds fmaf(0,0,t) == t, i.e. nothing.
-template <int PSZ>
+// NHI > 0 (PSZ == 2 only): exact-size table -- chunks [0, NHI) hold 2 floats per entry, the rest 1.  A 1-dim chunk skips the
+// second term, which is what the padded table computes for it (fmaf(0, 0, t) == t).  NHI is a template parameter so that every
+// entry address stays "code * size + immediate" (a runtime split costs an address register per chunk: measured as 100-200
+// spilled VGPRs in every 2-float instance).
+template <int PSZ, int NHI>
 __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, cfloat_p qc, uint32_t c, uint32_t code) {
-  const float* e = piv_lds + ((size_t)c * 256 + code) * PSZ;
   float t = 0.0f;
+  if (PSZ == 2 && NHI > 0) {
+    if (c < (uint32_t)NHI) {
+      const float2 p = *(const float2*)(piv_lds + c * 512u + code * 2u);
+      const float d0 = p.x - qc[c * 2 + 0];
+      t = __builtin_fmaf(d0, d0, t);
+      const float d1 = p.y - qc[c * 2 + 1];
+      t = __builtin_fmaf(d1, d1, t);
+    } else {
+      const float d0 = piv_lds[(uint32_t)NHI * 256u + c * 256u + code] - qc[c * 2 + 0];
+      t = __builtin_fmaf(d0, d0, t);
+    }
+    return t;
+  }
+  const float* e = piv_lds + ((size_t)c * 256 + code) * PSZ;
   if (PSZ == 1) {
     const float d = e[0] - qc[c];
     t = __builtin_fmaf(d, d, t);
@@ -130,7 +147,7 @@ __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_
   r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
 }
 
-template <int PSZ, int NDW, bool ALIGNED>
+template <int PSZ, int NDW, bool ALIGNED, int NHI>
 __device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds,
                                                cfloat_p qc) {
   float s[8];
@@ -143,7 +160,7 @@ __device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, con
     for (int b = 0; b < 4; ++b) {
       const uint32_t c = 4 * k + b;
       const uint32_t code = (dw >> (8 * b)) & 0xffu;
-      const float t = lut_entry<PSZ>(piv_lds, qc, c, code);
+      const float t = lut_entry<PSZ, NHI>(piv_lds, qc, c, code);
       s[c & 7] = s[c & 7] + t;
     }
   }
@@ -398,7 +415,7 @@ struct FrontArgs {
 // filter words -> code rows, ~2 us each) with at most 16 waves per CU (the pivot table owns the LDS), so every
 // phase is executed for NQW independent queries back to back: their loads are in flight together and the wave
 // pays each round trip once per NQW queries.
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST, int NHI>
 __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_iter_params& p = a.p;
@@ -647,7 +664,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
           }
           cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q[u] * (NDW * 4 * PSZ));
           if ((uint32_t)lane < n[u]) {
-            float d = pq_row_reduce<PSZ, NDW, ALIGNED>(rows[u & 1], piv_lds, qc);
+            float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI>(rows[u & 1], piv_lds, qc);
             if (a.debug & 2u) d = (float)sid0[u];
             d0[u] = d;
           }
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
             if (lane == 0) {
               PqRow<NDW, ALIGNED> r1;
               pq_row_load(r1, p.d_codes, p.m, sid1[u]);
-              d1[u] = pq_row_reduce<PSZ, NDW, ALIGNED>(r1, piv_lds, qc);
+              d1[u] = pq_row_reduce<PSZ, NDW, ALIGNED, NHI>(r1, piv_lds, qc);
             }
           }
         }
@@ -1081,6 +1098,40 @@ extern "C" int bang_pq_layout(const uint32_t* chunk_off, uint32_t D, uint32_t m,
   return BANG_OK;                                     // too many chunks for LDS: LUT path
 }
 
+// floats of the packed pivot table (multiple of 4: it is staged into LDS with 16-byte copies)
+static uint32_t pivot_table_floats(uint32_t psz, uint32_t mp, uint32_t nhi) {
+  if (psz == 2 && nhi != 0) return ((nhi * 512u + (mp - nhi) * 256u + 3u) & ~3u) + 4u;
+  return mp * 256u * psz;
+}
+
+extern "C" int bang_pack_pivots_ragged(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t mp,
+                                       uint32_t* nhi_out, float* out, uint64_t* floats_out) {
+  if (!chunk_off || !nhi_out || m == 0 || mp < m) return BANG_ERR_ARG;
+  *nhi_out = 0;
+  if (floats_out) *floats_out = 0;
+  uint32_t nhi = 0;
+  while (nhi < m && chunk_off[nhi + 1] - chunk_off[nhi] == 2) ++nhi;
+  if (nhi == 0 || nhi == m) return BANG_OK;                          // no 2-dim prefix, or nothing to save
+  for (uint32_t c = nhi; c < m; ++c)
+    if (chunk_off[c + 1] - chunk_off[c] > 1) return BANG_OK;       // not of the form 2,..,2,1,..,1
+  const uint32_t total = pivot_table_floats(2, mp, nhi);
+  *nhi_out = nhi;
+  if (floats_out) *floats_out = total;
+  if (!out) return BANG_OK;
+  if (!pivots) return BANG_ERR_ARG;
+  for (uint32_t i = 0; i < total; ++i) out[i] = 0.0f;
+  for (uint32_t c = 0; c < m; ++c) {
+    const uint32_t sz = chunk_off[c + 1] - chunk_off[c];
+    const size_t base = c < nhi ? (size_t)c * 512 : (size_t)nhi * 256 + (size_t)c * 256;
+    for (uint32_t code = 0; code < 256; ++code)
+      for (uint32_t i = 0; i < sz; ++i) {
+        const uint32_t j = chunk_off[c] + i;
+        if (j < D) out[base + (size_t)code * (c < nhi ? 2 : 1) + i] = pivots[(size_t)code * D + j];
+      }
+  }
+  return BANG_OK;
+}
+
 extern "C" int bang_pack_pivots(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t psz,
                                 uint32_t mp, float* out) {
   if (!pivots || !chunk_off || !out || psz == 0 || mp < m) return BANG_ERR_ARG;
@@ -1136,15 +1187,15 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
   });
 }
 
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST = false>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST = false, int NHI = 0>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST>,
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
@@ -1152,6 +1203,19 @@ static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t l
 // nqw: queries in flight per wave (1, 2 or 4 compiled); block.x <= 512 selects the 256-VGPR build
 template <int PSZ, int NDW>
 static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  if (a.p.pq_nhi) {
+    // exact-size pivot table: compiled for the two layouts of the BASELINE configs (128 dims in 70 chunks: 58 x 2 + 12 x 1;
+    // 96 dims in 74 chunks: 22 x 2 + 52 x 1), production (ALL) form only, rows of 70 / 74 bytes are never dword aligned
+    constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
+    if constexpr (NHI != 0) {
+      if ((int)a.p.pq_nhi == NHI && !aligned && a.stages == 7u) {
+        if (a.persist) return launch_front_inst<PSZ, NDW, false, true, 4, 512, true, NHI>(a, grid, block, lds, st);
+        return launch_front_inst<PSZ, NDW, false, true, 4, 512, false, NHI>(a, grid, block, lds, st);
+      }
+    }
+    bang_set_error("no kernel instance for the exact-size pivot table psz=%u mp=%u nhi=%u", a.p.psz, a.p.mp, a.p.pq_nhi);
+    return BANG_ERR_UNSUPPORTED;
+  }
   if (a.persist) {
     // persistent search kernel: 16 waves x 1 query each (128-VGPR build); for the SIFT1M-like layout 8 waves x 4 queries in
     // flight (the 256-VGPR build) was measured slower (front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us).
@@ -1227,7 +1291,8 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
     if (!x.d_bloom) x.d_bloom = x.d_nbrs;
   }
   const bool need_piv = (p->psz != 0) && (stages & 2u);
-  a.lds_piv_floats = need_piv ? p->mp * 256u * p->psz : 0u;
+  if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
+  a.lds_piv_floats = need_piv ? pivot_table_floats(p->psz, p->mp, p->pq_nhi) : 0u;
   const size_t piv_bytes = (size_t)a.lds_piv_floats * 4;
   const size_t lds_cap = 160 * 1024;
   // One workgroup per CU at most (the pivot table takes most of the LDS); a lane that shares the GPU
@@ -1248,6 +1313,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   int nqw = (stages != 7u) ? 1 : (pa ? (heavy ? 4 : 1) : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1)));
   nqw = (nqw >= 2) ? 4 : 1;
   int max_waves = (env_waves > 0 && !pa) ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
+  if (p->pq_nhi) { nqw = 4; if (max_waves > 8) max_waves = 8; }      // the exact-size instances are 8 waves x 4 queries in flight
   if (max_waves > 16) max_waves = 16;
   int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;
@@ -1306,12 +1372,17 @@ extern "C" int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter
 }
 extern "C" int bang_num_cus(void) { return num_cus(); }
 
+// Is there a kernel instance for the exact-size pivot table of this layout (see launch_front_al)?
+extern "C" int bang_ragged_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t m) {
+  return (psz == 2 && (m & 3u) != 0 && ((mp == 72 && nhi == 58) || (mp == 76 && nhi == 22))) ? 1 : 0;
+}
+
 // Does the persistent search kernel have room for enough waves (pivot table + per-wave front/merge scratch within 160 KB of
 // LDS) for this PQ layout and worklist length?  Mirrors the launcher's arithmetic.
-extern "C" int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t L) {
+extern "C" int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
   const bool heavy = psz != 0 && psz * (mp / 4u) > 32u;
   const uint32_t nqw = heavy ? 4u : 1u, waves = heavy ? 6u : 12u;      // at least three quarters of the waves must fit
-  const size_t piv_bytes = (size_t)mp * 256u * psz * 4u;
+  const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
   const size_t per_wave = (size_t)std::max<uint32_t>(FRONT_SCRATCH_WORDS * nqw, back_view_words(L)) * 4u;
   return piv_bytes + 16 + waves * per_wave <= (size_t)160 * 1024 ? 1 : 0;
 }

@@ -151,6 +151,13 @@ int bang_pq_layout(const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t* 
  * out holds mp*256*psz floats. */
 int bang_pack_pivots(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t psz,
                      uint32_t mp, float* out);
+/* Exact-size table for layouts whose chunks have 2 dims first and then 1 (DiskANN's split when D/m is between 1 and 2, e.g.
+ * 128 dims in 70 chunks, 96 in 74): [nhi][256][2] f32 followed by [mp - nhi][256][1], zero entries for the padding chunks, rounded up
+ * to a multiple of 4 floats plus 4 (the kernel reads one float past a 1-dim entry).  *nhi_out = 0 and nothing is written if the
+ * layout is not of that form.  out may be NULL to query the size.  256*D floats instead of 512*mp: 96 KB instead of 152 KB of LDS for
+ * DEEP100M's layout, 128 KB instead of 144 KB for SIFT1B's. */
+int bang_pack_pivots_ragged(const float* pivots, const uint32_t* chunk_off, uint32_t D, uint32_t m, uint32_t mp, uint32_t* nhi_out,
+                            float* out, uint64_t* floats_out);
 
 /* Centred queries in the same padded layout: d_qc[q][c*psz + i] = float(query[j]) - centroid[j],
  * j = chunk_off[c] + i (0 in the padding and beyond D - dim_adjust).  First half of
@@ -178,7 +185,7 @@ typedef struct {
   const uint32_t* d_stage;             /* [Q][BANG_STAGE_STRIDE] staged adjacency {count, ids} (first==0) */
   const uint32_t* d_seed;              /* [1 + R+1] {count, MEDOID, adj(MEDOID)...}  (first==1) */
   const uint8_t* d_codes;              /* [N][m] + 256 B slack */
-  const float* d_pivots_packed;        /* [mp][256][psz]                        (psz != 0) */
+  const float* d_pivots_packed;        /* [mp][256][psz] (psz != 0); with pq_nhi != 0 (psz == 2): [pq_nhi][256][2] then [mp - pq_nhi][256][1] */
   const float* d_qc;                   /* [Q][mp*psz]                           (psz != 0) */
   const float* d_lut;                  /* [Q][m][256]                           (psz == 0) */
   /* graph-on-device mode: adjacency read by the kernel itself from d_graph via d_parents */
@@ -209,6 +216,8 @@ typedef struct {
   unsigned long long* d_ktime;         /* [gridDim.x][2] per-workgroup {start,end} s_memrealtime stamps (100 MHz) of this launch, or NULL */
   uint32_t* h_parents;                 /* mapped pinned [Q]: the last workgroup copies d_parents there (coalesced) before the flag */
   uint32_t done_value;
+  uint32_t pq_nhi;                     /* psz == 2 only: exact-size ("ragged") pivot table -- the first pq_nhi chunks have 2 dims, the rest 1
+                                          (bang_pack_pivots_ragged); 0 = every chunk padded to psz floats (bang_pack_pivots) */
 } bang_iter_params;
 
 /* Fused K5 + K2 + K4: neighbor_filtering_new (bang_search.cu:1140-1165) -> compute_neighborDist_par

@@ -164,6 +164,21 @@ def test_engine_device_loop_variants_match_oracle(request, libbang, fixture, per
     assert st["persistent"] in (0, persistent)          # PQ layouts that need the 256-VGPR build keep the launch-per-iteration loop
 
 
+@pytest.mark.parametrize("fixture,L", [("small_u8", 40), ("small_u8", 256), ("small_deep", 40), ("small_deep", 200)])
+@pytest.mark.parametrize("graph", [0, 1])
+def test_engine_long_worklists_and_exact_size_pivot_table(request, libbang, fixture, L, graph):
+    """The persistent kernel keeps the pivot table and every wave's merge scratch in LDS: at large L (or for the 152 KB padded
+    table of the 96-dims-in-74-chunks layout at any L) the engine switches to the exact-size table; results do not change."""
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, L)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=graph)
+    assert np.array_equal(ids, ids_o)
+    assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    ids2, dists2, _ = _run_engine(ix, q, 10, L, graph=graph, pq_ragged=0, persistent=0)
+    assert np.array_equal(ids, ids2) and np.array_equal(dists.view(np.uint32), dists2.view(np.uint32))
+
+
 def test_query_smaller_than_allocation(request, libbang, small_f32):
     """bang_alloc(Q) then bang_query on fewer queries (the vector log and the rank-major distance matrix re-stride)."""
     import bang_amd

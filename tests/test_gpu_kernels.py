@@ -150,3 +150,30 @@ def test_pqdist_float_order_is_canonical(libbang, small_u8):
                 acc = np.float32(acc + lut[c, row[c]])
             naive_differs += int(acc != want[j])
     assert naive_differs > 0
+
+
+@pytest.mark.parametrize("fixture,nhi", [("small_u8", 58), ("small_deep", 22)])
+def test_exact_size_pivot_table_gives_the_same_distances(request, libbang, fixture, nhi):
+    """PQ layouts with 2-dim then 1-dim chunks (128 dims in 70 chunks, 96 in 74): the fused kernel's instance for the
+    exact-size ("ragged") pivot table [nhi][256][2] + [m-nhi][256][1] must reproduce the padded table's -- i.e. the
+    oracle's -- distances bit for bit."""
+    from bang_amd.binding import IterState
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    orc = O.Oracle(ix)
+    rng = np.random.default_rng(7)
+    lists = [rng.choice(ix.N, 64, replace=False).astype(np.uint32) for _ in range(8)]
+    got = {}
+    for ragged in (False, True):
+        st = IterState(ix, q[:8], 16, ragged=ragged)
+        assert st.pq_nhi == (nhi if ragged else 0)
+        st.first, st.iter = 0, 2
+        st.stage(lists)
+        st.run("front")
+        got[ragged] = st.nbrs()
+    for a, b in zip(got[False], got[True]):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    cnt, ids, dist = got[True]
+    for i in range(8):
+        want = orc.pqdist(orc.lut_build(q[i]), ids[i, :cnt[i]])
+        assert np.array_equal(dist[i, :cnt[i]].view(np.uint32), want.view(np.uint32))
