@@ -62,6 +62,23 @@ if stats:
               f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
     print()
 
+# the timed steps alone: the last `steps` dispatches of the front/search kernel in the kernel trace (bench.py runs an L sweep
+# and warm-up launches of the same kernel first, which the per-kernel average above also contains)
+timed_avg_us = None
+ktrace = find("trace/**/*kernel_trace.csv")
+steps = ((bench.get("trace") or {}).get("steps")) or 0
+if ktrace and steps:
+    rows = [r for r in csv.DictReader(open(ktrace)) if "front_kernel" in r.get("Kernel_Name", "")]
+    persistent_run = "PERSIST" in str(((bench.get("trace") or {}).get("roofline") or {}).get("kernel", ""))
+    if rows and persistent_run:
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        last = rows[-steps:]
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
+        timed_avg_us = sum(durs) / len(durs)
+        print(f"search kernel, the {steps} timed launches only (kernel trace): avg {timed_avg_us:.1f} us "
+              f"(min {min(durs):.1f}, max {max(durs):.1f}); bench.py's in-kernel timer for the same launches: "
+              f"{((bench.get('trace') or {}).get('roofline') or {}).get('avg_launch_us')} us\n")
+
 per = {}
 for t, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = find(f"{t}/**/*counter_collection.csv")
@@ -95,7 +112,8 @@ if tag and per:
           "fetch_bytes_per_launch_raw": round(fetch), "fetch_bytes_per_launch_x2_upper_bound": round(2 * fetch),
           "write_bytes_per_launch": round(write),
           "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
-          "rocprof_front_kernel_avg_us": front_avg_us, "bench_in_kernel_timer_avg_us": rf.get("avg_launch_us"),
+          "rocprof_front_kernel_avg_us": front_avg_us, "rocprof_timed_launches_avg_us": timed_avg_us,
+          "bench_in_kernel_timer_avg_us": rf.get("avg_launch_us"),
           "note": "FETCH_SIZE raw (random 64-B requests: the gfx950 x2 correction for wide coalesced reads does not apply; "
                   "uncalibrated per the guide) + WRITE_SIZE, separate --pmc passes of the same bench command"}
     os.makedirs("profiles", exist_ok=True)
