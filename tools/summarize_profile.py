@@ -85,12 +85,16 @@ for t, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     if not f:
         continue
     agg = defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") != counter:
-            continue
+    rows_c = [r for r in csv.DictReader(open(f)) if r.get("Counter_Name") == counter and short(r["Kernel_Name"])]
+    persistent_run = "PERSIST" in str(((bench.get(t) or {}).get("roofline") or {}).get("kernel", ""))
+    nsteps = ((bench.get(t) or {}).get("steps")) or 0
+    if persistent_run and nsteps:
+        # one search launch per batch: keep only the timed steps' launches (the L sweep and the warm-up come first)
+        fr = sorted((r for r in rows_c if short(r["Kernel_Name"]).startswith("front_kernel")), key=lambda r: int(r["Dispatch_Id"]))
+        drop = {id(r) for r in fr[:-nsteps]}
+        rows_c = [r for r in rows_c if id(r) not in drop]
+    for r in rows_c:
         s = short(r["Kernel_Name"])
-        if not s:
-            continue
         a = agg[s]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
