@@ -67,6 +67,29 @@ def test_pq_layout_and_pivot_packing_host_side(libbang):
     assert not packed[4:].any()
 
 
+def test_exact_size_pivot_table_host_side(libbang):
+    """bang_pack_pivots_ragged: [nhi][256][2] then [mp - nhi][256][1] floats, zero entries for the padding chunks; refused
+    (nhi = 0) for layouts that are not 2,..,2,1,..,1 dims wide."""
+    from bang_amd import binding
+    from bang_amd.synth import chunk_offsets
+    for D, m, nhi_want in ((128, 70, 58), (96, 74, 22)):
+        off = chunk_offsets(D, m)
+        piv = np.arange(256 * D, dtype=np.float32).reshape(256, D)
+        psz, mp = binding.pq_layout(off, D, m)
+        nhi, tab = binding.pack_pivots_ragged(piv, off, D, m, mp)
+        assert nhi == nhi_want and tab.size % 4 == 0 and tab.size >= nhi * 512 + (mp - nhi) * 256 + 1
+        assert tab.size * 4 < mp * 256 * psz * 4                          # smaller than the padded table
+        hi = tab[: nhi * 512].reshape(nhi, 256, 2)
+        lo = tab[nhi * 512: nhi * 512 + (mp - nhi) * 256].reshape(mp - nhi, 256)
+        for c in (0, 1, nhi - 1):
+            assert np.array_equal(hi[c], piv[:, off[c]:off[c] + 2])
+        for c in (nhi, m - 1):
+            assert np.array_equal(lo[c - nhi], piv[:, off[c]])
+        assert not lo[m - nhi:].any() and not tab[nhi * 512 + (mp - nhi) * 256:].any()
+    assert binding.pack_pivots_ragged(np.zeros((256, 128), np.float32), chunk_offsets(128, 32), 128, 32, 32) == (0, None)   # 4 dims/chunk
+    assert binding.pack_pivots_ragged(np.zeros((256, 128), np.float32), chunk_offsets(128, 64), 128, 64, 64) == (0, None)   # all 2-dim: nothing to save
+
+
 def test_no_gpu_means_error_not_fallback(libbang):
     """On a box without a HIP device every engine entry point must fail with BANG_ERR_NOGPU (-6)."""
     import bang_amd
