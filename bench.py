@@ -254,7 +254,7 @@ def main():
             achieved = evals_per_launch * bytes_per_eval / (avg_ms * 1e-3) / 1e9
             traffic = None                               # HBM bytes per launch from the committed PMC passes of this command
             tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}_{args.graph}.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and world == 1:            # the PMC passes were taken on the full single-GPU batch
                 try:
                     tj = json.load(open(tf))
                     traffic = tj.get("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch")
