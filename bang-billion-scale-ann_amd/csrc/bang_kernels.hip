@@ -583,8 +583,19 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       // CANON: every id is tested against the filter state at entry (all loads before any set)
 #pragma unroll
       for (int u = 0; u < NQW; ++u) {
+        // (the count arrives with the row: lanes past the list's end -- short adjacency lists, idle queries -- probe nothing)
+        uint32_t ci = uni(cnt_in[u]);
+        if (!have_row[u] || !valid[u]) ci = 0;
+        const uint32_t cap = p.R + first;
+        if (ci > cap) ci = cap;
+        cnt_in[u] = ci;
+      }
+#pragma unroll
+      for (int u = 0; u < NQW; ++u) {
         const uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
         h0a[u] = hash1(x0[u]); h0b[u] = hash2(x0[u]); h1a[u] = hash1(x1[u]); h1b[u] = hash2(x1[u]);
+        const bool v0 = (uint32_t)lane < cnt_in[u];
+        const bool v1 = cnt_in[u] > 64;
         if (a.debug & 8u) { w0a[u] = w0b[u] = w1a[u] = w1b[u] = 0; }
         else if (a.debug & 16u) {                     // both slots probed at once (one round trip, more sectors)
           w0a[u] = bloom[h0a[u] >> 5]; w0b[u] = bloom[h0b[u] >> 5];
@@ -592,8 +603,9 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
         } else {
           // the second slot is only probed where the first one is set: a never-seen id usually stops after one
           // probe (-25..-45 % filter sectors for one more dependent round trip; measured -4..-7 % kernel time)
-          w0a[u] = bloom[h0a[u] >> 5]; w1a[u] = bloom[h1a[u] >> 5];
-          w0b[u] = 0; w1b[u] = 0;
+          w0a[u] = 0; w1a[u] = 0; w0b[u] = 0; w1b[u] = 0;
+          if (v0) w0a[u] = bloom[h0a[u] >> 5];
+          if (v1) w1a[u] = bloom[h1a[u] >> 5];
           if ((w0a[u] >> (h0a[u] & 31)) & 1u) w0b[u] = bloom[h0b[u] >> 5];
           if ((w1a[u] >> (h1a[u] & 31)) & 1u) w1b[u] = bloom[h1b[u] >> 5];
         }
@@ -602,11 +614,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       for (int u = 0; u < NQW; ++u) {
         uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
         uint32_t* sc = scratch + u * FRONT_SCRATCH_WORDS;
-        uint32_t ci = uni(cnt_in[u]);
-        if (!have_row[u] || !valid[u]) ci = 0;
-        const uint32_t cap = p.R + first;
-        if (ci > cap) ci = cap;
-        cnt_in[u] = ci;
+        const uint32_t ci = cnt_in[u];
         // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
         const bool v0 = (uint32_t)lane < ci;
         const bool v1 = (lane == 0) && (ci > 64);
