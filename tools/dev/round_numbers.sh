@@ -18,3 +18,6 @@ BARGS="--steps 10 --warmup 3 --no-cpu-baseline" run host_vectors_shipped BANG_VE
 BARGS="--steps 10 --warmup 3 --no-cpu-baseline" run host_launch_per_iter BANG_PERSISTENT=0 BANG_VECTORS=0
 BARGS="--steps 10 --warmup 3 --no-cpu-baseline --graph device" run device_launch_per_iter BANG_PERSISTENT=0
 BARGS="--steps 5 --warmup 2 --no-cpu-baseline --workload deep100m_shape --graph device" run deep100m_shape_device X=1
+BARGS="--steps 5 --warmup 2 --no-cpu-baseline --workload deep100m_shape --graph device" run deep100m_shape_device_launch_per_iter BANG_PERSISTENT=0
+BARGS="--steps 5 --warmup 2 --no-cpu-baseline --workload sift1b_shape" run sift1b_shape_host X=1
+BARGS="--steps 5 --warmup 2 --no-cpu-baseline --workload sift1b_shape" run sift1b_shape_host_launch_per_iter BANG_PERSISTENT=0
