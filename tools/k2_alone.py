@@ -67,6 +67,9 @@ def run(N, D, m, dtype, Q=10_000, reps=20):
 
 if __name__ == "__main__":
     bang_amd.build()
-    res = [run(40_000_000, 128, 32, "uint8"), run(20_000_000, 128, 70, "uint8"), run(20_000_000, 96, 74, "float")]
+    if os.environ.get("K2_SIZE_SWEEP"):      # table size vs the 32 MB of L2 and the 256 MB Infinity Cache (m = 32: 32 B rows)
+        res = [run(n, 128, 32, "uint8") for n in (1_000_000, 3_000_000, 6_000_000, 12_000_000, 40_000_000)]
+    else:
+        res = [run(40_000_000, 128, 32, "uint8"), run(20_000_000, 128, 70, "uint8"), run(20_000_000, 96, 74, "float")]
     for r in res:
         print(json.dumps(r))
