@@ -325,6 +325,22 @@ def main():
                        "step_ms_min_max": [round(1e3 * float(times[0].min().item()), 3), round(1e3 * float(times[0].max().item()), 3)]},
             "roofline": roof, "cpu_baseline": cpu,
         }
+    # BASELINE.json configs[1] also names L = 200: the same batch at that worklist length, outside the timed region of `value`
+    at_L200 = None
+    if wl_name.startswith("sift1m") and L != 200 and world == 1 and gt_i is not None and not os.environ.get("BANG_BENCH_NO_L200"):
+        eng.free()
+        eng.set_searchparams(k, 200)
+        eng.alloc(Qr)
+        run_once(200, timed=True)
+        ts = []
+        ids200 = None
+        for _ in range(3):
+            ids200, _, el = run_once(200, timed=True)
+            ts.append(el)
+        at_L200 = {"L": 200, "queries_per_s": round(Q * len(ts) / sum(ts), 1), "ms_per_batch": round(1e3 * sum(ts) / len(ts), 3),
+                   "recall_at_10": round(recall_of(ids200), 3), "steps": len(ts)}
+        if out is not None:
+            out["config"]["at_L200"] = at_L200
     eng.free()
     eng.unload()
     eng.close()

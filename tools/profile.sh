@@ -6,6 +6,7 @@
 set -u
 TAG=${1:-r01}; TTAG=${2:-sift1m_host}; shift; shift || true
 export TMPDIR=/tmp
+export BANG_BENCH_NO_L200=1     # keep the timed steps the LAST launches of the run (tools/summarize_profile.py picks them by position)
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
