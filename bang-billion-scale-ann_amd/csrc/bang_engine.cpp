@@ -1209,6 +1209,10 @@ static int alloc_buffers(bang_engine* e, int Q) {
   if (e->persist_on || e->persist_dev) {
     const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
     e->pw_B = std::max<uint32_t>(16u, ((uint32_t)Q + cus - 1) / cus);
+    if (const char* v = getenv("BANG_PW_B")) {               // experiment knob: queries per workgroup (>= the default, so that all fit)
+      const uint32_t b = (uint32_t)atoi(v);
+      if (b > e->pw_B) e->pw_B = b;
+    }
     e->pw_G = ((uint32_t)Q + e->pw_B - 1) / e->pw_B;
   }
   HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
