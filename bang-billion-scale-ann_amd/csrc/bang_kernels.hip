@@ -612,7 +612,6 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < NQW; ++u) {
-        uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
         uint32_t* sc = scratch + u * FRONT_SCRATCH_WORDS;
         const uint32_t ci = cnt_in[u];
         // round 0: lanes 0..63 ; round 1: element 64 (only the seed list has 65 entries)
