@@ -373,6 +373,21 @@ class IterState:
         _check(getattr(lib(), "bang_k_" + entry)(C.byref(p), None), "bang_k_" + entry)
         sync()
 
+    def run_persistent(self, wg_queries: int = 16):
+        """The whole search loop in ONE self-paced launch (graph resident in HBM: needs device_graph=True).  Returns the highest
+        iteration any workgroup ran."""
+        assert self.d_graph is not None
+        self.iter, self.first = 1, 1
+        p = self.params()
+        d_abort = DeviceBuffer(8)
+        cap = self.L + EXTRA_ITERS - 1
+        _check(lib().bang_k_search_persistent(C.byref(p), cap, wg_queries, None, None, C.c_void_p(d_abort.ptr), 1, None),
+               "bang_k_search_persistent")
+        sync()
+        st = d_abort.download(np.uint32, (2,))
+        assert st[0] == 0
+        return int(st[1])
+
     def stage(self, lists):
         """Upload per-query adjacency lists (what the host walker stages every iteration)."""
         st = np.zeros((self.Q, STAGE_STRIDE), dtype=np.uint32)

@@ -24,17 +24,6 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
-// Persistent search kernel: ONE launch runs front(t) -> back(t) for t = p->iter .. iter_end.  Workgroup w owns queries
-// [w*wg_queries, (w+1)*wg_queries) and advances on its own; ceil(Q / wg_queries) workgroups, all resident (<= CU count).
-//  * host-paced (host-graph mode, d_go != NULL): before front(t) the workgroup waits until d_go[16*w] >= t (0xFFFFFFFF = stop);
-//    after front(t) it copies its parents to p->h_parents and stores t into p->h_done_flag[16*w].  rows_uncached = 1: p->d_stage
-//    is local device memory written through the BAR (plain coalesced row loads); 0: mapped host memory (cache-bypassing loads).
-//  * self-paced (graph resident in HBM, d_go == NULL, p->d_graph set): no host involvement; a workgroup leaves when none of
-//    its queries is active any more.
-// d_ktime_base: [iter_end + 1][256][4] stamps or NULL.  d_abort (2 words, zeroed, or NULL): [0] is set when a workgroup gave up
-// waiting for the host (3 s), [1] receives the highest iteration any workgroup ran.  No d_qmap.
-int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
-                             unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_uncached, void* stream);
 int bang_num_cus(void);
 // 1 if the persistent search kernel can run this PQ layout at worklist length L with all its waves (LDS budget)
 int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
