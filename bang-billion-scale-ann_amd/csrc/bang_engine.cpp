@@ -216,6 +216,7 @@ struct bang_engine {
   uint32_t* d_qstats = nullptr;        // [Q][2] per-query {survivors, fetched}
   uint8_t* d_fp = nullptr;             // [(L+50)][Q][vec_bytes] vector log (host-graph mode)
   uint8_t* h_fp = nullptr;             // pinned mirror
+  std::vector<uint8_t> h_fin;          // [Q] walker-side: query seen finished (its staged row count is already 0)
   uint32_t* h_stage = nullptr;         // pinned [Q][65]
   uint64_t* d_ids_out = nullptr;
   float* d_dists_out = nullptr;
@@ -580,6 +581,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   const bool ship_vec = !e->vec_on_device;
   uint8_t* fp_row = ship_vec ? (e->fp_direct ? e->d_fp : e->h_fp) + ((size_t)row * e->Qcur + ln.q0) * vb : nullptr;
   const uint32_t R = e->R;
+  uint8_t* fin = e->h_fin.data() + ln.q0;
   uint32_t active = 0, np = 0;
   uint64_t bytes = 0;
   const uint32_t PF = 8;                                   // software prefetch distance (entries are 388-644 B)
@@ -616,7 +618,10 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
       ++active;
       ++np;
     } else {
-      if (adjacency) srow[0] = 0;                                     // memset(numNeighbors_query) :761
+      // memset(numNeighbors_query) :761.  A finished query's count is zeroed ONCE: its staged row is never written again, and
+      // a 4-byte store per finished query, WG service and iteration is a PCIe transaction each in the tail of a search.
+      if (adjacency && !(par == BANG_NO_PARENT && fin[i])) srow[0] = 0;
+      if (par == BANG_NO_PARENT) fin[i] = 1;
       if (par == BANG_IDLE_PARENT) ++active;
     }
   }
@@ -795,6 +800,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
   if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words); ln.kt_used = 0; }   // stats not collected
+  if (e->h_fin.size() >= (size_t)ln.q0 + ln.nq) memset(e->h_fin.data() + ln.q0, 0, ln.nq);
   ln.h2d_bytes.store(0); ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
   auto t_enq = Clock::now();
 #define ENQ_BEGIN() (t_enq = Clock::now())
@@ -1261,6 +1267,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
     if (!e->vec_on_device) HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
   }
+  e->h_fin.assign((size_t)Q, 0);
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);

@@ -466,6 +466,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const uint32_t q_step = own_blk ? nwaves : total_waves;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   uint32_t n_active = 0;
+  // PERSIST: queries of this wave that have finished (no parent, no unmerged survivors -- they never change state again), bit =
+  // ordinal of the query within the wave.  Finished queries are skipped altogether: in the last third of a search most
+  // query-iterations are such.  (Waves that own more than 32 queries only track the first 32.)
+  uint32_t fin_mask = 0;
 
   // PERSIST: one launch runs iterations p.iter .. a.iter_end for the queries its waves own (static ownership: a query is
   // always handled by the same wave, so no grid-wide barrier is needed); the host paces it through `go`.
@@ -512,10 +516,16 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   for (uint32_t g0 = q_begin; g0 < q_end; g0 += q_step * NQW) {
     uint32_t q[NQW];
     bool valid[NQW];
+    const uint32_t ord0 = PERSIST ? (g0 - q_begin) / q_step : 0u;      // ordinal of the group's first query within this wave
+    if (PERSIST && ord0 + NQW <= 32u) {
+      const uint32_t grp = ((NQW == 32 ? 0u : (1u << NQW)) - 1u) << ord0;
+      if ((fin_mask & grp) == grp) continue;                            // every query of the group has finished
+    }
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
       const uint32_t slot = g0 + (uint32_t)u * q_step;
       valid[u] = slot < q_end;
+      if (PERSIST && !valid[u] && ord0 + (uint32_t)u < 32u) fin_mask |= 1u << (ord0 + (uint32_t)u);   // nothing there: "finished"
       const uint32_t s_ok = valid[u] ? slot : g0;   // invalid slots shadow slot 0: loads stay legal, every store is guarded
       q[u] = p.d_qmap ? uni(p.d_qmap[s_ok]) : s_ok;  // straggler compaction: slot -> query
     }
@@ -789,6 +799,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
           }
         }
         if (found || nn > 0) ++n_active;
+        else if (PERSIST && ord0 + (uint32_t)u < 32u && !(a.debug & 32u)) fin_mask |= 1u << (ord0 + (uint32_t)u);   // debug bit 32: no skipping
       }
     }
 
@@ -876,7 +887,8 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     // of THIS iteration; the other one is reset at the start of the next iteration, behind a workgroup barrier)
     const bool block_done = (a.go == nullptr) && (scratch_all[(size_t)nwaves * a.scratch_words + 1 + (cur_iter & 1u)] == 0u);
     if (cur_iter < a.iter_end || a.go != nullptr)
-      for (uint32_t slot = q_begin; slot < q_end; slot += q_step) {
+      for (uint32_t slot = q_begin, ord = 0; slot < q_end; slot += q_step, ++ord) {
+        if (ord < 32u && ((fin_mask >> ord) & 1u)) continue;            // finished: no survivors to merge, ever again
         // (prefetching the next query's BackIn while this one is merged was tried: the two live register sets pushed the
         // kernel into scratch spills and doubled the phase)
         BackIn in;
