@@ -128,7 +128,7 @@ struct Lane {
   int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 1 = persistent walk
   uint32_t pw_groups = 0;                        // workgroups of the running persistent kernel
   std::atomic<uint32_t> pw_max_iter{0};
-  std::atomic<uint64_t> h2d_bytes{0};
+  mutable std::atomic<uint64_t> h2d_bytes{0};   // bumped by the walker through a const Lane&
   std::atomic<int> pw_error{0};
   std::atomic<uint32_t> job_active{0}, job_parents{0};
   std::atomic<int> phase{0};          // debugging aid: what the lane thread is doing (see watchdog)
@@ -628,7 +628,7 @@ void walk_slice(bang_engine* e, const Lane& ln, uint32_t i0, uint32_t i1, uint32
   if (e->stage_mode_eff == 2) _mm_sfence();             // drain the write-combining buffers before the launch
   *n_active = active;
   *n_parents = np;
-  if (bytes) const_cast<Lane&>(ln).h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
+  if (bytes) ln.h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
 }
 
 inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
