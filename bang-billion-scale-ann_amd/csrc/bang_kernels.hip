@@ -195,8 +195,8 @@ __device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ cod
 #define BACK_WAVES 4
 #define BACK_WL_REGS (BANG_MAX_L / WAVE)   // worklist entries a lane owns: k = lane + 64 j
 #define BACK_WI_REGS 4                     // ... whose ids are kept in registers across the sort (the rest is parked in LDS)
-struct BackLds {
-  float sd[BANG_NBR_STRIDE];      // unsorted distances
+struct __attribute__((aligned(16))) BackLds {
+  float sd[BANG_NBR_STRIDE];      // unsorted distances (read 16 bytes at a time by the rank sort)
   uint32_t si[BANG_NBR_STRIDE];
   float td[BANG_NBR_STRIDE];      // sorted
   uint32_t ti[BANG_NBR_STRIDE];
@@ -238,18 +238,20 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t h
 
 // Everything back_one_query reads from global memory: depends on the query only, so a wave can have the NEXT query's loads
 // in flight while it sorts and merges the current one.
+template <int WLR>                   // WLR = worklist entries a lane may own = ceil(L / 64), rounded up to a compiled size
 struct BackIn {
   uint32_t n_raw, w_raw, mark, i_lo, i_hi;
   float d_lo, d_hi;
-  float wd_r[BACK_WL_REGS];          // short lived: parked in LDS before the sort
-  uint32_t wi_r[BACK_WL_REGS];       // ids of the worklist entries this lane owns (k = lane + 64 j); j >= BACK_WI_REGS parked in LDS
+  float wd_r[WLR];                   // short lived: parked in LDS before the sort
+  uint32_t wi_r[WLR];                // ids of the worklist entries this lane owns (k = lane + 64 j); j >= BACK_WI_REGS parked in LDS
   uint32_t wv_bits;                  // their visited flags, bit j
 };
 #define BACK_HI_AT(lane) (WAVE + ((uint32_t)(lane) & (BANG_NBR_STRIDE - WAVE - 1)))   // entries 64..71 (a row holds at most R + 1 = 65)
 
 // ONE memory round trip: every load depends on q only and is issued before the first result is used (the survivor row always
 // holds BANG_NBR_STRIDE words and the worklist arrays L words, whatever the counters say)
-__device__ __forceinline__ void back_load(const bang_iter_params& p, uint32_t q, int lane, BackIn& in) {
+template <int WLR>
+__device__ __forceinline__ void back_load(const bang_iter_params& p, uint32_t q, int lane, BackIn<WLR>& in) {
   const uint32_t L = p.L;
   const uint32_t* nbrs = p.d_nbrs + (size_t)q * BANG_NBR_STRIDE;
   const float* dist = p.d_dist + (size_t)q * BANG_NBR_STRIDE;
@@ -263,9 +265,9 @@ __device__ __forceinline__ void back_load(const bang_iter_params& p, uint32_t q,
   in.i_lo = nbrs[lane];
   in.d_hi = dist[BACK_HI_AT(lane)];
   in.i_hi = nbrs[BACK_HI_AT(lane)];
-  uint32_t vis[BACK_WL_REGS];
+  uint32_t vis[WLR];
 #pragma unroll
-  for (int j = 0; j < BACK_WL_REGS; ++j) {
+  for (int j = 0; j < WLR; ++j) {
     in.wd_r[j] = 0.0f; vis[j] = 0u;
     in.wi_r[j] = 0u;
     if ((uint32_t)j * WAVE < L) {                       // uniform: only the ceil(L / 64) entries a lane can own are loaded
@@ -277,13 +279,14 @@ __device__ __forceinline__ void back_load(const bang_iter_params& p, uint32_t q,
   }
   uint32_t bits = 0;
 #pragma unroll
-  for (int j = 0; j < BACK_WL_REGS; ++j) bits |= (vis[j] ? 1u : 0u) << j;
+  for (int j = 0; j < WLR; ++j) bits |= (vis[j] ? 1u : 0u) << j;
   in.wv_bits = bits;
 }
 
 // sort + merge of one query by one wave (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
+template <int WLR>
 __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32_t q, uint32_t iter, const BackView& s, int lane,
-                                               const BackIn& in) {
+                                               const BackIn<WLR>& in) {
   const uint32_t L = p.L;
   uint32_t* wl_ids = p.d_wl_ids + (size_t)q * L;
   float* wl_dist = p.d_wl_dist + (size_t)q * L;
@@ -298,21 +301,34 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
   s.sd[lane] = d_lo; s.si[lane] = i_lo;
   if ((uint32_t)lane < BANG_NBR_STRIDE - WAVE) { s.sd[hi_at] = d_hi; s.si[hi_at] = i_hi; }
 #pragma unroll
-  for (int j = 0; j < BACK_WL_REGS; ++j) {
+  for (int j = 0; j < WLR; ++j) {
     const uint32_t i = (uint32_t)lane + (uint32_t)j * WAVE;
     if (i < L) {
       s.wd[i] = wd_r[j];
-      if (j >= BACK_WI_REGS) s.wi_hi[i - BACK_WI_REGS * WAVE] = in.wi_r[j];
+      if (WLR > BACK_WI_REGS && j >= BACK_WI_REGS) s.wi_hi[i - BACK_WI_REGS * WAVE] = in.wi_r[j];
     }
   }
   wave_sync();
-  // K3a: stable rank sort == the reference's stable merge sort (:1553-1584)
+  // K3a: stable rank sort == the reference's stable merge sort (:1553-1584).  The distances are read eight at a time (two 16-byte
+  // LDS reads in flight instead of a chain of n dependent 4-byte ones: that chain was about half of a query's merge time); the
+  // tail of the last group is padded with +inf, which ranks behind every real distance and ties with none.
+  const uint32_t n8 = (n + 7u) & ~7u;                    // <= 72 = BANG_NBR_STRIDE
+  if ((uint32_t)lane < n8 - n) s.sd[n + lane] = __builtin_inff();
+  wave_sync();
   for (uint32_t i = lane; i < n; i += WAVE) {
     const float d = s.sd[i];
     uint32_t r = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-      const float o = s.sd[j];
-      r += (o < d || (o == d && j < i)) ? 1u : 0u;
+    for (uint32_t j = 0; j < n8; j += 8) {
+      const float4 o0 = *(const float4*)(s.sd + j);
+      const float4 o1 = *(const float4*)(s.sd + j + 4);
+      r += (o0.x < d || (o0.x == d && j + 0 < i)) ? 1u : 0u;
+      r += (o0.y < d || (o0.y == d && j + 1 < i)) ? 1u : 0u;
+      r += (o0.z < d || (o0.z == d && j + 2 < i)) ? 1u : 0u;
+      r += (o0.w < d || (o0.w == d && j + 3 < i)) ? 1u : 0u;
+      r += (o1.x < d || (o1.x == d && j + 4 < i)) ? 1u : 0u;
+      r += (o1.y < d || (o1.y == d && j + 5 < i)) ? 1u : 0u;
+      r += (o1.z < d || (o1.z == d && j + 6 < i)) ? 1u : 0u;
+      r += (o1.w < d || (o1.w == d && j + 7 < i)) ? 1u : 0u;
     }
     s.td[r] = d;
     s.ti[r] = s.si[i];
@@ -353,13 +369,13 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
       }
     }
 #pragma unroll
-    for (int j = 0; j < BACK_WL_REGS; ++j) {             // old entries: upper_bound + k :1678-1680
+    for (int j = 0; j < WLR; ++j) {             // old entries: upper_bound + k :1678-1680
       const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
       if (k < w_n) {
         const float d = s.wd[k];
         const uint32_t pos = upper_bound_lds(s.td, nb, d) + k;
         if (pos < new_n) {
-          const uint32_t id = (j < BACK_WI_REGS) ? in.wi_r[j] : s.wi_hi[k - BACK_WI_REGS * WAVE];
+          const uint32_t id = (WLR <= BACK_WI_REGS || j < BACK_WI_REGS) ? in.wi_r[j] : s.wi_hi[k - BACK_WI_REGS * WAVE];
           wl_ids[pos] = id; wl_dist[pos] = d; wl_vis[pos] = (((in.wv_bits >> j) & 1u) || id == mark) ? 1 : 0;
         }
       }
@@ -367,6 +383,46 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
   }
   if (lane == 0) p.d_wl_cnt[q] = new_n;
   wave_sync();
+}
+
+// Sort + merge of all unfinished queries a wave owns in a persistent launch.  For L <= 128 (WLR <= 2: a BackIn is a dozen
+// registers) the NEXT query's loads are in flight while the current one is sorted and merged -- two register sets, ping-pong,
+// no copies; the memory round trip (about half of a query's 4.5 us) is paid once per wave instead of once per query.
+template <int WLR>
+__device__ __forceinline__ void back_block(const bang_iter_params& p, uint32_t q_begin, uint32_t q_end, uint32_t q_step,
+                                           uint32_t fin_mask, uint32_t iter, const BackView& bv, int lane) {
+  uint32_t slot = q_begin, ord = 0;
+#define BACK_SKIP_FINISHED() while (slot < q_end && ord < 32u && ((fin_mask >> ord) & 1u)) { slot += q_step; ++ord; }
+  BACK_SKIP_FINISHED();
+  if constexpr (WLR <= 2) {
+    BackIn<WLR> A, B;
+    if (slot < q_end) back_load<WLR>(p, slot, lane, A);
+    while (slot < q_end) {
+      const uint32_t s0 = slot;
+      slot += q_step; ++ord;
+      BACK_SKIP_FINISHED();
+      const bool m1 = slot < q_end;
+      if (m1) back_load<WLR>(p, slot, lane, B);
+      back_one_query<WLR>(p, s0, iter, bv, lane, A);
+      if (!m1) break;
+      const uint32_t s1 = slot;
+      slot += q_step; ++ord;
+      BACK_SKIP_FINISHED();
+      const bool m2 = slot < q_end;
+      if (m2) back_load<WLR>(p, slot, lane, A);
+      back_one_query<WLR>(p, s1, iter, bv, lane, B);
+      if (!m2) break;
+    }
+  } else {
+    while (slot < q_end) {
+      BackIn<WLR> in;
+      back_load<WLR>(p, slot, lane, in);
+      back_one_query<WLR>(p, slot, iter, bv, lane, in);
+      slot += q_step; ++ord;
+      BACK_SKIP_FINISHED();
+    }
+  }
+#undef BACK_SKIP_FINISHED
 }
 
 __global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_params p) {
@@ -378,9 +434,9 @@ __global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_
   s.sd = b.sd; s.si = b.si; s.td = b.td; s.ti = b.ti; s.wd = b.wd; s.wi_hi = b.wi_hi;
   for (uint32_t slot = blockIdx.x * BACK_WAVES + wave; slot < p.Q; slot += gridDim.x * BACK_WAVES) {
     const uint32_t q = p.d_qmap ? uni(p.d_qmap[slot]) : slot;
-    BackIn in;
-    back_load(p, q, lane, in);
-    back_one_query(p, q, p.iter, s, lane, in);
+    BackIn<BACK_WL_REGS> in;
+    back_load<BACK_WL_REGS>(p, q, lane, in);
+    back_one_query<BACK_WL_REGS>(p, q, p.iter, s, lane, in);
   }
 }
 
@@ -887,14 +943,12 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     // of THIS iteration; the other one is reset at the start of the next iteration, behind a workgroup barrier)
     const bool block_done = (a.go == nullptr) && (scratch_all[(size_t)nwaves * a.scratch_words + 1 + (cur_iter & 1u)] == 0u);
     if (cur_iter < a.iter_end || a.go != nullptr)
-      for (uint32_t slot = q_begin, ord = 0; slot < q_end; slot += q_step, ++ord) {
-        if (ord < 32u && ((fin_mask >> ord) & 1u)) continue;            // finished: no survivors to merge, ever again
-        // (prefetching the next query's BackIn while this one is merged was tried: the two live register sets pushed the
-        // kernel into scratch spills and doubled the phase)
-        BackIn in;
-        back_load(p, slot, lane, in);
-        back_one_query(p, slot, cur_iter, bv, lane, in);
-      }
+    {
+      const uint32_t wlr = (L + WAVE - 1) / WAVE;                        // uniform: pick the compiled BackIn size
+      if (wlr <= 2) back_block<2>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+      else if (wlr <= 4) back_block<4>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+      else back_block<BACK_WL_REGS>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+    }
     n_active = 0;
     if (a.ktime_base) {
       __syncthreads();
