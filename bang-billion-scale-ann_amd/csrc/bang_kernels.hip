@@ -386,15 +386,15 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
 }
 
 // Sort + merge of all unfinished queries a wave owns in a persistent launch.  For L <= 128 (WLR <= 2: a BackIn is a dozen
-// registers) the NEXT query's loads are in flight while the current one is sorted and merged -- two register sets, ping-pong,
+// registers; L <= 256 in the 256-VGPR builds) the NEXT query's loads are in flight while the current one is sorted and merged -- two register sets, ping-pong,
 // no copies; the memory round trip (about half of a query's 4.5 us) is paid once per wave instead of once per query.
-template <int WLR>
+template <int WLR, bool BIGREGS>      // BIGREGS: the 256-VGPR builds can afford two register sets up to L = 256
 __device__ __forceinline__ void back_block(const bang_iter_params& p, uint32_t q_begin, uint32_t q_end, uint32_t q_step,
                                            uint32_t fin_mask, uint32_t iter, const BackView& bv, int lane) {
   uint32_t slot = q_begin, ord = 0;
 #define BACK_SKIP_FINISHED() while (slot < q_end && ord < 32u && ((fin_mask >> ord) & 1u)) { slot += q_step; ++ord; }
   BACK_SKIP_FINISHED();
-  if constexpr (WLR <= 2) {
+  if constexpr (WLR <= 2 || (BIGREGS && WLR <= 4)) {
     BackIn<WLR> A, B;
     if (slot < q_end) back_load<WLR>(p, slot, lane, A);
     while (slot < q_end) {
@@ -945,9 +945,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     if (cur_iter < a.iter_end || a.go != nullptr)
     {
       const uint32_t wlr = (L + WAVE - 1) / WAVE;                        // uniform: pick the compiled BackIn size
-      if (wlr <= 2) back_block<2>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
-      else if (wlr <= 4) back_block<4>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
-      else back_block<BACK_WL_REGS>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+      constexpr bool BIG = (MAXT <= 512);
+      if (wlr <= 2) back_block<2, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+      else if (wlr <= 4) back_block<4, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
+      else back_block<BACK_WL_REGS, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
     }
     n_active = 0;
     if (a.ktime_base) {
