@@ -1007,6 +1007,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
   if (pw_stats[0]) { bang_set_error("persistent search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
+  if ((persist || e->persist_dev) && getenv("BANG_PHASE_PROBE")) {   // diagnostic build (-DBANG_PHASE_PROBE) only: d_pcnt[4..11]
+    uint32_t pr[8] = {0};
+    (void)hipMemcpy(pr, ln.d_pcnt + 4, sizeof(pr), hipMemcpyDeviceToHost);
+    if (pr[7]) fprintf(stderr, "[bang] phase probe, wave 0 of workgroup 0, %u query-iterations: A %.2f us, filter %.2f, distances %.2f, parent %.2f, ORs %.2f\n",
+                       pr[7], pr[0] * 0.01 / pr[7], pr[1] * 0.01 / pr[7], pr[2] * 0.01 / pr[7], pr[3] * 0.01 / pr[7], pr[4] * 0.01 / pr[7]);
+  }
   if (e->persist_dev && pw_stats[1]) ln.iterations = pw_stats[1];
   DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats

@@ -464,6 +464,21 @@ struct FrontArgs {
 
 // per-wave LDS scratch (uint32 words): compacted ids [0..71]
 #define FRONT_SCRATCH_WORDS 72
+// -DBANG_PHASE_PROBE: diagnostic build -- wave 0 of workgroup 0 drains its memory queue at every phase boundary of the front
+// loop and accumulates the phase durations (100 MHz ticks) into d_abort[4 + k]; serialises that wave, never used in production.
+#ifdef BANG_PHASE_PROBE
+#define PHASE_PROBE(k)                                                                                  \
+  do {                                                                                                  \
+    if (PERSIST && blockIdx.x == 0 && wave == 0) {                                                      \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
+      const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();                                \
+      probe_acc[k] += (uint32_t)(t_now - probe_t);                                                      \
+      probe_t = t_now;                                                                                  \
+    }                                                                                                   \
+  } while (0)
+#else
+#define PHASE_PROBE(k) do {} while (0)
+#endif
 
 // ALL = true: the production instantiation (filter + distance + parent, no stage branches).  ALL = false:
 // stage mask taken from a.stages (kernel-level parity tests).
@@ -526,6 +541,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // ordinal of the query within the wave.  Finished queries are skipped altogether: in the last third of a search most
   // query-iterations are such.  (Waves that own more than 32 queries only track the first 32.)
   uint32_t fin_mask = 0;
+#ifdef BANG_PHASE_PROBE
+  uint32_t probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long probe_t = 0;
+#endif
 
   // PERSIST: one launch runs iterations p.iter .. a.iter_end for the queries its waves own (static ownership: a query is
   // always handled by the same wave, so no grid-wide barrier is needed); the host paces it through `go`.
@@ -564,6 +583,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#ifdef BANG_PHASE_PROBE
+    if (*s_go == BANG_GO_STOP && a.abort_flag && blockIdx.x == 0 && threadIdx.x == 0)
+      for (int k = 0; k < 8; ++k) a.abort_flag[4 + k] = probe_acc[k];
+#endif
     if (*s_go == BANG_GO_STOP) break;
     if (a.ktime_base && threadIdx.x == 0)
       a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4] = __builtin_amdgcn_s_memrealtime();
@@ -586,6 +609,9 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       q[u] = p.d_qmap ? uni(p.d_qmap[s_ok]) : s_ok;  // straggler compaction: slot -> query
     }
 
+#ifdef BANG_PHASE_PROBE
+    if (PERSIST && blockIdx.x == 0 && wave == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); probe_t = __builtin_amdgcn_s_memrealtime(); probe_acc[7] += 1; }
+#endif
     // ---- round trip A: every load that does not depend on another load of the query, issued
     // unconditionally (the launcher guarantees all pointers are valid).  The worklist head needed by K4 is
     // prefetched speculatively: the arrays always hold L valid words.
@@ -636,6 +662,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       if (p.d_qstats && lane == 0) qs[u] = *(const uint2*)(p.d_qstats + (size_t)q[u] * 2);
     }
 
+    PHASE_PROBE(0);   // A: row, worklist head, counters
     uint32_t n[NQW], sid0[NQW], sid1[NQW];   // survivors; lane's survivor id; survivor 64 (lane 0 only)
     uint32_t h0a[NQW], h0b[NQW], h1a[NQW], h1b[NQW];   // filter slots of the lane's id / of element 64
     bool set0[NQW], set1[NQW];                        // slots to set once the query's loads have been issued
@@ -721,6 +748,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
     }
 
+    PHASE_PROBE(1);   // B + B': filter probes, compaction, survivor stores issued
     // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
     float d0[NQW], d1[NQW];
 #pragma unroll
@@ -774,6 +802,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
     }
 
+    PHASE_PROBE(2);   // C: code rows + LDS reduce + distance stores
     // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ------
     if (do_parent) {
 #pragma unroll
@@ -859,6 +888,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
     }
 
+    PHASE_PROBE(3);   // K4: parent selection + its stores
     // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
     // Issued LAST: vmcnt retires in order, so anything issued after an atomic waits for it (2-3 us under load);
     // here the ORs are fire-and-forget and overlap the next queries' first round trip.  A query's filter is touched by
@@ -871,6 +901,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
         if (set1[u]) { bloom_set(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); bloom_set(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
       }
     }
+    PHASE_PROBE(4);   // the filter's ORs, drained
   }
 
   // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
@@ -957,6 +988,10 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
     if (block_done || cur_iter == a.iter_end) {
       if (a.abort_flag && threadIdx.x == 0) atomicMax(a.abort_flag + 1, cur_iter);   // statistics: iterations of the slowest block
+#ifdef BANG_PHASE_PROBE
+      if (a.abort_flag && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k) a.abort_flag[4 + k] = probe_acc[k];
+#endif
       break;
     }
   }
