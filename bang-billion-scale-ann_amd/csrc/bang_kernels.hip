@@ -686,9 +686,11 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
 #pragma unroll
       for (int u = 0; u < NQW; ++u) {
         const uint32_t* bloom = p.d_bloom + (size_t)q[u] * BANG_BF_WORDS;
-        h0a[u] = hash1(x0[u]); h0b[u] = hash2(x0[u]); h1a[u] = hash1(x1[u]); h1b[u] = hash2(x1[u]);
         const bool v0 = (uint32_t)lane < cnt_in[u];
         const bool v1 = cnt_in[u] > 64;
+        h0a[u] = hash1(x0[u]); h0b[u] = hash2(x0[u]);
+        if (v1) { h1a[u] = hash1(x1[u]); h1b[u] = hash2(x1[u]); }   // the 65th id exists in the seed list only (uniform branch):
+                                                                 // two 64-bit multiply-and-modulo hashes less per lane otherwise
         if (a.debug & 8u) { w0a[u] = w0b[u] = w1a[u] = w1b[u] = 0; }
         else if (a.debug & 16u) {                     // both slots probed at once (one round trip, more sectors)
           w0a[u] = bloom[h0a[u] >> 5]; w0b[u] = bloom[h0b[u] >> 5];
