@@ -129,6 +129,8 @@ struct Lane {
   int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 1 = persistent walk
   uint32_t pw_groups = 0;                        // workgroups of the running persistent kernel
   std::atomic<uint32_t> pw_max_iter{0};
+  std::unique_ptr<std::atomic<uint32_t>[]> pw_expect;   // [workgroups] shared by the walker team (see pwalk)
+  std::atomic<uint32_t> pw_remaining{0};
   mutable std::atomic<uint64_t> h2d_bytes{0};   // bumped by the walker through a const Lane&
   std::atomic<int> pw_error{0};
   std::atomic<uint32_t> job_active{0}, job_parents{0};
@@ -651,32 +653,44 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
   const uint32_t G = ln.pw_groups, B = e->pw_B;
   const uint32_t w0 = (uint32_t)((uint64_t)G * (uint32_t)t / (uint32_t)T), w1 = (uint32_t)((uint64_t)G * (uint32_t)(t + 1) / (uint32_t)T);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;
-  if (w1 <= w0) return;
-  std::vector<uint32_t> expect(w1 - w0, 1u);
-  uint32_t remaining = w1 - w0, max_iter = 1;
+  constexpr uint32_t CLAIM = 0x80000000u;
+  std::atomic<uint32_t>* expect = ln.pw_expect.get();      // per workgroup: the iteration whose parents are awaited; 0 = finished;
+                                                           // | CLAIM while a thread is serving it
+  uint32_t max_iter = 1;
   volatile uint32_t* done = e->h_done;
   volatile uint32_t* go = ln.go_host;
   auto t_last = Clock::now();
   uint32_t idle = 0;
-  while (remaining) {
+  // serve workgroup w if its parents are there and nobody else has taken it
+  auto try_serve = [&](uint32_t w) -> bool {
+    uint32_t it = expect[w].load(std::memory_order_relaxed);
+    if (it == 0 || (it & CLAIM) || done[(size_t)w * 16] != it) return false;
+    if (!expect[w].compare_exchange_strong(it, it | CLAIM, std::memory_order_acquire)) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const uint32_t i0 = w * B, i1 = std::min(ln.nq, i0 + B);
+    uint32_t active = 0, np = 0;
+    walk_slice(e, ln, i0, i1, it, it < cap_iter, &active, &np);            // ends with an sfence in BAR mode
+    if (it > max_iter) max_iter = it;
+    if (it == cap_iter || active == 0) {
+      if (it < cap_iter) { go[(size_t)w * 16] = 0xFFFFFFFFu; _mm_sfence(); }
+      expect[w].store(0, std::memory_order_release);
+      ln.pw_remaining.fetch_sub(1, std::memory_order_acq_rel);
+    } else {
+      go[(size_t)w * 16] = it + 1;
+      _mm_sfence();
+      expect[w].store(it + 1, std::memory_order_release);
+    }
+    return true;
+  };
+  while (ln.pw_remaining.load(std::memory_order_acquire) != 0) {
     bool progress = false;
-    for (uint32_t w = w0; w < w1; ++w) {
-      const uint32_t it = expect[w - w0];
-      if (it == 0 || done[(size_t)w * 16] != it) continue;
-      std::atomic_thread_fence(std::memory_order_acquire);
-      progress = true;
-      const uint32_t i0 = w * B, i1 = std::min(ln.nq, i0 + B);
-      uint32_t active = 0, np = 0;
-      walk_slice(e, ln, i0, i1, it, it < cap_iter, &active, &np);          // ends with an sfence in BAR mode
-      if (it > max_iter) max_iter = it;
-      if (it == cap_iter || active == 0) {
-        if (it < cap_iter) { go[(size_t)w * 16] = 0xFFFFFFFFu; _mm_sfence(); }
-        expect[w - w0] = 0;
-        --remaining;
-      } else {
-        go[(size_t)w * 16] = it + 1;
-        _mm_sfence();
-        expect[w - w0] = it + 1;
+    for (uint32_t w = w0; w < w1; ++w) progress |= try_serve(w);
+    if (!progress) {
+      // nothing of my own is waiting: help out -- a walker thread that the OS has descheduled for a millisecond would
+      // otherwise stall its workgroups (and with them the batch) for that long
+      for (uint32_t k = 0; k + (w1 - w0) < G; ++k) {
+        const uint32_t w = (w1 + k) % G;
+        if (try_serve(w)) { progress = true; break; }
       }
     }
     if (progress) { idle = 0; continue; }
@@ -685,7 +699,7 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
       if (idle == 0x10000) t_last = Clock::now();
       else if (ms_since(t_last) > 20000.0 || ln.pw_error.load(std::memory_order_relaxed)) {
         ln.pw_error.store(1);
-        for (uint32_t w = w0; w < w1; ++w) go[(size_t)w * 16] = 0xFFFFFFFFu;
+        for (uint32_t w = 0; w < G; ++w) go[(size_t)w * 16] = 0xFFFFFFFFu;
         _mm_sfence();
         break;
       }
@@ -881,6 +895,8 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     ln.pw_groups = G;
     ln.pw_max_iter.store(1);
     ln.pw_error.store(0);
+    for (uint32_t w = 0; w < G; ++w) ln.pw_expect[w].store(1u, std::memory_order_relaxed);
+    ln.pw_remaining.store(G, std::memory_order_release);
     for (uint32_t w = 0; w < G; ++w) { e->h_done[(size_t)w * 16] = 0; ln.go_host[(size_t)w * 16] = 1; }
     _mm_sfence();
     LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
@@ -1331,6 +1347,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
     }
     if (e->persist_on) {
+      ln.pw_expect.reset(new std::atomic<uint32_t>[std::max<uint32_t>(1u, e->pw_G)]);
       const size_t go_bytes = (size_t)e->pw_G * 64;
       BANG_TRY(dmalloc(&ln.d_pcnt, 16));
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));

@@ -322,7 +322,8 @@ def main():
                        "sync_ms_per_step": round(agg["sync_ms"] / args.steps, 3),
                        "enqueue_ms_per_step": round(agg["enqueue_ms"] / args.steps, 3),
                        "dist_evals_per_step": agg["dist_evals"] // args.steps,
-                       "step_ms_min_max": [round(1e3 * float(times[0].min().item()), 3), round(1e3 * float(times[0].max().item()), 3)]},
+                       "step_ms_min_max": [round(1e3 * float(times[0].min().item()), 3), round(1e3 * float(times[0].max().item()), 3)],
+                       "step_ms": [round(1e3 * float(t), 2) for t in times[0].tolist()][:64]},
             "roofline": roof, "cpu_baseline": cpu,
         }
     # BASELINE.json configs[1] also names L = 200: the same batch at that worklist length, outside the timed region of `value`
