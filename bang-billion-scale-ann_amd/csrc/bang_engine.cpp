@@ -685,7 +685,8 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
   while (ln.pw_remaining.load(std::memory_order_acquire) != 0) {
     bool progress = false;
     for (uint32_t w = w0; w < w1; ++w) progress |= try_serve(w);
-    if (!progress) {
+    static const bool steal = !(getenv("BANG_PW_STEAL") && atoi(getenv("BANG_PW_STEAL")) == 0);
+    if (!progress && steal) {
       // nothing of my own is waiting: help out -- a walker thread that the OS has descheduled for a millisecond would
       // otherwise stall its workgroups (and with them the batch) for that long
       for (uint32_t k = 0; k + (w1 - w0) < G; ++k) {
