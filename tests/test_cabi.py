@@ -90,6 +90,23 @@ def test_exact_size_pivot_table_host_side(libbang):
     assert binding.pack_pivots_ragged(np.zeros((256, 128), np.float32), chunk_offsets(128, 64), 128, 64, 64) == (0, None)   # all 2-dim: nothing to save
 
 
+def test_persistent_kernel_lds_budget_arithmetic(libbang):
+    """bang_persistent_supported(psz, mp, nhi, L): pivot table + the waves' merge scratch must fit 160 KB of LDS with at least
+    three quarters of the waves (host-side arithmetic, mirrors the launcher)."""
+    f = libbang.bang_persistent_supported
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint32] * 4
+    assert f(4, 32, 0, 70) == 1 and f(4, 32, 0, 200) == 1          # SIFT1M layout: 128 KB table, 16 waves
+    assert f(4, 32, 0, 512) == 0                                   # maximum L: not even 12 waves fit
+    assert f(2, 72, 0, 152) == 1                                   # 128 dims in 70 chunks, padded table 144 KB, 8 waves
+    assert f(2, 76, 0, 152) == 0 and f(2, 76, 22, 152) == 1        # 96 dims in 74 chunks: only the exact-size table (96 KB) fits
+    assert f(0, 5, 0, 100) == 1                                    # LUT path: no table in LDS
+    g = libbang.bang_ragged_supported
+    g.restype = C.c_int
+    g.argtypes = [C.c_uint32] * 4
+    assert g(2, 72, 58, 70) == 1 and g(2, 76, 22, 74) == 1 and g(2, 32, 20, 30) == 0 and g(4, 32, 0, 32) == 0
+
+
 def test_no_gpu_means_error_not_fallback(libbang):
     """On a box without a HIP device every engine entry point must fail with BANG_ERR_NOGPU (-6)."""
     import bang_amd
