@@ -205,7 +205,8 @@ def read_truthset(path: str):
 SECTOR_LEN = 4096  # bang_preprocess.py:21
 
 
-def write_diskann_index(path: str, vectors: np.ndarray, degrees: np.ndarray, adjacency: np.ndarray, medoid: int) -> None:
+def write_diskann_index(path: str, vectors: np.ndarray, degrees: np.ndarray, adjacency: np.ndarray, medoid: int,
+                        pad_garbage: bool = False) -> None:
     """Write a DiskANN-style sector-padded `_disk.index` (test input for the converter).
     Sector 0 = header: {u32,u32 (skipped), u64 npts, u64 ndims, u64 medoid, u64 max_node_len, u64 nnodes_per_sector,
     3 x u64 (skipped), u64 file_size}; then ``nnodes_per_sector`` node records per 4096-byte sector, each
@@ -233,6 +234,8 @@ def write_diskann_index(path: str, vectors: np.ndarray, degrees: np.ndarray, adj
                 nb = adjacency[i, :deg].astype("<u4").copy()
                 rng.shuffle(nb)                     # DiskANN does not sort; the converter must
                 rec = vectors[i].tobytes() + struct.pack("<I", deg) + nb.tobytes()
+                if pad_garbage:
+                    rec += rng.integers(1, 2**32, R - deg, dtype=np.uint64).astype("<u4").tobytes()
                 rec += b"\0" * (node_len - len(rec))
                 buf[j * node_len:(j + 1) * node_len] = rec
             f.write(bytes(buf))

@@ -1,6 +1,8 @@
 """File formats of the path: byte-level layout and round trips."""
 import struct
 
+import pytest
+
 import numpy as np
 
 from bang_amd import formats
@@ -107,3 +109,29 @@ def test_preprocess_cli_matches_reference_usage(tmp_path, small_i8):
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(ix.N, ix.entry_len), ix.graph)
     assert formats.read_graph_metadata(str(tmp_path / "y_disk_metadata.bin"))["N"] == ix.N
     assert subprocess.run([sys.executable, "-m", "bang_amd.preprocess"], capture_output=True, env=env).returncode == 2
+
+
+@pytest.mark.parametrize("dtype,D,R,N", [("uint8", 24, 12, 130), ("int8", 16, 8, 170), ("float", 12, 8, 101)])
+def test_converter_matches_reference_preprocess(tmp_path, dtype, D, R, N):
+    """PIN: tests/golden/pre_<dtype>_disk.{bin,_metadata.bin} are the outputs of the REFERENCE's own
+    BANG_Base/bang_preprocess.py (:28-116) on pre_<dtype>_disk.index, generated by tests/golden/make_preprocess_golden.py in
+    the build container.  Our converter must reproduce both files byte for byte (ragged degrees 1..R, shuffled lists,
+    non-zero garbage behind every list, three sectors with a partly filled last one)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"pre_{dtype}")
+    out = str(tmp_path / "c_disk.bin")
+    info = formats.convert_diskann_index(gold + "_disk.index", out, D, dtype, R)
+    assert info["nodes"] == N
+    assert open(out, "rb").read() == open(gold + "_disk.bin", "rb").read()
+    assert open(str(tmp_path / "c_disk_metadata.bin"), "rb").read() == open(gold + "_disk_metadata.bin", "rb").read()
+    # and the reference's output is what the engine-side reader expects
+    md = formats.read_graph_metadata(gold + "_disk_metadata.bin")
+    assert md == dict(medoid=N // 3, entry_len=formats.entry_len(D, R, dtype), dtype_code=formats.PREPROCESS_DTYPE_CODE[dtype],
+                      D=D, R=R, N=N)
+    g = np.fromfile(gold + "_disk.bin", np.uint8).reshape(N, md["entry_len"])
+    isz = 4 if dtype == "float" else 1
+    deg = g[:, D * isz:D * isz + 4].copy().view("<u4").reshape(-1)
+    adj = g[:, D * isz + 4:].copy().view("<u4").reshape(N, R)
+    assert deg.min() == 1 and deg.max() == R
+    for i in range(N):
+        assert (np.diff(adj[i, :deg[i]].astype(np.int64)) > 0).all()          # sorted ascending by the reference (:102-104)
