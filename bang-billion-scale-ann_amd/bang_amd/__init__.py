@@ -6,5 +6,5 @@ There is no Python or CPU fallback: every compute call needs libbang.so and a HI
 """
 from .binding import (  # noqa: F401
     BangError, Engine, DeviceBuffer, IterState, lib, lib_path, build, device_count,
-    U8, I8, F32, DIST_L2, DIST_MIPS, GRAPH_HOST, GRAPH_DEVICE, DTYPE_CODE,
+    U8, I8, F32, DIST_L2, DIST_MIPS, GRAPH_HOST, GRAPH_DEVICE, GRAPH_AUTO, DTYPE_CODE,
 )

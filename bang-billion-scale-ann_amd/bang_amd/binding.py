@@ -12,7 +12,7 @@ _LIB = os.path.join(_PKG, "lib", "libbang.so")
 
 U8, I8, F32 = 0, 1, 2
 DIST_L2, DIST_MIPS = 0, 1
-GRAPH_HOST, GRAPH_DEVICE = 0, 1
+GRAPH_HOST, GRAPH_DEVICE, GRAPH_AUTO = 0, 1, 2
 DTYPE_CODE = {"uint8": U8, "int8": I8, "float": F32}
 NP_DTYPE = {"uint8": np.uint8, "int8": np.int8, "float": np.float32}
 
@@ -55,7 +55,9 @@ class Stats(C.Structure):
                 ("fetched", C.c_uint64), ("candidates", C.c_uint64), ("front_launches", C.c_uint64),
                 ("front_ms", C.c_double), ("back_ms", C.c_double), ("rerank_ms", C.c_double),
                 ("walker_ms", C.c_double), ("sync_ms", C.c_double), ("enqueue_ms", C.c_double), ("front_busy_ms", C.c_double),
-                ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64)]
+                ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64),
+                ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
+                ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64)]
 
 
 def lib_path() -> str:

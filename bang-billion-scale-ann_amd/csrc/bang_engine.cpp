@@ -164,7 +164,8 @@ struct bang_engine {
   int dtype = BANG_U8;
   size_t tsize = 1;
   // options
-  int graph_mode = BANG_GRAPH_HOST;
+  int graph_mode = BANG_GRAPH_AUTO;   // resolved to HOST / DEVICE by bang_load
+  int graph_opt = BANG_GRAPH_AUTO;    // what the caller asked for (restored by bang_unload)
   int lanes_opt = 0;      // 0 = auto
   int threads_opt = 0;    // walker threads per lane (lane thread + helpers); 0 = auto from the CPU quota
   int device = 0;
@@ -309,6 +310,18 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
     for (size_t off = 0; off < code_bytes; off += step)
       HIP_TRY(hipMemcpy(e->d_codes + off, h_codes + off, std::min(step, code_bytes - off), hipMemcpyHostToDevice));
   }
+  // Placement.  HBM left after the PQ codes decides: the whole graph (adjacency + vectors) if it fits with 16 GB to spare for
+  // the per-batch state -> no host in the loop at all; else the graph stays in host RAM (C++ walker) and, if THEY fit, a packed
+  // copy of the full-precision vectors goes to HBM for the re-rank (128 GB for 1e9 x 128 uint8 next to 70 GB of codes).
+  const size_t hbm_reserve = (size_t)16 << 30;
+  if (e->graph_mode == BANG_GRAPH_AUTO) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t gbytes = (size_t)e->N * e->entry_len + 256;
+    e->graph_mode = (gbytes + hbm_reserve <= free_b) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
+    if (getenv("BANG_DEBUG")) fprintf(stderr, "[bang] graph=auto -> %s (graph %.1f GB, free HBM %.1f GB)\n",
+                                      e->graph_mode == BANG_GRAPH_DEVICE ? "device" : "host", gbytes / 1e9, free_b / 1e9);
+  }
   // pivots: transposed [D][256] for K1 (bang_search.cu:281-285) and chunk-packed for the LDS kernel
   std::vector<float> pt((size_t)D * 256);
   for (uint32_t row = 0; row < 256; ++row)
@@ -350,6 +363,11 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   uint32_t deg;
   memcpy(&deg, me + vec_bytes(e), 4);
   if (deg > e->R) deg = e->R;
+  for (uint32_t i = 0; i < deg; ++i) {                 // cheap spot check of the adjacency layout: the medoid's neighbours
+    uint32_t nb;
+    memcpy(&nb, me + vec_bytes(e) + 4 + 4 * (size_t)i, 4);
+    if (nb >= e->N) { bang_set_error("medoid neighbour %u = %u is out of range (N = %u): wrong data type or corrupt index", i, nb, e->N); return BANG_ERR_IO; }
+  }
   std::vector<uint32_t> seed(2 + BANG_MAX_R + 1, 0);
   seed[0] = deg + 1;
   seed[1] = (uint32_t)e->medoid;
@@ -360,12 +378,13 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   HIP_TRY(hipMemcpy(e->d_medoid_vec, me, vec_bytes(e), hipMemcpyHostToDevice));
   e->vec_on_device = false;
   if (e->graph_mode != BANG_GRAPH_DEVICE && e->vectors_opt != 0) {
-    // 288 GB of HBM hold the full-precision vectors of a billion uint8 points next to their PQ codes: keep a packed copy on
-    // the device for the re-rank, so that the walker ships adjacency rows only (a third less PCIe traffic per expanded node)
+    // 288 GB of HBM hold the full-precision vectors of a billion uint8 points (128 GB) next to their PQ codes (70 GB): keep a
+    // packed copy on the device for the re-rank, so that the walker ships adjacency rows only (a third less PCIe traffic per
+    // expanded node).  "auto" = whenever the copy fits the free HBM with 16 GB to spare.
     const size_t vb = vec_bytes(e), need = (size_t)e->N * vb;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    if (e->vectors_opt == 1 || (double)need <= 0.4 * (double)free_b) {
+    if (e->vectors_opt == 1 || need + hbm_reserve <= free_b) {
       HIP_TRY(hipMalloc((void**)&e->d_vecs, need + 256));
       const size_t rows_per = std::max<size_t>(1, ((size_t)32 << 20) / vb);
       uint8_t* stage[2] = {nullptr, nullptr};
@@ -413,6 +432,7 @@ void unload_index(bang_engine* e) {
   e->graph_owned = nullptr;
   e->graph = nullptr;
   e->loaded = false;
+  e->graph_mode = e->graph_opt;
 }
 
 void stop_threads(bang_engine* e);
@@ -478,9 +498,26 @@ int load_files(bang_engine* e, const char* prefix) {
     if (!read_exact(fm, md, 32)) { bang_set_error("short metadata file"); rc = BANG_ERR_IO; break; }
     memcpy(&e->medoid, md, 8);
     memcpy(&e->entry_len, md + 8, 8);
+    int32_t md_dtype = -1;
+    memcpy(&md_dtype, md + 16, 4);
     memcpy(&e->D, md + 20, 4);
     memcpy(&e->R, md + 24, 4);
     memcpy(&e->N, md + 28, 4);
+    // The reference never looks at uDatatype (bang_search.cu:180-188) and a wrong <data type> argument makes it read vectors and
+    // adjacency lists at the wrong offsets.  bang_preprocess.py:12-13 writes 0 = int8, 1 = uint8, 2 = float: refuse an index whose
+    // code or entry length contradicts the element type of this engine.
+    {
+      static const int code_of[3] = {1 /*BANG_U8*/, 0 /*BANG_I8*/, 2 /*BANG_F32*/};
+      if (md_dtype >= 0 && md_dtype <= 2 && md_dtype != code_of[e->dtype]) {
+        printf("Error.. Index data type (%d) does not match the requested data type\n", md_dtype);
+        bang_set_error("index metadata says dtype code %d (0 int8, 1 uint8, 2 float) but the engine was created for code %d", md_dtype, code_of[e->dtype]);
+        rc = BANG_ERR_ARG; break;
+      }
+      if (e->entry_len != (uint64_t)e->D * e->tsize + 4 + 4ull * e->R) {
+        bang_set_error("index entry length %llu does not match D=%u x %zu B + 4 + 4 x R=%u", (unsigned long long)e->entry_len, e->D, e->tsize, e->R);
+        rc = BANG_ERR_IO; break;
+      }
+    }
     // compressed vectors {i32 N, i32 m, u8[N][m]} (:218-234)
     int32_t n_pts = 0, n_chunks = 0;
     if (!read_exact(fc, &n_pts, 4) || !read_exact(fc, &n_chunks, 4) || n_pts <= 0 || n_chunks <= 0) {
@@ -699,7 +736,7 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
     _mm_pause();
     if ((++idle & 0xFFFF) == 0) {
       if (idle == 0x10000) t_last = Clock::now();
-      else if (ms_since(t_last) > 20000.0 || ln.pw_error.load(std::memory_order_relaxed)) {
+      else if (ms_since(t_last) > BANG_HOST_WALK_TIMEOUT_MS || ln.pw_error.load(std::memory_order_relaxed)) {
         ln.pw_error.store(1);
         for (uint32_t w = 0; w < G; ++w) go[(size_t)w * 16] = 0xFFFFFFFFu;
         _mm_sfence();
@@ -1126,7 +1163,10 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   // defaults from the environment so that callers of the bang.h class API (no option methods,
   // e.g. the bang_search CLI) can still choose the placement: BANG_GRAPH=host|device,
   // BANG_LANES=n, BANG_DEVICE=ordinal, BANG_PQ=0|1, BANG_TIMING=0|1
-  if (const char* v = getenv("BANG_GRAPH")) e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE : BANG_GRAPH_HOST;
+  if (const char* v = getenv("BANG_GRAPH"))
+    e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE
+                  : (strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? BANG_GRAPH_AUTO : BANG_GRAPH_HOST;
+  e->graph_opt = e->graph_mode;
   if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_CHECK_EVERY")) e->check_every = std::max(1, atoi(v));
@@ -1157,7 +1197,15 @@ extern "C" int bang_destroy(bang_engine_t* e) {
 extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   if (!e || !key) return BANG_ERR_ARG;
   const std::string k(key);
-  if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE) return BANG_ERR_ARG; e->graph_mode = (int)value; }
+  // placement and layout options are consumed by bang_load, loop-shape options by bang_alloc (bang_c.h): changing them
+  // afterwards would leave buffers that do not match the option
+  if (e->loaded && (k == "graph" || k == "device" || k == "pq" || k == "pq_ragged" || k == "vectors")) {
+    bang_set_error("option %s must be set before bang_load", key); return BANG_ERR_ARG;
+  }
+  if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "timing" || k == "front_wgs")) {
+    bang_set_error("option %s must be set before bang_alloc", key); return BANG_ERR_ARG;
+  }
+  if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE && value != BANG_GRAPH_AUTO) return BANG_ERR_ARG; e->graph_mode = e->graph_opt = (int)value; }
   else if (k == "lanes") { if (value < 0 || value > 256) return BANG_ERR_ARG; e->lanes_opt = (int)value; }
   else if (k == "threads") { if (value < 0) return BANG_ERR_ARG; e->threads_opt = (int)value; }
   else if (k == "device") { e->device = (int)value; }
@@ -1244,6 +1292,20 @@ static int alloc_buffers(bang_engine* e, int Q) {
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev_id) != hipSuccess) large_bar = 0;
     e->stage_mode_eff = large_bar ? 2 : 1;
   } else e->stage_mode_eff = e->stage_zero_copy;
+  // BAR mode: the CPU writes the staged rows into device memory while kernels read them.  That is only sound on FINE-GRAINED
+  // (host-coherent) device memory: on ordinary coarse-grained memory PCIe writes do not probe the per-XCD L2, so a persistent
+  // launch (no kernel boundary between two reads of a row) could be served a stale line.  No fine-grained memory -> no BAR mode.
+  e->stage_local = false;
+  if (!dev_graph && e->stage_mode_eff == 2) {
+    if (hipExtMallocWithFlags((void**)&e->d_stage, std::max<size_t>(nq * BANG_STAGE_STRIDE * 4, 16), hipDeviceMallocFinegrained) == hipSuccess) {
+      e->stage_local = true;
+    } else {
+      (void)hipGetLastError();
+      e->d_stage = nullptr;
+      e->stage_mode_eff = 1;
+      fprintf(stderr, "[bang] fine-grained device memory unavailable: staged rows stay in mapped host memory (stage_zero_copy=1)\n");
+    }
+  }
   // persistent search kernel: host graph, in-kernel completion flags, rows readable in place (BAR or zero-copy), and room in
   // LDS for the pivot table plus the merge scratch of all waves (otherwise: the launch-per-iteration loop)
   // (mapped-host rows need cache-bypassing loads, which are issued per lane: measured 2x slower than the per-iteration loop,
@@ -1302,13 +1364,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
     HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocMapped));      // :416
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_stage_dev, e->h_stage, 0));
-    // The walker may write these rows from the CPU through the PCIe BAR (stage mode 2): ask for fine-grained
-    // (host-coherent) device memory so that visibility does not hinge on kernel-boundary L2 invalidation alone.
-    e->stage_local = true;
-    if (hipExtMallocWithFlags((void**)&e->d_stage, std::max<size_t>(nq * BANG_STAGE_STRIDE * 4, 16), hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));
-    }
+    if (!e->d_stage) BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));   // stage modes 0/1: filled by H2D copies / unused
     HIP_TRY(hipMemset(e->d_stage, 0, nq * BANG_STAGE_STRIDE * 4));
     memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
     if (!e->vec_on_device) HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
@@ -1485,6 +1541,11 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   }
   s.persistent = (e->persist_on || e->persist_dev) ? 1 : 0;
   s.vectors_on_device = e->vec_on_device ? 1 : 0;
+  s.graph_mode = (uint64_t)e->graph_mode;
+  s.lanes = (uint64_t)nl;
+  s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
+  s.wg_queries = s.persistent ? e->pw_B : 0;
+  s.workgroups = s.persistent ? ((uint32_t)Q + e->pw_B - 1) / std::max<uint32_t>(1u, e->pw_B) : 0;
   return rc;
 }
 
@@ -1570,6 +1631,10 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t c : cc) s.candidates += c;
+    std::sort(cc.begin(), cc.end());
+    s.hops_p50 = cc[cc.size() / 2];
+    s.hops_p99 = cc[std::min(cc.size() - 1, (cc.size() * 99) / 100)];
+    s.hops_max = cc.back();
   }
   *out = s;
   return BANG_OK;

@@ -24,6 +24,11 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
+// Hand-shake timeouts of the host-paced persistent kernel.  The HOST gives up first (it then stores STOP into every pacing
+// word, which ends the kernel at once); a workgroup only gives up on its own -- the host process is gone -- well after that.
+#define BANG_HOST_WALK_TIMEOUT_MS 20000.0
+#define BANG_KERNEL_GO_TIMEOUT_TICKS 3000000000ull   /* 30 s of the 100 MHz s_memrealtime clock */
+
 int bang_num_cus(void);
 // 1 if the persistent search kernel can run this PQ layout at worklist length L with all its waves (LDS budget)
 int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);

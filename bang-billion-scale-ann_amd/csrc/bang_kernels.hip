@@ -570,7 +570,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       while (v < cur_iter) {                         // BANG_GO_STOP is the largest value: it also ends the wait
         __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {      // 3 s at 100 MHz: the host is gone
+        if (__builtin_amdgcn_s_memrealtime() - t0 > BANG_KERNEL_GO_TIMEOUT_TICKS) {   // the host is gone (it gives up first, see bang_internal.h)
           v = BANG_GO_STOP;
           if (a.abort_flag) *a.abort_flag = 1u;
           break;
@@ -1168,16 +1168,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     }                                                                      \
   } while (0)
 
-static int g_num_cus = 0;
+// Per-DEVICE launcher state: one process may drive several GPUs (one engine per device), and both the CU count and the
+// dynamic-LDS attribute of a kernel instance belong to the device that is current at launch time.
+#define BANG_MAX_DEVICES 64
+static int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BANG_MAX_DEVICES) dev = 0;
+  return dev;
+}
 static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
+  static int cus[BANG_MAX_DEVICES] = {0};
+  const int dev = current_device();
+  if (cus[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
+    int n = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    cus[dev] = n > 0 ? n : 256;
   }
-  return g_num_cus;
+  return cus[dev];
 }
 
 // Supported (PSZ, NDW) instances of the LDS-resident distance kernel.  LDS need = NDW*4*256*PSZ*4 B.
@@ -1300,11 +1308,12 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
 
 template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST = false, int NHI = 0>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[BANG_MAX_DEVICES] = {false};      // per kernel instance AND device
+  const int dev = current_device();
+  if (!attr_done[dev]) {
     HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done[dev] = true;
   }
   hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());

@@ -16,6 +16,7 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -37,29 +38,36 @@ unsigned long long now_millis() {   // millisecond wall clock, as the reference 
   return (unsigned long long)duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();
 }
 
-// 10-recall@10 with distance ties counted (:43-93)
-double calculate_recall(unsigned num_queries, const unsigned* gold_std, const float* gs_dist, unsigned dim_gs,
-                        const result_ann_t* our_results, unsigned dim_or, unsigned recall_at) {
-  double total = 0;
-  std::set<unsigned> gt, res;
-  for (size_t i = 0; i < num_queries; i++) {
-    gt.clear();
-    res.clear();
-    const unsigned* gt_vec = gold_std + (size_t)dim_gs * i;
-    const result_ann_t* res_vec = our_results + (size_t)dim_or * i;
-    size_t tie_breaker = recall_at;
-    if (gs_dist != nullptr) {
-      tie_breaker = recall_at - 1;
-      const float* gt_dist_vec = gs_dist + (size_t)dim_gs * i;
-      while (tie_breaker < dim_gs && gt_dist_vec[tie_breaker] == gt_dist_vec[recall_at - 1]) tie_breaker++;
+// k-recall@k as the reference harness defines it (test_driver.cpp:43-93): per query, the ground-truth set is the first k
+// entries extended over every further entry that ties with the k-th ground-truth DISTANCE; the score is the number of
+// distinct ground-truth ids found among the k returned ids (compared as 32-bit ids); the result is the mean, in percent of k.
+double calculate_recall(unsigned num_queries, const unsigned* truth_ids, const float* truth_dists, unsigned truth_width,
+                        const result_ann_t* found, unsigned found_width, unsigned k) {
+  std::vector<unsigned> want, got;
+  double hits = 0;
+  for (size_t q = 0; q < num_queries; ++q) {
+    const unsigned* t_ids = truth_ids + q * truth_width;
+    size_t n_want = k;
+    if (truth_dists) {                                  // extend over the ties of the k-th distance
+      const float* t_d = truth_dists + q * truth_width;
+      n_want = k - 1;
+      while (n_want < truth_width && t_d[n_want] == t_d[k - 1]) ++n_want;
     }
-    gt.insert(gt_vec, gt_vec + tie_breaker);
-    for (unsigned j = 0; j < recall_at; ++j) res.insert((unsigned)res_vec[j]);
-    unsigned cur = 0;
-    for (unsigned v : gt) cur += res.count(v) ? 1 : 0;
-    total += cur;
+    want.assign(t_ids, t_ids + n_want);
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    got.resize(k);
+    for (unsigned j = 0; j < k; ++j) got[j] = (unsigned)found[q * found_width + j];
+    std::sort(got.begin(), got.end());
+    got.erase(std::unique(got.begin(), got.end()), got.end());
+    size_t a = 0, b = 0;                                // size of the intersection of two sorted id lists
+    while (a < want.size() && b < got.size()) {
+      if (want[a] < got[b]) ++a;
+      else if (got[b] < want[a]) ++b;
+      else { hits += 1; ++a; ++b; }
+    }
   }
-  return total / num_queries * (100.0 / recall_at);
+  return hits / num_queries * (100.0 / k);
 }
 
 bool file_exists(const std::string& name) {

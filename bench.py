@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- queries/sec @ 10-recall@10 >= 0.9 on a 10K-query batch (BASELINE.json metric), plus the
-roofline of the PQ-distance kernel and the CPU baseline.
+"""bench.py -- queries/sec @ 10-recall@10 >= 0.9 on a 10K-query batch (BASELINE.json metric), the roofline of the search
+kernel and of the PQ-distance stage (K2) alone, and the CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|sift1b_shape|small] [--graph host|device]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|sift1b_shape|deep100m_shape|small|tiny]
+                    [--graph host|device|auto] [--batches B] [--no-legs]
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); the 10K-query batch is split into
-contiguous shards, one per rank, each rank searches its shard on its own replica of the PQ table and
-graph, and ONE RCCL all-gather of the result ids ends the step (strong scaling: total work is fixed).
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
 
-A "step" = one bang_query over the whole batch.  bang_init (visited-filter / worklist reset) is outside
-the timed bracket, exactly as in the reference harness (BANG_Base/test_driver.cpp:432-439); the
-init-inclusive rate is reported beside it.  Every step is bracketed by barrier + cuda.synchronize on both
-sides and the MAX over ranks is taken.
+* N = 1 (the default): the workload is BASELINE.json configs[1] (SIFT1M-like, 10 000 queries) on the north-star path (graph in
+  host RAM, C++ walker).  The same JSON line carries, under `config`, the other single-GPU configurations as LEGS, each timed
+  the same way on its own index: `at_device_graph` (configs[1] with the graph in HBM), `at_L200` (configs[1]'s L = 200),
+  `at_deep100m_shape` (configs[2]) and `at_sift1b_shape` (configs[3]: the shape the target number is quoted on).
+* N > 1: the 10K-query batch is split into contiguous shards, one per rank; every rank searches its shard on its own replica of
+  the PQ table, all ranks share ONE read-only host graph, and ONE RCCL all-gather of the result ids ends the step
+  ("scaling": "strong": the total work is fixed).  `--batches B` instead streams B whole 10K batches per rank and step
+  ("scaling": "weak": throughput mode, no collective on the data path).
+
+A "step" = one bang_query over the whole batch.  bang_init (visited-filter / worklist reset) is outside the timed bracket,
+exactly as in the reference harness (BANG_Base/test_driver.cpp:432-439); the init-inclusive rate is reported beside it.  Every
+step is bracketed by barrier + cuda.synchronize on both sides and the MAX over ranks is taken.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,6 +41,7 @@ WORKLOADS = {
     "small": (100_000, 128, "uint8", 64, 32, 10_000, 64),       # quick functional run
     "tiny": (20_000, 128, "uint8", 64, 32, 1_000, 32),
 }
+ARITH_DTYPE = "f32"    # the path computes PQ sums and exact distances in float32 (u8/i8 subtract in int, accumulate in f32)
 
 
 def usable_cpus() -> int:
@@ -53,6 +62,253 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
+class Ctx:
+    """Process-wide state of a bench run."""
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------------- workloads
+def build_workload(name, ctx, Q=0, shape_n=0):
+    """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), release()."""
+    import torch
+    from bang_amd import synth
+    t0 = time.time()
+    if name.endswith("_shape"):
+        from tools import shape_workload
+        ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
+            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log)
+        rel = lambda: shape_workload.release(ix)   # noqa: E731
+    else:
+        N, D, dtype, R, m, Qd, ncl = WORKLOADS[name]
+        ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+        d_codes, shape_graph = None, "host"
+        wl_name = (f"{name}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
+                   f"Q={Q or Qd} k={ctx.k} (kNN+random-link graph, trained PQ, brute-force GT)")
+        rel = lambda: None   # noqa: E731
+    torch.cuda.synchronize()
+    log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
+    return dict(ix=ix, queries=queries, gt_i=gt_i, gt_d=gt_d, d_codes=d_codes, name=wl_name, graph=shape_graph, release=rel,
+                key=name)
+
+
+# ---------------------------------------------------------------------------------------------------------- one measurement
+def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1):
+    import bang_amd
+    gm = {"host": bang_amd.GRAPH_HOST, "device": bang_amd.GRAPH_DEVICE, "auto": bang_amd.GRAPH_AUTO}[graph]
+    eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing)
+    eng.load_index(wl["ix"], d_codes=wl["d_codes"])
+    return eng
+
+
+def run_once(eng, my_q, ctx, timed=False, gather=True):
+    import torch
+    import torch.distributed as dist
+    from bang_amd import shard
+    eng.init(my_q.shape[0])
+    if timed:
+        if ctx.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    t_a = time.perf_counter()
+    ids, dists = eng.query(my_q)
+    if ctx.world > 1 and gather:                         # the single RCCL collective of the job
+        shard.gather_ids(ids, ctx.Q_total, ctx.k, ctx.rank, ctx.world, device=ctx.cdev)
+    if timed:
+        torch.cuda.synchronize()
+        if ctx.world > 1:
+            dist.barrier()
+    return ids, dists, time.perf_counter() - t_a
+
+
+def check_properties(ix, my_q, ids, dists, k):
+    """Size-independent result properties (shape-only workloads keep their PQ codes only in HBM, so the oracle cannot run):
+    ids in range and distinct, distances ascending and equal to the exact distance of the returned id recomputed on the host."""
+    ok = True
+    isz = 4 if ix.dtype == "float" else 1
+    npd = np.float32 if ix.dtype == "float" else np.uint8
+    Qr = my_q.shape[0]
+    for qi in range(0, Qr, max(1, Qr // 256)):
+        row = ids[qi].astype(np.int64)
+        if not (row < ix.N).all():
+            return False
+        vec = np.ascontiguousarray(ix.graph[row, : ix.D * isz]).view(npd).reshape(k, ix.D).astype(np.float64)
+        ex = ((vec - my_q[qi].astype(np.float64)) ** 2).sum(axis=1)
+        dd = dists[:, qi].astype(np.float64)
+        ok &= bool(len(set(row.tolist())) == k and (np.diff(dd) >= 0).all() and np.allclose(dd, ex, rtol=1e-5))
+    return ok
+
+
+def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batches=1):
+    """Times `steps` steps of `batches` bang_query calls each at worklist length L on an allocated engine.  Returns a dict with
+    the rate, the per-step times, the engine statistics and the roofline of the search kernel."""
+    import torch
+    import torch.distributed as dist
+    ix, k = wl["ix"], ctx.k
+    Qr = my_q.shape[0]
+    for _ in range(warmup):
+        run_once(eng, my_q, ctx, timed=True)
+    step_s, init_s = [], []
+    keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
+                "workgroups", "hops_p50", "hops_p99", "hops_max")
+    agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
+               fetched=0, candidates=0, h2d_bytes=0)
+    agg.update({kk: 0 for kk in keys_max})
+    ids = dists = None
+    for _ in range(steps):
+        ti = time.perf_counter()
+        el = 0.0
+        for b in range(batches):
+            ids, dists, e1 = run_once(eng, my_q, ctx, timed=True, gather=(batches == 1))
+            el += e1
+            st = eng.stats()
+            for key in agg:
+                agg[key] = max(agg[key], st[key]) if key in keys_max else agg[key] + st[key]
+        init_s.append(time.perf_counter() - ti)
+        step_s.append(el)
+    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=ctx.cdev)
+    if ctx.world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    total = float(times[0].sum().item())
+    if ctx.world == 1:
+        n_q = Qr * batches
+    else:                                               # sharded: the ranks' shards add up to the batch; weak: a batch per rank
+        n_q = ctx.Q_total if batches == 1 else Qr * ctx.world * batches       # queries all ranks processed per step
+    res = dict(L=L, queries_per_s=round(n_q * steps / total, 1), ms_per_step=round(1e3 * total / steps, 4),
+               qps_incl_init=round(n_q * steps / float(times[1].sum().item()), 1),
+               step_ms=[round(1e3 * float(t), 2) for t in times[0].tolist()][:64], ids=ids, dists=dists, agg=agg)
+    # ---- roofline of the search kernel of this measurement
+    m = ix.m
+    bpe = m + 8                                         # SURVEY 8(d): m code bytes + 4 B id + 4 B distance per evaluation
+    roof = None
+    launches = agg["front_launches"]
+    if launches and agg["front_ms"] > 0:
+        persistent = bool(agg["persistent"])
+        evals_per_launch = agg["dist_evals"] / launches
+        avg_ms = (agg["front_busy_ms"] if persistent else agg["front_ms"]) / launches
+        achieved = evals_per_launch * bpe / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_note = None, None
+        tf = os.path.join(ROOT, "profiles", f"traffic_{traffic_key}.json") if traffic_key else None
+        if tf and os.path.exists(tf) and ctx.world == 1:
+            try:
+                tj = json.load(open(tf))
+                traffic = tj.get("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch")
+                traffic_note = (f"HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
+                                f"(profiles/traffic_{traffic_key}.json: FETCH_SIZE + WRITE_SIZE, separate passes) -- NOT re-measured in this run")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                "kernel": ("search kernel, ONE launch per batch (K5 filter + K2 PQ distance + K4 parent + K3a sort + K3b merge for every "
+                           "iteration of every query)") if persistent else "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
+                "algorithmic_bytes_per_launch": round(evals_per_launch * bpe, 1),
+                "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches, "bytes_per_distance_eval": bpe,
+                "timer": "in-kernel s_memrealtime stamps (100 MHz) on every launch of the timed steps; cross-checked against "
+                         "rocprofv3 --kernel-trace in profiles/"}
+        if traffic_note:
+            roof["traffic_note"] = traffic_note
+        if persistent and graph == "host":
+            h2d = agg["h2d_bytes"] / launches
+            roof["pcie_h2d"] = {"bytes_per_launch": int(h2d), "achieved_GBps": round(h2d / (avg_ms * 1e-3) / 1e9, 2),
+                                "note": "adjacency rows (+ vectors if shipped) the walker threads store through the PCIe BAR while the "
+                                        "kernel runs; 64-B write TLPs carry at most ~46-48 GB/s on x16 Gen5"}
+    res["roofline"] = roof
+    return res
+
+
+def leg_summary(res, wl, graph, recall=None, props=None, extra=None):
+    a = res["agg"]
+    out = {"workload": wl["name"], "graph": graph, "L": res["L"], "queries_per_s": res["queries_per_s"],
+           "ms_per_batch": res["ms_per_step"], "iterations": a["iterations"],
+           "hops_p50_p99_max": [a["hops_p50"], a["hops_p99"], a["hops_max"]],
+           "host_loop": "persistent search kernel" if a["persistent"] else "launch per iteration",
+           "rerank_vectors": ("graph entries in HBM" if graph == "device" else
+                              "packed copy in HBM" if a["vectors_on_device"] else "shipped by the walker (PCIe)"),
+           "steps": len(res["step_ms"]), "step_ms_min_max": [min(res["step_ms"]), max(res["step_ms"])]}
+    if recall is not None:
+        out["recall_at_10"] = round(recall, 3)
+    if props is not None:
+        out["result_properties_ok"] = props
+    if res["roofline"]:
+        r = res["roofline"]
+        out["roofline"] = {kk: r[kk] for kk in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "traffic") if kk in r}
+    if extra:
+        out.update(extra)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------- K2 alone
+def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, reps=5):
+    """The PQ-distance stage (K2, compute_neighborDist_par, bang_search.cu:1201-1241) ALONE: `bang_k_pqdist` over enough
+    (query, neighbour) pairs that one launch takes >= 1 ms, on a random code table far larger than the 256 MB Infinity Cache.
+    Timed with HIP events on the launch stream.  Algorithmic bytes = evaluations x (m + 8)."""
+    import torch
+    from bang_amd import binding as B
+    from bang_amd.synth import chunk_offsets
+    dev = ctx.dev
+    N = int(table_bytes // m)
+    Qk = rows_per_launch // 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for a in range(0, N * m, step):
+        b = min(N * m, a + step)
+        codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
+    codes[N * m:] = 0
+    chunk_off = chunk_offsets(D, m)
+    psz, mp = B.pq_layout(chunk_off, D, m)
+    if psz == 0:
+        return None
+    rng = np.random.default_rng(3)
+    pivots = (rng.standard_normal((256, D)) * 30).astype(np.float32)
+    nhi, table = B.pack_pivots_ragged(pivots, chunk_off, D, m, mp) if psz == 2 else (0, None)
+    if nhi and not B.lib().bang_ragged_supported(psz, mp, nhi, m):
+        nhi = 0
+    packed = torch.from_numpy(table if nhi else B.pack_pivots(pivots, chunk_off, D, m, psz, mp).reshape(-1)).to(dev)
+    nbrs = torch.zeros((Qk, B.NBR_STRIDE), dtype=torch.int32, device=dev)
+    nbrs[:, :64] = torch.randint(0, N, (Qk, 64), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    dist_o = torch.zeros((Qk, B.NBR_STRIDE), dtype=torch.float32, device=dev)
+    cnt = torch.full((Qk,), 64, dtype=torch.int32, device=dev)
+    qc = torch.randn((Qk, mp * psz), dtype=torch.float32, device=dev, generator=g)
+    seed = torch.zeros(80, dtype=torch.int32, device=dev)
+    p = B.IterParams()
+    p.Q, p.R, p.m, p.L, p.medoid, p.iter, p.first = Qk, 64, m, 16, 0, 2, 0
+    p.psz, p.mp, p.pq_nhi = psz, mp, nhi
+    p.d_codes, p.d_pivots_packed, p.d_qc = codes.data_ptr(), packed.data_ptr(), qc.data_ptr()
+    p.d_nbrs, p.d_dist, p.d_cnt, p.d_seed = nbrs.data_ptr(), dist_o.data_ptr(), cnt.data_ptr(), seed.data_ptr()
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    entry = B.lib().bang_k_pqdist if not nhi else None
+    if entry is None:
+        # the exact-size table only has the fused production instance; the stage-only entry uses the padded table
+        packed = torch.from_numpy(B.pack_pivots(pivots, chunk_off, D, m, psz, mp).reshape(-1)).to(dev)
+        p.d_pivots_packed, p.pq_nhi = packed.data_ptr(), 0
+        entry = B.lib().bang_k_pqdist
+    for _ in range(2):
+        B._check(entry(C.byref(p), sp), "bang_k_pqdist")
+    torch.cuda.synchronize()
+    us = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        B._check(entry(C.byref(p), sp), "bang_k_pqdist")
+        e1.record(stream)
+        e1.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
+    avg = float(np.mean(us))
+    evals = Qk * 64
+    ach = evals * (m + 8) / (avg * 1e-6) / 1e9
+    out = {"kernel": "front_kernel<stage = K2 only> via bang_k_pqdist", "m": m, "D": D, "psz_mp": [psz, mp],
+           "code_table_bytes": N * m, "evals_per_launch": evals, "algorithmic_bytes_per_launch": evals * (m + 8),
+           "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "achieved": round(ach, 1), "unit": "GB/s",
+           "peak": HBM_PEAK_GBPS, "frac": round(ach / HBM_PEAK_GBPS, 4), "rows_per_s": round(evals / (avg * 1e-6) / 1e9, 2),
+           "timer": "HIP events on the launch stream"}
+    del codes, nbrs, dist_o, cnt, qc, packed
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +316,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sift1m", choices=sorted(WORKLOADS) + ["sift1b_shape", "deep100m_shape"])
     ap.add_argument("--shape-n", type=int, default=0, help="override N of a *_shape workload")
-    ap.add_argument("--graph", default="", choices=["", "host", "device"],
+    ap.add_argument("--graph", default="", choices=["", "host", "device", "auto"],
                     help="host: graph in host RAM + C++ walker (BANG_Base, the north-star path); device: graph in HBM")
     ap.add_argument("--L", type=int, default=0, help="worklist length; 0 = smallest L on the harness grid with recall >= target")
     ap.add_argument("--k", type=int, default=10)
@@ -68,24 +324,28 @@ def main():
     ap.add_argument("--recall-target", type=float, default=90.0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="walker threads per lane; 0 = engine default")
+    ap.add_argument("--batches", type=int, default=1, help="N > 1 throughput mode: every rank streams this many WHOLE batches per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
-    ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events in the timed steps")
+    ap.add_argument("--no-events", action="store_true", help="do not stamp the launches of the timed steps")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx = Ctx()
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.k = k = args.k
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libbang has no CPU fallback)")
     if os.environ.get("BANG_BENCH_SHARE_GPU"):          # dry run of the N>1 logic on a 1-GPU box: every rank on device 0
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
+        ctx.local_rank = 0
+    torch.cuda.set_device(ctx.local_rank)
+    ctx.dev = dev = torch.device("cuda", ctx.local_rank)
+    ctx.cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -94,7 +354,7 @@ def main():
             dist.init_process_group("gloo")
 
     import bang_amd
-    from bang_amd import shard, synth
+    from bang_amd import shard
     from oracle import oracle as O           # checker + cpu_baseline leg only
     if rank == 0:                            # one builder per node; the others wait (make is not re-entrant)
         bang_amd.build()
@@ -102,81 +362,44 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # ------------------------------------------------------------------ workload
-    t0 = time.time()
-    if args.workload.endswith("_shape"):
-        from tools import shape_workload
-        ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
-            args.workload, dev, n_override=args.shape_n, Q=args.queries or 10_000, log=log)
-        if not args.graph:
-            args.graph = shape_graph
+    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n)
+    ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
+    graph = args.graph or wl["graph"]          # sift1m: "host" = the north-star path
+    ctx.Q_total = Q = queries.shape[0]
+    weak = world > 1 and args.batches > 1
+    if weak:
+        q0, q1 = 0, Q                          # throughput mode: every rank searches whole batches
     else:
-        N, D, dtype, R, m, Q, ncl = WORKLOADS[args.workload]
-        if args.queries:
-            Q = args.queries
-        ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q, K=args.k, n_clusters=ncl, device=dev)
-        d_codes = None
-        wl_name = (f"{args.workload}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
-                   f"Q={Q} k={args.k} (kNN+random-link graph, trained PQ, brute-force GT)")
-    if not args.graph:
-        args.graph = "host"                       # the north-star path: graph in host RAM + C++ walker
-    torch.cuda.synchronize()
-    log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
-    Q = queries.shape[0]
-    k = args.k
-    q0, q1 = shard.shard_range(Q, rank, world)
+        q0, q1 = shard.shard_range(Q, rank, world)
     my_q = np.ascontiguousarray(queries[q0:q1])
     Qr = q1 - q0
 
-    graph_mode = bang_amd.GRAPH_DEVICE if args.graph == "device" else bang_amd.GRAPH_HOST
-    # 0 = engine default (lanes from the batch size, walker threads from the CPU quota)
     lanes = args.lanes or int(os.environ.get("BANG_LANES", "0"))
     threads = args.threads or int(os.environ.get("BANG_THREADS", "0"))
-    if world > 1 and graph_mode == bang_amd.GRAPH_HOST:
-        # all ranks of the node share one CPU quota: size (lanes x walker threads) from this rank's share of it
+    if world > 1 and graph == "host":
+        # all ranks of the node share one CPU quota: size the walker team from this rank's share of it
         share = max(1, usable_cpus() // world)
-        if not lanes:
-            lanes = max(1, min(4, share // 2, Qr // 512 if Qr >= 512 else 1))
         if not threads:
-            # (the persistent kernel ignores lanes: its one walker team gets the whole share)
-            threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // lanes))
-    eng = bang_amd.Engine(ix.dtype, graph=graph_mode, device=local_rank, lanes=lanes, threads=threads,
-                          timing=0 if args.no_events else 1)
-    eng.load_index(ix, d_codes=d_codes)
+            threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // max(1, lanes or 1)))
+    eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1)
 
-    def run_once(L, timed=False):
-        eng.init(Qr)
-        if timed:
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-        t_a = time.perf_counter()
-        ids, dists = eng.query(my_q)
-        if world > 1:                                    # the single RCCL collective of the job
-            shard.gather_ids(ids, Q, k, rank, world, device=cdev)
-        if timed:
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-        return ids, dists, time.perf_counter() - t_a
-
-    # ------------------------------------------------------------------ choose L (untimed)
-    def recall_of(ids):
+    def recall_of(ids, a=q0, b=q1):
         if gt_i is None:
             return float("nan")
-        return O.recall(gt_i[q0:q1], gt_d[q0:q1], ids, k)
+        return O.recall(gt_i[a:b], gt_d[a:b], ids, k)
 
+    # ------------------------------------------------------------------ choose L (untimed)
     L = args.L
     recall = float("nan")
     if L == 0 and gt_i is not None:
         for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
             eng.set_searchparams(k, cand)
             eng.alloc(Qr)
-            ids, _, _ = run_once(cand)
+            ids, _, _ = run_once(eng, my_q, ctx)
             eng.free()
             r = recall_of(ids)
             if world > 1:
-                t = torch.tensor([r], device=cdev, dtype=torch.float64)
+                t = torch.tensor([r], device=ctx.cdev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 r = float(t.item())
             log(f"[bench] L={cand:3d} recall={r:.2f}")
@@ -188,39 +411,20 @@ def main():
     elif L == 0:
         L = 152                                          # reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
 
+    # ------------------------------------------------------------------ timed steps of the primary workload
     eng.set_searchparams(k, L)
     eng.alloc(Qr)
-
-    # ------------------------------------------------------------------ timed steps
-    for _ in range(args.warmup):
-        run_once(L, timed=True)
-    step_s, init_s = [], []
-    agg = dict(front_ms=0.0, front_busy_ms=0.0, back_ms=0.0, rerank_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0, iterations=0,
-               fetched=0, candidates=0, h2d_bytes=0, persistent=0, vectors_on_device=0)
-    ids = None
-    for _ in range(args.steps):
-        ti = time.perf_counter()
-        ids, dists, el = run_once(L, timed=True)
-        init_s.append(time.perf_counter() - ti)
-        step_s.append(el)
-        st = eng.stats()
-        for key in agg:
-            agg[key] = agg[key] + st[key] if key not in ("iterations", "persistent", "vectors_on_device") else max(agg[key], st[key])
+    res = measure(eng, wl, my_q, L, args.steps, args.warmup, ctx, graph, traffic_key=f"{args.workload}_{graph}",
+                  batches=args.batches if weak else 1)
+    ids, dists, agg = res["ids"], res["dists"], res["agg"]
     if gt_i is not None:
         recall = recall_of(ids)
-    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-        rc = torch.tensor([recall], dtype=torch.float64, device=cdev)
-        dist.all_reduce(rc, op=dist.ReduceOp.MIN)
-        recall = float(rc.item())
-    total = float(times[0].sum().item())
-    total_incl_init = float(times[1].sum().item())
-    value = Q * args.steps / total
-
-    # parity spot check on the real workload: first 64 queries of this rank vs the oracle.  Shape-only workloads keep
-    # their PQ codes only in HBM (70 GB), so the oracle cannot run there: size-independent properties are checked
-    # instead (ids in range and distinct, distances ascending and equal to the exact distance of the returned id).
+        if world > 1:
+            rc = torch.tensor([recall], dtype=torch.float64, device=ctx.cdev)
+            dist.all_reduce(rc, op=dist.ReduceOp.MIN)
+            recall = float(rc.item())
+    # parity spot check on the real workload: first 64 queries of this rank vs the oracle (structured workloads), or the
+    # size-independent result properties (shape-only workloads)
     orc = None
     if gt_i is not None:
         orc = O.Oracle(ix)
@@ -228,67 +432,11 @@ def main():
         ids_o, _ = orc.search(my_q[:chk], k, L)
         parity_ok = bool(np.array_equal(ids[:chk], ids_o))
     else:
-        parity_ok = True
-        isz = 4 if ix.dtype == "float" else 1
-        npd = np.float32 if ix.dtype == "float" else np.uint8
-        for qi in range(0, Qr, max(1, Qr // 256)):
-            row = ids[qi].astype(np.int64)
-            vec = np.ascontiguousarray(ix.graph[row, : ix.D * isz]).view(npd).reshape(k, ix.D).astype(np.float64)
-            ex = ((vec - my_q[qi].astype(np.float64)) ** 2).sum(axis=1)
-            dd = dists[:, qi].astype(np.float64)
-            parity_ok &= bool((row < ix.N).all() and len(set(row.tolist())) == k and (np.diff(dd) >= 0).all()
-                              and np.allclose(dd, ex, rtol=1e-5))
+        parity_ok = check_properties(ix, my_q, ids, dists, k)
 
     out = None
+    cfg = {}
     if rank == 0:
-        m = ix.m
-        bytes_per_eval = m + 8                           # m code bytes + 4 B id + 4 B distance
-        roof = None
-        if not args.no_events and agg["front_ms"] > 0:
-            launches = agg["front_launches"]
-            persistent = bool(agg["persistent"])
-            evals_per_launch = agg["dist_evals"] / launches
-            # launch-per-iteration loop: sum of the launch durations; persistent kernel: ONE launch per batch whose duration
-            # (first to last in-kernel stamp) includes the time its workgroups wait for the host walker
-            avg_ms = (agg["front_busy_ms"] if persistent else agg["front_ms"]) / launches
-            achieved = evals_per_launch * bytes_per_eval / (avg_ms * 1e-3) / 1e9
-            traffic = None                               # HBM bytes per launch from the committed PMC passes of this command
-            tf = os.path.join(ROOT, "profiles", f"traffic_{args.workload}_{args.graph}.json")
-            if os.path.exists(tf) and world == 1:            # the PMC passes were taken on the full single-GPU batch
-                try:
-                    tj = json.load(open(tf))
-                    traffic = tj.get("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                    "kernel": ("front_kernel<PERSIST> (whole search in ONE launch: K5 filter + K2 PQ distance + K4 parent, then K3a sort + "
-                               "K3b merge, per workgroup and iteration, paced by the host walker)") if persistent else
-                              "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
-                    "algorithmic_bytes_per_launch": round(evals_per_launch * bytes_per_eval, 1),
-                    "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches,
-                    "bytes_per_distance_eval": bytes_per_eval}
-            if persistent:
-                roof["achieved_in_front_phases"] = round(agg["dist_evals"] * bytes_per_eval / (agg["front_ms"] * 1e-3) / 1e9, 3)
-                roof["front_phase_ms_per_workgroup"] = round(agg["front_ms"] / launches, 3)
-                h2d = agg["h2d_bytes"] / launches
-                roof["pcie_h2d"] = {"bytes_per_launch": int(h2d), "achieved_GBps": round(h2d / (avg_ms * 1e-3) / 1e9, 2),
-                                    "note": "adjacency rows + full-precision vectors the walker threads store through the PCIe BAR "
-                                            "while the kernel runs: the resource this launch is actually bound by (x16 Gen5: "
-                                            "about 48 GB/s of CPU stores measured on this box, tools/dev/bar_write.cpp)"}
-                roof["note"] = ("achieved = algorithmic bytes of the ONE launch of a batch / its duration; the launch spans the whole "
-                                "search, so the duration contains every wait for the host walker (PCIe) -- achieved_in_front_phases "
-                                "divides by the time a workgroup spends in its front phases instead (mean over workgroups)")
-                roof["timer"] = ("in-kernel s_memrealtime stamps (100 MHz): launch = first go-seen stamp .. last stamp of any "
-                                 "workgroup; cross-checked against rocprofv3 --kernel-trace in profiles/")
-            else:
-                roof["achieved_all_lanes"] = (round(agg["dist_evals"] * bytes_per_eval / (agg["front_busy_ms"] * 1e-3) / 1e9, 3)
-                                              if agg["front_busy_ms"] > 0 else None)
-                roof["note"] = ("achieved = algorithmic bytes of ONE launch / its duration (a lane's launch covers Q/lanes queries and "
-                                "overlaps the other lanes' launches); achieved_all_lanes = all algorithmic bytes / time during which "
-                                "any front kernel was running")
-                roof["timer"] = ("in-kernel s_memrealtime stamps (100 MHz): per launch max(end) - min(start) over its workgroups, "
-                                 "every launch of the timed steps; cross-checked against rocprofv3 --kernel-trace in profiles/")
         cpu = None
         if world == 1 and not args.no_cpu_baseline and orc is not None:
             nthreads = usable_cpus()
@@ -303,48 +451,78 @@ def main():
                    "sample": f"{reps} x the full {Q}-query batch at L={L} through oracle/ (C + OpenMP, {nthreads} threads = "
                              f"the CPU quota of this box; {os.cpu_count()} hardware threads visible), same timed region "
                              f"(search only)"}
-        out = {
-            "metric": "queries/sec @ recall@10>=0.9, 10K-query batch", "value": round(value, 1), "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * total / args.steps, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_name, "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None), "graph": args.graph,
-                       "lanes": lanes, "walker_threads_per_lane": threads, "iterations": agg["iterations"],
-                       "host_loop": "persistent search kernel" if agg["persistent"] else "launch per iteration",
-                       "rerank_vectors": ("graph entries in HBM" if args.graph == "device" else
-                                          "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
-                       "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
-                       "qps_incl_init": round(Q * args.steps / total_incl_init, 1),
-                       "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
-                       "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
-                       "front_busy_ms_per_step": round(agg["front_busy_ms"] / args.steps, 3),
-                       "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
-                       "sync_ms_per_step": round(agg["sync_ms"] / args.steps, 3),
-                       "enqueue_ms_per_step": round(agg["enqueue_ms"] / args.steps, 3),
-                       "dist_evals_per_step": agg["dist_evals"] // args.steps,
-                       "step_ms_min_max": [round(1e3 * float(times[0].min().item()), 3), round(1e3 * float(times[0].max().item()), 3)],
-                       "step_ms": [round(1e3 * float(t), 2) for t in times[0].tolist()][:64]},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-    # BASELINE.json configs[1] also names L = 200: the same batch at that worklist length, outside the timed region of `value`
-    at_L200 = None
-    if wl_name.startswith("sift1m") and L != 200 and world == 1 and gt_i is not None and not os.environ.get("BANG_BENCH_NO_L200"):
+        cfg = {"workload": wl["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
+               "graph": graph, "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
+               "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
+               "iterations": agg["iterations"], "hops_p50_p99_max": [agg["hops_p50"], agg["hops_p99"], agg["hops_max"]],
+               "host_loop": "persistent search kernel" if agg["persistent"] else "launch per iteration",
+               "rerank_vectors": ("graph entries in HBM" if graph == "device" else
+                                  "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
+               "vector_dtype": ix.dtype, "batches_per_step": args.batches if weak else 1,
+               "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
+               "qps_incl_init": res["qps_incl_init"],
+               "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
+               "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
+               "front_busy_ms_per_step": round(agg["front_busy_ms"] / args.steps, 3),
+               "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
+               "dist_evals_per_step": agg["dist_evals"] // args.steps,
+               "step_ms_min_max": [min(res["step_ms"]), max(res["step_ms"])], "step_ms": res["step_ms"]}
+        out = {"metric": "queries/sec @ recall@10>=0.9, 10K-query batch", "value": res["queries_per_s"], "unit": "queries/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": ARITH_DTYPE,
+               "data": "synthetic", "config": cfg, "roofline": res["roofline"], "cpu_baseline": cpu}
+
+    # ------------------------------------------------------------------ legs (single GPU only): the other BASELINE configs
+    legs = world == 1 and not args.no_legs and args.workload == "sift1m" and not os.environ.get("BANG_BENCH_NO_LEGS")
+    leg_steps, leg_warm = 5, 1
+    if legs and gt_i is not None and L != 200 and not os.environ.get("BANG_BENCH_NO_L200"):
+        # BASELINE.json configs[1] also names L = 200: the same batch at that worklist length
         eng.free()
         eng.set_searchparams(k, 200)
         eng.alloc(Qr)
-        run_once(200, timed=True)
-        ts = []
-        ids200 = None
-        for _ in range(3):
-            ids200, _, el = run_once(200, timed=True)
-            ts.append(el)
-        at_L200 = {"L": 200, "queries_per_s": round(Q * len(ts) / sum(ts), 1), "ms_per_batch": round(1e3 * sum(ts) / len(ts), 3),
-                   "recall_at_10": round(recall_of(ids200), 3), "steps": len(ts)}
-        if out is not None:
-            out["config"]["at_L200"] = at_L200
+        r2 = measure(eng, wl, my_q, 200, 3, 1, ctx, graph)
+        ids_o, _ = orc.search(my_q[:64], k, 200)
+        cfg["at_L200"] = leg_summary(r2, wl, graph, recall=recall_of(r2["ids"]),
+                                     extra={"parity_vs_oracle_first_64": bool(np.array_equal(r2["ids"][:64], ids_o))})
     eng.free()
     eng.unload()
     eng.close()
+    if legs and gt_i is not None:
+        other = "device" if graph == "host" else "host"
+        e2 = make_engine(wl, other, ctx, timing=0 if args.no_events else 1)
+        e2.set_searchparams(k, L)
+        e2.alloc(Qr)
+        r3 = measure(e2, wl, my_q, L, leg_steps, leg_warm, ctx, other, traffic_key=f"{args.workload}_{other}")
+        cfg[f"at_{other}_graph"] = leg_summary(r3, wl, other, recall=recall_of(r3["ids"]),
+                                               extra={"ids_equal_primary_run": bool(np.array_equal(r3["ids"], ids))})
+        e2.free(); e2.unload(); e2.close()
+    k2 = {}
+    if legs:
+        k2[f"m{ix.m}"] = k2_alone(ix.D, ix.m, ix.dtype, ctx)
+    wl["release"]()
+    del wl, ix, queries
+    torch.cuda.empty_cache()
+    if legs:
+        for name in ("deep100m_shape", "sift1b_shape"):
+            try:
+                w2 = build_workload(name, ctx)
+                q2 = np.ascontiguousarray(w2["queries"])
+                e3 = make_engine(w2, w2["graph"], ctx, timing=0 if args.no_events else 1)
+                e3.set_searchparams(k, 152)                  # the reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
+                e3.alloc(q2.shape[0])
+                r4 = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, w2["graph"], traffic_key=f"{name}_{w2['graph']}")
+                props = check_properties(w2["ix"], q2, r4["ids"], r4["dists"], k)
+                cfg[f"at_{name}"] = leg_summary(r4, w2, w2["graph"], props=props)
+                e3.free(); e3.unload(); e3.close()
+                k2[f"m{w2['ix'].m}"] = k2_alone(w2["ix"].D, w2["ix"].m, w2["ix"].dtype, ctx)
+                w2["release"]()
+                del w2, q2, e3
+                torch.cuda.empty_cache()
+            except Exception as ex:                          # a leg must never take the primary line down
+                cfg[f"at_{name}"] = {"error": repr(ex)[:300]}
+        if out is not None and out["roofline"] is not None:
+            out["roofline"]["k2_alone"] = k2.get(f"m{WORKLOADS[args.workload][4]}")
+            out["roofline"]["k2_alone_other_layouts"] = {kk: v for kk, v in k2.items() if kk != f"m{WORKLOADS[args.workload][4]}"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -47,7 +47,10 @@ extern "C" {
 enum { BANG_U8 = 0, BANG_I8 = 1, BANG_F32 = 2 };            /* element type of vectors/queries */
 enum { BANG_DIST_L2 = 0, BANG_DIST_MIPS = 1 };              /* DistFunc, bang.h:26-30 */
 enum { BANG_GRAPH_HOST = 0,      /* graph in host RAM, C++ walker + staged H2D (BANG_Base) */
-       BANG_GRAPH_DEVICE = 1 };  /* graph + vectors resident in HBM (BANG_Inmemory placement) */
+       BANG_GRAPH_DEVICE = 1,    /* graph + vectors resident in HBM (BANG_Inmemory placement) */
+       BANG_GRAPH_AUTO = 2 };    /* resolved by bang_load: DEVICE when graph + vectors fit the free HBM next to the PQ codes
+                                    (with 16 GB to spare for the per-batch state), else HOST.  288 GB hold SIFT1M .. DEEP100M
+                                    (configs[1], [2]) whole; SIFT1B's 388 GB graph stays in host RAM (configs[3]) */
 
 /* ------------------------------------------------------------------ (1) engine level */
 typedef struct bang_engine bang_engine_t;
@@ -59,7 +62,7 @@ int bang_create(int dtype, bang_engine_t** out);             /* BANGSearch<T>() 
 int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   bang.h:43 */
 
 /* options must be set before bang_load_e / bang_alloc_e:
- *   "graph"   : BANG_GRAPH_HOST | BANG_GRAPH_DEVICE
+ *   "graph"   : BANG_GRAPH_HOST | BANG_GRAPH_DEVICE | BANG_GRAPH_AUTO (default: auto; environment BANG_GRAPH=host|device|auto)
  *   "lanes"   : number of independent query groups pipelined against each other (>=1)
  *   "threads" : host walker threads per lane (>=1)
  *   "device"  : HIP device ordinal
@@ -116,6 +119,14 @@ typedef struct {
   uint64_t h2d_bytes;         /* host-graph mode: bytes the walker handed to the device (adjacency rows + full-precision vectors) */
   uint64_t vectors_on_device; /* host-graph mode: 1 = the re-rank read a packed copy of the vectors in HBM ("vectors" option),
                                  0 = the walker shipped every expanded node's vector (the reference's data flow) */
+  /* effective configuration of the allocation the query ran on (what "auto" resolved to) */
+  uint64_t graph_mode;        /* BANG_GRAPH_HOST | BANG_GRAPH_DEVICE */
+  uint64_t lanes;             /* independent query groups (1 with the persistent search kernel) */
+  uint64_t walker_threads;    /* host walker threads per lane (0 in device-graph mode) */
+  uint64_t wg_queries;        /* persistent search kernel: queries per workgroup block, 0 otherwise */
+  uint64_t workgroups;        /* persistent search kernel: workgroups of the launch, 0 otherwise */
+  /* expansions (= graph hops = iterations in which the query had a parent) per query: median, 99th percentile, maximum */
+  uint64_t hops_p50, hops_p99, hops_max;
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 

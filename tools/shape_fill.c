@@ -24,7 +24,8 @@ void *shape_alloc(size_t bytes) {
 }
 void shape_free(void *p, size_t bytes) { if (p) munmap(p, bytes); }
 
-void shape_fill_graph(uint8_t *graph, uint64_t N, uint32_t vec_bytes, uint32_t R, uint64_t seed, int nthreads) {
+/* vec_float != 0: the vector part holds vec_bytes/4 floats, uniform in [-1, 1) (random bytes are not sane floats) */
+void shape_fill_graph(uint8_t *graph, uint64_t N, uint32_t vec_bytes, uint32_t R, uint64_t seed, int nthreads, int vec_float) {
   const uint64_t entry = (uint64_t)vec_bytes + 4 + 4ull * R;
   uint64_t lo_[64], w_[64];
   if (R > 64) return;
@@ -35,6 +36,18 @@ void shape_fill_graph(uint8_t *graph, uint64_t N, uint32_t vec_bytes, uint32_t R
     uint64_t s = seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull);
     uint8_t *e = graph + (uint64_t)i * entry;
     uint32_t k = 0;
+    if (vec_float) {
+      for (; k + 8 <= vec_bytes; k += 8) {
+        const uint64_t r = splitmix(&s);
+        const float f[2] = {(float)((int32_t)(r & 0xFFFFFF) - 0x800000) * (1.0f / 8388608.0f),
+                            (float)((int32_t)((r >> 32) & 0xFFFFFF) - 0x800000) * (1.0f / 8388608.0f)};
+        memcpy(e + k, f, 8);
+      }
+      for (; k + 4 <= vec_bytes; k += 4) {
+        const float f = (float)((int32_t)(splitmix(&s) & 0xFFFFFF) - 0x800000) * (1.0f / 8388608.0f);
+        memcpy(e + k, &f, 4);
+      }
+    }
     for (; k + 8 <= vec_bytes; k += 8) { uint64_t r = splitmix(&s); memcpy(e + k, &r, 8); }
     for (; k < vec_bytes; ++k) e[k] = (uint8_t)splitmix(&s);
     uint32_t deg = R;

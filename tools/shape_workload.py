@@ -34,7 +34,7 @@ def _lib():
     lib.shape_alloc.restype = C.c_void_p
     lib.shape_alloc.argtypes = [C.c_size_t]
     lib.shape_free.argtypes = [C.c_void_p, C.c_size_t]
-    lib.shape_fill_graph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+    lib.shape_fill_graph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
     lib.shape_fill_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     return lib
 
@@ -76,7 +76,9 @@ class ShapeIndex:
         return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
 
 
-def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print):
+def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False):
+    """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
+    can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent."""
     import torch
     from bang_amd.synth import chunk_offsets
     sh = dict(SHAPES[name])
@@ -110,28 +112,30 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print):
     ptr = lib.shape_alloc(gbytes)
     if not ptr:
         raise MemoryError(f"cannot map {gbytes} bytes")
-    lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu)
+    lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu, 1 if sh["dtype"] == "float" else 0)   # floats: uniform in [-1, 1)
     graph = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(gbytes,)).reshape(N, entry)
-    if sh["dtype"] == "float":          # random bytes are not sane floats: overwrite the vector part block-wise with N(0,1)
-        rng = np.random.default_rng(seed)
-        step = 1 << 20
-        for a in range(0, N, step):
-            b = min(N, a + step)
-            v = rng.standard_normal((b - a, D), dtype=np.float32)
-            graph[a:b, : D * 4] = v.view(np.uint8).reshape(b - a, D * 4)
     log(f"[shape] graph image {gbytes / 2**30:.1f} GiB filled in {time.time() - t0:.1f}s with {ncpu} threads{note}")
-    # PQ codes straight on the device
     t0 = time.time()
-    codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
-    step = 1 << 28
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed + 7)
-    for a in range(0, N * m, step):
-        b = min(N * m, a + step)
-        codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
-    codes[N * m:] = 0
-    torch.cuda.synchronize()
-    log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated on the device in {time.time() - t0:.1f}s")
+    codes_host, cptr = None, None
+    if host_codes:
+        cptr = lib.shape_alloc(N * m)
+        if not cptr:
+            raise MemoryError(f"cannot map {N * m} bytes")
+        lib.shape_fill_bytes(cptr, N * m, seed + 7, ncpu)
+        codes_host = np.ctypeslib.as_array(C.cast(cptr, C.POINTER(C.c_uint8)), shape=(N * m,)).reshape(N, m)
+        codes = None
+        log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated in host memory in {time.time() - t0:.1f}s")
+    else:                               # PQ codes straight on the device
+        codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
+        step = 1 << 28
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed + 7)
+        for a in range(0, N * m, step):
+            b = min(N * m, a + step)
+            codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
+        codes[N * m:] = 0
+        torch.cuda.synchronize()
+        log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated on the device in {time.time() - t0:.1f}s")
     rng = np.random.default_rng(seed + 1)
     scale = 40.0 if sh["dtype"] == "uint8" else 0.5
     pivots = (rng.standard_normal((256, D)) * scale).astype(np.float32)
@@ -139,10 +143,23 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print):
     if sh["dtype"] == "uint8":
         queries = rng.integers(0, 256, (Q, D), dtype=np.uint8)
     else:
-        queries = rng.standard_normal((Q, D)).astype(np.float32)
+        queries = (rng.random((Q, D), dtype=np.float32) * 2 - 1).astype(np.float32)
     ix = ShapeIndex(dtype=sh["dtype"], N=N, D=D, R=R, m=m, medoid=int(N // 2), graph=graph,
-                    codes=np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
-                    chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib)
+                    codes=codes_host if host_codes else np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
+                    chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib, _cptr=cptr, _cbytes=N * m)
     name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
               f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * m / 1e9:.0f} GB in HBM{note}")
-    return ix, queries, None, None, codes.data_ptr(), name_s, sh["graph"]
+    return ix, queries, None, None, (codes.data_ptr() if codes is not None else None), name_s, sh["graph"]
+
+
+def release(ix):
+    """Unmap the host images of a shape index (the numpy views of it must not be used afterwards)."""
+    if getattr(ix, "_ptr", None):
+        ix.graph = None
+        ix._lib.shape_free(ix._ptr, ix._bytes)
+        ix._ptr = None
+    if getattr(ix, "_cptr", None):
+        ix.codes = None
+        ix._lib.shape_free(ix._cptr, ix._cbytes)
+        ix._cptr = None
+    ix._codes = None
