@@ -57,7 +57,8 @@ class Stats(C.Structure):
                 ("walker_ms", C.c_double), ("sync_ms", C.c_double), ("enqueue_ms", C.c_double), ("front_busy_ms", C.c_double),
                 ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64),
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
-                ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64)]
+                ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
+                ("search_kernel", C.c_uint64)]
 
 
 def lib_path() -> str:
@@ -204,6 +205,13 @@ class Engine:
         s = Stats()
         _check(lib().bang_get_stats(self._h, C.byref(s)), "bang_get_stats")
         return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def query_counters(self, Q: int) -> np.ndarray:
+        """[Q][4] per-query {iterations (search kernel only, else 0), candidates, dist_evals, fetched} of the last query -- the
+        column order of the oracle's per-query statistics."""
+        cols = [np.zeros(Q, np.uint32) for _ in range(4)]
+        _check(lib().bang_get_query_counters(self._h, _vp(cols[2]), _vp(cols[3]), _vp(cols[1]), _vp(cols[0])), "bang_get_query_counters")
+        return np.stack(cols, axis=1).astype(np.int64)
 
     def free(self):
         _check(lib().bang_free_e(self._h), "bang_free")

@@ -1,0 +1,227 @@
+// bang_device.h -- device-side helpers shared by the kernel translation units (bang_kernels.hip: per-iteration kernels and the
+// round-1 persistent kernel; bang_search.hip: the query-resident search kernel).  Not public.
+// Reference line numbers: /root/reference/BANG_Base/bang_search.cu.
+#ifndef BANG_DEVICE_H_
+#define BANG_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bang_c.h"
+#include "bang_internal.h"
+
+#define WAVE 64
+#define BIG_DIST ((float)3.402823E+38)  // bang_search.cu:1406,1484
+
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef const float __attribute__((address_space(4))) * cfloat_p;  // constant AS: scalar loads
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash1(uint32_t x) {  // hashFn1_d :1168-1178
+  uint64_t h = 0xcbf29ce4ull;
+  h = (h ^ (uint64_t)(x & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 8) & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 16) & 0xff)) * 0x01000193ull;
+  h = (h ^ (uint64_t)((x >> 24) & 0xff)) * 0x01000193ull;
+  return (uint32_t)(h % BANG_BF_ENTRIES);
+}
+__device__ __forceinline__ uint32_t hash2(uint32_t x) {  // hashFn2_d :1180-1189
+  uint64_t h = 0x84222325ull;
+  h = (h ^ (uint64_t)(x & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 8) & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 16) & 0xff)) * 0x1B3ull;
+  h = (h ^ (uint64_t)((x >> 24) & 0xff)) * 0x1B3ull;
+  return (uint32_t)(h % BANG_BF_ENTRIES);
+}
+
+__device__ __forceinline__ void bloom_set(uint32_t* w, uint32_t bit) {
+  (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void wave_sync() {
+  // Intra-wave LDS hand-off: a wave executes its LDS instructions in program order, so a plain
+  // write followed by a read needs no fence; this only stops the compiler from moving code across.
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of mask bits below my lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 core: distance of one neighbour (one lane) -- pivot-stationary form
+// ------------------------------------------------------------------------------------------
+// Canonical float order (bang_search.cu:1229-1239): eight partial sums
+// s_l = (((0 + t_l) + t_{l+8}) + ...), then ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)).
+// t_c = LUT[c][code_c] is recomputed as the fmaf chain of populate_pqDist_par (:1118-1128);
+// zero padding of a chunk to PSZ dims adds fmaf(0,0,t) == t, i.e. nothing.
+// NHI > 0 (PSZ == 2 only): exact-size table -- chunks [0, NHI) hold 2 floats per entry, the rest 1.  A 1-dim chunk skips the
+// second term, which is what the padded table computes for it (fmaf(0, 0, t) == t).  NHI is a template parameter so that every
+// entry address stays "code * size + immediate" (a runtime split costs an address register per chunk: measured as 100-200
+// spilled VGPRs in every 2-float instance).
+template <int PSZ, int NHI>
+__device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, cfloat_p qc, uint32_t c, uint32_t code) {
+  float t = 0.0f;
+  if (PSZ == 2 && NHI > 0) {
+    if (c < (uint32_t)NHI) {
+      const float2 p = *(const float2*)(piv_lds + c * 512u + code * 2u);
+      const float d0 = p.x - qc[c * 2 + 0];
+      t = __builtin_fmaf(d0, d0, t);
+      const float d1 = p.y - qc[c * 2 + 1];
+      t = __builtin_fmaf(d1, d1, t);
+    } else {
+      const float d0 = piv_lds[(uint32_t)NHI * 256u + c * 256u + code] - qc[c * 2 + 0];
+      t = __builtin_fmaf(d0, d0, t);
+    }
+    return t;
+  }
+  const float* e = piv_lds + ((size_t)c * 256 + code) * PSZ;
+  if (PSZ == 1) {
+    const float d = e[0] - qc[c];
+    t = __builtin_fmaf(d, d, t);
+  } else if (PSZ == 2) {
+    const float2 p = *(const float2*)e;
+    const float d0 = p.x - qc[c * 2 + 0];
+    t = __builtin_fmaf(d0, d0, t);
+    const float d1 = p.y - qc[c * 2 + 1];
+    t = __builtin_fmaf(d1, d1, t);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PSZ; i += 4) {
+      const float4 p = *(const float4*)(e + i);
+      const float d0 = p.x - qc[c * PSZ + i + 0];
+      t = __builtin_fmaf(d0, d0, t);
+      const float d1 = p.y - qc[c * PSZ + i + 1];
+      t = __builtin_fmaf(d1, d1, t);
+      const float d2 = p.z - qc[c * PSZ + i + 2];
+      t = __builtin_fmaf(d2, d2, t);
+      const float d3 = p.w - qc[c * PSZ + i + 3];
+      t = __builtin_fmaf(d3, d3, t);
+    }
+  }
+  return t;
+}
+
+// NDW = number of code dwords per row after padding the chunk count to MP = 4*NDW (the padding
+// chunks are all-zero in the packed pivot table and in qc, so they add fmaf(0,0,0) = +0).
+// ALIGNED = (m % 4 == 0): rows start dword-aligned, no funnel shift needed.
+// A code row is fetched with 16-byte loads from its 4-byte-aligned base (pq_row_load) and consumed by
+// straight-line code (pq_row_reduce) so that the compiler can batch the LDS reads and scalar loads;
+// splitting load from use lets the caller put another query's row in flight first.
+template <int NDW, bool ALIGNED>
+struct PqRow {
+  static constexpr int NLOAD = ALIGNED ? NDW : NDW + 1;   // dwords needed from the aligned base
+  static constexpr int NX4 = (NLOAD + 3) / 4;
+  uint32_t w[NX4 * 4 + 1];
+  uint32_t sh;
+};
+
+template <int NDW, bool ALIGNED>
+__device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_t* __restrict__ codes, uint32_t m,
+                                            uint32_t id) {
+  const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
+  r.sh = (uint32_t)a & 3u;
+  const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
+#pragma unroll
+  for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4; ++i) {
+    const u32x4a v = p[i];
+    r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+  }
+  r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
+}
+
+// SB > 0: the row is consumed in segments of SB code dwords; a dependency fence between segments keeps the compiler from hoisting
+// the LDS reads of the whole row (72 chunks of the 70/74-chunk layouts) in front of the first add -- that is what pushed those
+// instances past 128 VGPRs.
+template <int PSZ, int NDW, bool ALIGNED, int NHI, int SB = 0>
+__device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds,
+                                               cfloat_p qc) {
+  float s[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) {
+    if constexpr (SB > 0) {
+      if (k > 0 && (k % SB) == 0) {
+        // Every partial sum and every code dword still to be consumed passes through an empty asm: nothing of the next segment
+        // (byte extraction -> LDS address -> read) can be scheduled in front of the last add of this one.
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]));
+        uint32_t* w = const_cast<uint32_t*>(r.w);
+#pragma unroll
+        for (int kk = k; kk < NDW + (ALIGNED ? 0 : 1) && kk < k + SB + 1; ++kk) asm volatile("" : "+v"(w[kk]));
+      }
+    }
+    const uint32_t dw = ALIGNED ? r.w[k] : __builtin_amdgcn_alignbyte(r.w[k + 1], r.w[k], r.sh);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t c = 4 * k + b;
+      const uint32_t code = (dw >> (8 * b)) & 0xffu;
+      const float t = lut_entry<PSZ, NHI>(piv_lds, qc, c, code);
+      s[c & 7] = s[c & 7] + t;
+    }
+  }
+  const float x = (s[0] + s[1]) + (s[2] + s[3]);
+  const float y = (s[4] + s[5]) + (s[6] + s[7]);
+  return x + y;
+}
+
+
+__device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target <= arr[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t hi, float target) {  // :1735-1749
+  uint32_t lo = 0;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (target >= arr[mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-side launcher helpers (per translation unit)
+// ---------------------------------------------------------------------------------------------------------------------
+#define HIP_TRY(x)                                                         \
+  do {                                                                     \
+    hipError_t _e = (x);                                                   \
+    if (_e != hipSuccess) {                                                \
+      bang_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return BANG_ERR_HIP;                                                 \
+    }                                                                      \
+  } while (0)
+
+// Per-DEVICE launcher state: one process may drive several GPUs (one engine per device), and both the CU count and the
+// dynamic-LDS attribute of a kernel instance belong to the device that is current at launch time.
+#define BANG_MAX_DEVICES 64
+static inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BANG_MAX_DEVICES) dev = 0;
+  return dev;
+}
+static inline int num_cus() {
+  static int cus[BANG_MAX_DEVICES] = {0};
+  const int dev = current_device();
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    int n = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    cus[dev] = n > 0 ? n : 256;
+  }
+  return cus[dev];
+}
+
+// floats of the packed pivot table (multiple of 4: it is staged into LDS with 16-byte copies)
+static inline uint32_t pivot_table_floats(uint32_t psz, uint32_t mp, uint32_t nhi) {
+  if (psz == 2 && nhi != 0) return ((nhi * 512u + (mp - nhi) * 256u + 3u) & ~3u) + 4u;
+  return mp * 256u * psz;
+}
+
+#endif

@@ -244,6 +244,11 @@ struct bang_engine {
                                        // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
   bool persist_on = false;             // resolved at bang_alloc: the host-paced persistent kernel is used for this allocation
   bool persist_dev = false;            // resolved at bang_alloc: device-graph mode runs as ONE self-paced persistent kernel
+  int search_opt = -1;                 // device-graph mode: 1 = the query-resident search kernel (bang_search.hip), 0 = the round-1 loops,
+                                       // -1 = auto (1 where the pivot table leaves LDS for at least 4 waves' worklists)
+  bool search_v2 = false;              // resolved at bang_alloc
+  uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
+  std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
   int pq_ragged = 1;                   // 2-float PQ layouts: exact-size pivot table where possible (0 = always the padded table)
   uint32_t pq_nhi_avail = 0;           // resolved at load: leading 2-dim chunks of the exact-size table in d_pivots_ragged, 0 = none
@@ -462,7 +467,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
   dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
-  dfree(e->d_done_count); dfree(e->d_stage);
+  dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_qiters);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_fp) (void)hipHostFree(e->h_fp);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -927,7 +932,31 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   };
 
   uint32_t pw_stats[2] = {0, 0};
-  if (e->persist_dev) {
+  if (e->search_v2) {
+    // graph resident in HBM: ONE launch of the query-resident search kernel; no host involvement until the re-rank
+    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
+    bang_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.Q = ln.nq; sp.R = e->R; sp.m = e->m; sp.L = (uint32_t)e->L; sp.medoid = (uint32_t)e->medoid; sp.cap_iter = cap_iter;
+    sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
+    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
+    sp.d_graph = e->d_graph; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
+    sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
+    sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
+    sp.d_ktime = ktime_slot(e, ln);
+    {
+      static const int env_wgs = getenv("BANG_SEARCH_MAX_WGS") ? atoi(getenv("BANG_SEARCH_MAX_WGS")) : 0;   // experiment / test knobs
+      static const int env_waves = getenv("BANG_SEARCH_MAX_WAVES") ? atoi(getenv("BANG_SEARCH_MAX_WAVES")) : 0;
+      const char* v1 = getenv("BANG_SEARCH_MAX_WGS");
+      sp.max_wgs = v1 ? (uint32_t)std::max(0, atoi(v1)) : (uint32_t)std::max(0, env_wgs);
+      sp.max_waves = (uint32_t)std::max(0, env_waves);
+    }
+    ENQ_BEGIN();
+    BANG_TRY(bang_k_search(&sp, ln.s_main));
+    ENQ_END();
+    ++ln.front_launches;
+    iter = cap_iter;                                                         // refined from the per-query counts below
+  } else if (e->persist_dev) {
     // graph resident in HBM: the whole search is ONE self-paced launch, no host involvement until the re-rank
     LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
     p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq; p.max_wgs = 0; p.d_active = nullptr;
@@ -1070,6 +1099,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
   if (persist || e->persist_dev) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt, 8, hipMemcpyDeviceToHost, ln.s_main));
+  if (e->search_v2) LANE_HIP(hipMemcpyAsync(e->h_qiters.data() + ln.q0, e->d_qiters + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main));
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
@@ -1081,6 +1111,11 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                        pr[7], pr[0] * 0.01 / pr[7], pr[1] * 0.01 / pr[7], pr[2] * 0.01 / pr[7], pr[3] * 0.01 / pr[7], pr[4] * 0.01 / pr[7]);
   }
   if (e->persist_dev && pw_stats[1]) ln.iterations = pw_stats[1];
+  if (e->search_v2) {
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < ln.nq; ++i) mx = std::max(mx, e->h_qiters[ln.q0 + i]);
+    ln.iterations = mx;
+  }
   DBG("[lane %d] synced\n", ln.index);
   ln.front_ms = ln.back_ms = ln.rerank_ms = 0;   // the in-kernel stamps are reduced lazily in bang_get_stats
   return BANG_OK;
@@ -1174,6 +1209,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_COMPACT")) e->compact = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = std::min(1, std::max(-1, atoi(v)));
+  if (const char* v = getenv("BANG_SEARCH")) e->search_opt = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_FP_BATCH")) e->fp_batch = std::max(1, atoi(v));
@@ -1202,7 +1238,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   if (e->loaded && (k == "graph" || k == "device" || k == "pq" || k == "pq_ragged" || k == "vectors")) {
     bang_set_error("option %s must be set before bang_load", key); return BANG_ERR_ARG;
   }
-  if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "timing" || k == "front_wgs")) {
+  if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "search" || k == "timing" || k == "front_wgs")) {
     bang_set_error("option %s must be set before bang_alloc", key); return BANG_ERR_ARG;
   }
   if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE && value != BANG_GRAPH_AUTO) return BANG_ERR_ARG; e->graph_mode = e->graph_opt = (int)value; }
@@ -1217,6 +1253,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "compact") { e->compact = value ? 1 : 0; }
   else if (k == "persistent") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->persistent = (int)value; }
+  else if (k == "search") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->search_opt = (int)value; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
   else if (k == "check_every") { if (value < 1) return BANG_ERR_ARG; e->check_every = (int)value; }
@@ -1319,6 +1356,17 @@ static int alloc_buffers(bang_engine* e, int Q) {
   }
   e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && persist_fits;
   e->persist_dev = dev_graph && e->persistent != 0 && persist_fits;
+  // graph in HBM: the query-resident search kernel, with whichever pivot table (padded / exact-size) leaves LDS for more waves
+  e->search_v2 = false;
+  if (dev_graph && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
+    const int w_pad = bang_search_supported(e->psz, e->mp, 0, (uint32_t)e->L);
+    const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
+    if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
+      e->search_v2 = true;
+      e->persist_dev = false;
+      e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
+    }
+  }
   e->fp_direct = false;
   if (e->persist_on || e->persist_dev) {
     const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
@@ -1347,6 +1395,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_parents_dev, nq));
+  if (e->search_v2) { BANG_TRY(dmalloc(&e->d_qiters, nq)); e->h_qiters.assign(nq, 0); }
   if (dev_graph) {
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {
@@ -1373,7 +1422,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->persist_on || e->persist_dev) nl = 1;           // the persistent kernel's workgroups are the unit of overlap, not lanes
+  if (e->persist_on || e->persist_dev || e->search_v2) nl = 1;   // the persistent kernel's workgroups are the unit of overlap, not lanes
   if (e->persist_on && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
   else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
@@ -1414,7 +1463,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
       }
     }
-    if (e->persist_dev) {
+    if (e->persist_dev || e->search_v2) {
       BANG_TRY(dmalloc(&ln.d_pcnt, 16));
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
     }
@@ -1539,13 +1588,15 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
     s.h2d_bytes += ln.h2d_bytes.load();
   }
-  s.persistent = (e->persist_on || e->persist_dev) ? 1 : 0;
+  s.persistent = (e->persist_on || e->persist_dev || e->search_v2) ? 1 : 0;
   s.vectors_on_device = e->vec_on_device ? 1 : 0;
   s.graph_mode = (uint64_t)e->graph_mode;
   s.lanes = (uint64_t)nl;
   s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
-  s.wg_queries = s.persistent ? e->pw_B : 0;
-  s.workgroups = s.persistent ? ((uint32_t)Q + e->pw_B - 1) / std::max<uint32_t>(1u, e->pw_B) : 0;
+  s.wg_queries = (e->persist_on || e->persist_dev) ? e->pw_B : 0;
+  s.workgroups = (e->persist_on || e->persist_dev) ? ((uint32_t)Q + e->pw_B - 1) / std::max<uint32_t>(1u, e->pw_B)
+               : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
+  s.search_kernel = e->search_v2 ? 1 : 0;
   return rc;
 }
 
@@ -1637,6 +1688,23 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     s.hops_max = cc.back();
   }
   *out = s;
+  return BANG_OK;
+}
+
+extern "C" int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, uint32_t* fetched, uint32_t* candidates, uint32_t* iterations) {
+  if (!e) return BANG_ERR_ARG;
+  if (!e->allocated || e->Qcur <= 0) { bang_set_error("bang_get_query_counters: no query has run on this allocation"); return BANG_ERR_ARG; }
+  const size_t Q = (size_t)e->Qcur;
+  if (dist_evals || fetched) {
+    std::vector<uint32_t> qs(Q * 2);
+    HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < Q; ++i) { if (dist_evals) dist_evals[i] = qs[2 * i]; if (fetched) fetched[i] = qs[2 * i + 1]; }
+  }
+  if (candidates) HIP_TRY(hipMemcpy(candidates, e->d_cand_cnt, Q * 4, hipMemcpyDeviceToHost));
+  if (iterations) {
+    if (e->search_v2 && e->h_qiters.size() >= Q) memcpy(iterations, e->h_qiters.data(), Q * 4);
+    else memset(iterations, 0, Q * 4);
+  }
   return BANG_OK;
 }
 

@@ -1,0 +1,504 @@
+// bang_search.hip -- the QUERY-RESIDENT search kernel: the whole search loop of a batch (bang_search.cu:569-1068) in ONE launch
+// in which a wavefront owns ONE query at a time from its first iteration to its last and keeps that query's state on chip.
+//
+// What differs from the round-1 persistent kernel (front_kernel<PERSIST> in bang_kernels.hip), and why:
+//  * Ownership is dynamic: a wave that finishes a query pulls the next unstarted one from a device counter.  No workgroup waits
+//    for its slowest query while its other waves idle (round 1: 119 iterations of the slowest block vs a median of 75), and at
+//    most (CUs x waves) queries are alive at a time, so their visited filters (50 KB each) stay within reach of the Infinity Cache.
+//  * The worklist (K3b, :1605-1715), the survivors and every per-query counter live in LDS / registers for the life of the
+//    query: the merge reads and writes no global memory, K4 (:1384-1521) reads the worklist head from LDS, and the only HBM
+//    traffic of an iteration is what the algorithm needs -- the adjacency row, the filter words, the PQ code rows, one
+//    candidate-log word.
+//  * The visited filter is updated with PLAIN stores.  A query's filter is private to its wave, so atomics are only needed for
+//    two lanes of the SAME wave-instruction that hit the same word.  Those are found with a 64-slot claim table in LDS (three
+//    rounds with different hashes); same-word lanes merge their bits there and one lane stores old | bits.  The rare lanes that
+//    lose all three rounds to other words fall back to an atomic OR after the plain stores have drained.  (Round 1 issued
+//    73 M fully scattered atomic ORs per 10 K batch: ~17x below the rate of plain stores of the same shape on MI355X.)
+//  * Both filter words of an id are probed in one round trip: the second word is needed anyway -- for the test when the first
+//    bit is set, for the update when it is not.
+//  * In graph-on-HBM mode the next adjacency row is requested the moment the parent is known, so its latency hides behind the
+//    filter update and the sort/merge.
+//
+// Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
+// canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
+//
+// Reference line numbers: /root/reference/BANG_Base/bang_search.cu.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "bang_c.h"
+#include "bang_internal.h"
+#include "bang_device.h"
+
+struct SearchArgs {
+  bang_search_params p;
+  uint32_t lds_piv_floats;
+  uint32_t wave_words;       // LDS words per wave: worklist (2L + ceil(L/4), rounded to 4) + 144 scratch
+  uint32_t wl_words;         // offset of the scratch inside a wave's region
+};
+
+#define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (key[64] + acc[64]) aliases both
+
+__host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
+__host__ __device__ inline uint32_t search_wave_words(uint32_t L) { return search_wl_words(L) + SRCH_SCRATCH_WORDS; }
+
+__device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5, second half (:1159-1160): set the two filter bits of every survivor -- plain stores, same-word lanes merged in LDS
+// ---------------------------------------------------------------------------------------------------------------------
+// Every lane brings up to two items (word index, bit mask, the word's value as probed in THIS iteration).  All probes of the
+// iteration were issued before this point and nothing was stored in between, so two lanes that hit the same word hold the same
+// old value.  tbl: 128 LDS words private to the wave.  Returns with every item stored, merged into another lane's store, or
+// (pa / pb still set) left for the atomic fallback.
+__device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint32_t* tbl, int lane, bool& pa, uint32_t ia,
+                                              uint32_t ba, uint32_t wa, bool& pb, uint32_t ib, uint32_t bb, uint32_t wb) {
+  uint32_t* key = tbl;
+  uint32_t* acc = tbl + 64;
+  const uint32_t tag_a = (ia << 7) | ((uint32_t)lane << 1), tag_b = (ib << 7) | ((uint32_t)lane << 1) | 1u;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (__ballot(pa || pb) == 0) break;                          // uniform
+    const uint32_t mul = r == 0 ? 0x9E37u : r == 1 ? 0x85EBu : 0xC2B3u;
+    const uint32_t sa = ((ia * mul) >> 9) & 63u, sb = ((ib * mul) >> 9) & 63u;
+    key[lane] = 0xFFFFFFFFu;
+    wave_sync();
+    if (pa) key[sa] = tag_a;
+    if (pb) key[sb] = tag_b;                                      // a later instruction: wins over this lane's own item a
+    wave_sync();
+    const uint32_t ra = key[sa], rb = key[sb];
+    const bool own_a = pa && ra == tag_a, own_b = pb && rb == tag_b;
+    const bool same_a = pa && !own_a && (ra >> 7) == ia, same_b = pb && !own_b && (rb >> 7) == ib;
+    if (own_a) acc[sa] = ba;
+    if (own_b) acc[sb] = bb;
+    wave_sync();
+    if (same_a) (void)__hip_atomic_fetch_or(&acc[sa], ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_or_b32
+    if (same_b) (void)__hip_atomic_fetch_or(&acc[sb], bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    wave_sync();
+    if (own_a) bloom[ia] = wa | acc[sa];
+    if (own_b) bloom[ib] = wb | acc[sb];
+    pa = pa && !(own_a || same_a);
+    pb = pb && !(own_b || same_b);
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K3a + K3b on LDS-resident state (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
+// ---------------------------------------------------------------------------------------------------------------------
+struct WaveLds {
+  float* wd; uint32_t* wi; uint8_t* wv;     // worklist: distances, ids, visited flags (sorted ascending by distance)
+  float* sd; uint32_t* ti;                  // unsorted survivor distances; after ranking: sorted ids (same words)
+  float* td;                                // sorted survivor distances; before the distance stage: compaction scratch
+};
+
+// stable rank of element (d, i) among sd[0, n): #smaller + #equal with a lower index (== the reference's stable merge sort)
+__device__ __forceinline__ uint32_t rank_in(const float* sd, uint32_t n8, float d, uint32_t i) {
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < n8; j += 8) {
+    const float4 o0 = *(const float4*)(sd + j);
+    const float4 o1 = *(const float4*)(sd + j + 4);
+    r += (o0.x < d || (o0.x == d && j + 0 < i)) ? 1u : 0u;
+    r += (o0.y < d || (o0.y == d && j + 1 < i)) ? 1u : 0u;
+    r += (o0.z < d || (o0.z == d && j + 2 < i)) ? 1u : 0u;
+    r += (o0.w < d || (o0.w == d && j + 3 < i)) ? 1u : 0u;
+    r += (o1.x < d || (o1.x == d && j + 4 < i)) ? 1u : 0u;
+    r += (o1.y < d || (o1.y == d && j + 5 < i)) ? 1u : 0u;
+    r += (o1.z < d || (o1.z == d && j + 6 < i)) ? 1u : 0u;
+    r += (o1.w < d || (o1.w == d && j + 7 < i)) ? 1u : 0u;
+  }
+  return r;
+}
+
+// merge of the nb leading sorted survivors into the worklist, in place (every read precedes every write: one wave, LDS in order)
+template <int WLR>
+__device__ __forceinline__ uint32_t merge_in_lds(const WaveLds& s, uint32_t n, uint32_t w_n, uint32_t L, uint32_t mark, int lane) {
+  const float worst = s.wd[w_n - 1];
+  const uint32_t lim = L < n ? L : n;
+  uint32_t nb = lim;                                            // leading survivors with dist < worst (stop at the first >=) :1653-1657
+  {
+    const bool ge = ((uint32_t)lane < lim) && (s.td[lane] >= worst);
+    const uint64_t mk = __ballot(ge);
+    if (mk) nb = (uint32_t)__builtin_ctzll(mk);
+    else if (lim > 64 && s.td[64] >= worst) nb = 64;
+  }
+  const uint32_t room = L - w_n;
+  const uint32_t fill = room < n ? room : n;
+  if (fill > nb) nb = fill;                                     // :1660
+  const uint32_t new_n = (w_n + nb) < L ? (w_n + nb) : L;       // :1662
+  float od[WLR];
+  uint32_t oi[WLR], po[WLR], ov = 0;
+#pragma unroll
+  for (int j = 0; j < WLR; ++j) {
+    const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
+    od[j] = 0.0f; oi[j] = 0; po[j] = 0xFFFFFFFFu;
+    if (k < w_n) { od[j] = s.wd[k]; oi[j] = s.wi[k]; ov |= (uint32_t)s.wv[k] << j; }
+  }
+  uint32_t pn = 0xFFFFFFFFu, pn64 = 0xFFFFFFFFu, idn = 0, idn64 = 0;
+  float dn = 0.0f, dn64 = 0.0f;
+  if ((uint32_t)lane < nb) {                                    // new entries: lower_bound + i :1675-1677
+    dn = s.td[lane]; idn = s.ti[lane];
+    pn = lower_bound_lds(s.wd, w_n, dn) + (uint32_t)lane;
+  }
+  if (nb > 64 && lane == 0) {
+    dn64 = s.td[64]; idn64 = s.ti[64];
+    pn64 = lower_bound_lds(s.wd, w_n, dn64) + 64u;
+  }
+#pragma unroll
+  for (int j = 0; j < WLR; ++j) {                               // old entries: upper_bound + k :1678-1680
+    const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
+    if (k < w_n) po[j] = upper_bound_lds(s.td, nb, od[j]) + k;
+  }
+  wave_sync();
+  if (pn < new_n) { s.wi[pn] = idn; s.wd[pn] = dn; s.wv[pn] = (idn == mark) ? 1 : 0; }
+  if (pn64 < new_n) { s.wi[pn64] = idn64; s.wd[pn64] = dn64; s.wv[pn64] = (idn64 == mark) ? 1 : 0; }
+#pragma unroll
+  for (int j = 0; j < WLR; ++j)
+    if (po[j] < new_n) { s.wi[po[j]] = oi[j]; s.wd[po[j]] = od[j]; s.wv[po[j]] = (((ov >> j) & 1u) || oi[j] == mark) ? 1 : 0; }   // + mark step :1711-1714
+  wave_sync();
+  return new_n;
+}
+
+// sort the n survivors (lane i < 64 holds survivor i, lane 0 also survivor 64) and merge them into the worklist; returns the new length
+__device__ __forceinline__ uint32_t sort_and_merge(const WaveLds& s, uint32_t n, float d0, uint32_t id0, float d1, uint32_t id1,
+                                                   uint32_t iter, uint32_t w_n, uint32_t L, uint32_t medoid, uint32_t mark, int lane) {
+  const float inf = __builtin_inff();
+  s.sd[lane] = ((uint32_t)lane < n) ? d0 : inf;
+  if (lane < 8) s.sd[64 + lane] = (lane == 0 && n > 64) ? d1 : inf;
+  wave_sync();
+  // K3a: stable rank sort.  The padding (+inf) ranks behind every real distance and ties with none.
+  const uint32_t n8 = (n + 7u) & ~7u;
+  uint32_t r0 = 0, r64 = 0;
+  if ((uint32_t)lane < n) r0 = rank_in(s.sd, n8, d0, (uint32_t)lane);
+  if (n > 64) { if (lane == 0) r64 = rank_in(s.sd, n8, d1, 64u); }
+  wave_sync();
+  if ((uint32_t)lane < n) { s.td[r0] = d0; s.ti[r0] = id0; }
+  if (n > 64 && lane == 0) { s.td[r64] = d1; s.ti[r64] = id1; }
+  wave_sync();
+  if (iter == 1) {                                              // :1638-1649
+    const uint32_t new_n = n < L ? n : L;
+    for (uint32_t i = lane; i < new_n; i += WAVE) {
+      const uint32_t id = s.ti[i];
+      s.wi[i] = id; s.wd[i] = s.td[i];
+      s.wv[i] = (id == medoid || id == mark) ? 1 : 0;           // + mark step :1711-1714
+    }
+    wave_sync();
+    return new_n;
+  }
+  const uint32_t wlr = (w_n + WAVE - 1) / WAVE;                 // uniform: registers for the old entries a lane owns
+  if (wlr <= 1) return merge_in_lds<1>(s, n, w_n, L, mark, lane);
+  if (wlr <= 2) return merge_in_lds<2>(s, n, w_n, L, mark, lane);
+  if (wlr <= 4) return merge_in_lds<4>(s, n, w_n, L, mark, lane);
+  return merge_in_lds<8>(s, n, w_n, L, mark, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PSZ, int NDW, bool ALIGNED, int NHI>
+__global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const bang_search_params& p = a.p;
+  float* piv_lds = lds;
+  {
+    // stage the chunk-packed pivot table (query independent) once per workgroup: 16 B per lane, 8 loads in flight per lane
+    const float4* src = (const float4*)p.d_pivots_packed;
+    float4* dst = (float4*)piv_lds;
+    const uint32_t n4 = a.lds_piv_floats >> 2;
+    for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += blockDim.x * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t i = i0 + (uint32_t)j * blockDim.x;
+        v[j] = src[i < n4 ? i : n4 - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t i = i0 + (uint32_t)j * blockDim.x;
+        if (i < n4) dst[i] = v[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+
+  const int lane = lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t nwaves = blockDim.x >> 6;
+  const uint32_t L = p.L, medoid = p.medoid, cap_iter = p.cap_iter;
+  uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
+  WaveLds s;
+  s.wd = (float*)wbase; s.wi = wbase + L; s.wv = (uint8_t*)(wbase + 2 * L);
+  s.sd = (float*)(wbase + a.wl_words); s.ti = wbase + a.wl_words; s.td = (float*)(wbase + a.wl_words + 72);
+  uint32_t* sc = wbase + a.wl_words + 72;          // compaction scratch (== td: dead before the sort)
+  uint32_t* tbl = wbase + a.wl_words;              // filter claim table, 128 words (== sd + td: dead between the stages that use them)
+  const uint32_t total_waves = gridDim.x * nwaves;
+  const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
+  constexpr int SB = (NDW >= 18) ? 6 : 0;          // long rows (70 .. 128 chunks): consumed 6 code dwords (24 chunks) at a time
+
+  // ---- queries of this wave: the first one by position, the following ones from the hand-out counter
+  bool first_q = true;
+  for (;;) {
+    uint32_t q;
+    if (first_q) q = blockIdx.x * nwaves + wave;
+    else {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
+      q = total_waves + uni(t);
+    }
+    first_q = false;
+    if (q >= p.Q) break;
+
+    uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
+    cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q * (NDW * 4 * PSZ));
+    uint32_t w_n = 0, cc = 1, mark = 0x01010101u;      // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
+    uint32_t evals = 0, fetched = 0, iters = 0;
+    if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
+    // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
+    uint32_t cnt_in = p.d_seed[0], x0 = p.d_seed[1 + lane], x1 = p.d_seed[65];
+    bool have_row = true;
+
+    for (uint32_t iter = 1;; ++iter) {
+      const bool first = (iter == 1);
+      iters = iter;
+      // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
+      uint32_t ci = have_row ? uni(cnt_in) : 0u;
+      {
+        const uint32_t cap = p.R + (first ? 1u : 0u);
+        if (ci > cap) ci = cap;
+      }
+      fetched += ci;
+      const bool v0 = (uint32_t)lane < ci;
+      const bool v1 = ci > 64;                               // the 65th id exists in the seed list only (uniform)
+      const uint32_t h0a = hash1(x0), h0b = hash2(x0);
+      uint32_t h1a = 0, h1b = 0, w0a = 0, w0b = 0, w1a = 0, w1b = 0;
+      // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip
+      if (v0) { w0a = ld_bypass_l1(&bloom[h0a >> 5]); w0b = ld_bypass_l1(&bloom[h0b >> 5]); }
+      if (v1) {
+        h1a = hash1(x1); h1b = hash2(x1);
+        if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
+      }
+      const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
+      const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
+      const uint64_t m0 = __ballot(pass0);
+      const uint64_t m1 = __ballot(pass1);
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      const uint32_t n = n0 + (uint32_t)__popcll(m1);
+      // ordered compaction through LDS: survivors keep input order (CANON; the reference emits in atomicAdd order :1161)
+      uint32_t sid0 = 0, sid1 = 0;
+      if (pass0) sc[lanes_below(m0)] = x0;
+      if (pass1) sc[n0] = x1;
+      wave_sync();
+      if ((uint32_t)lane < n) sid0 = sc[lane];
+      if (lane == 0 && n > 64) sid1 = sc[64];
+      wave_sync();
+      evals += n;
+
+      // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
+      float d0 = BIG_DIST, d1 = BIG_DIST;
+      {
+        PqRow<NDW, ALIGNED> row;
+        if ((uint32_t)lane < n) {
+          pq_row_load(row, p.d_codes, p.m, sid0);
+          d0 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
+        }
+        if (n > 64) {                                          // survivor 64 (seed list only), lane 0
+          if (lane == 0) {
+            PqRow<NDW, ALIGNED> r1;
+            pq_row_load(r1, p.d_codes, p.m, sid1);
+            d1 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
+          }
+        }
+      }
+
+      // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ----------------
+      // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
+      const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
+      float bd = elig ? d0 : BIG_DIST;
+      uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
+      uint32_t bid = sid0;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) {
+        const float od = __shfl_xor(bd, off);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+        const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
+        const bool take = (oi != 0xFFFFu) && (bi == 0xFFFFu || od < bd || (od == bd && oi < bi));
+        if (take) { bd = od; bi = oi; bid = oid; }
+      }
+      if (n > 64) {                                            // element 64 can only win with a strictly smaller distance
+        const float e_d = __shfl(d1, 0);
+        const uint32_t e_id = (uint32_t)__shfl((int)sid1, 0);
+        if (e_id != medoid && e_d < BIG_DIST && (bi == 0xFFFFu || e_d < bd)) { bd = e_d; bi = 64; bid = e_id; }
+      }
+      const bool have_best = (bi != 0xFFFFu);
+      if (!have_best) bd = BIG_DIST;
+      bool found = false, from_best = false;
+      uint32_t parent = 0;
+      if (first) {
+        if (have_best) { found = true; parent = bid; from_best = true; }
+      } else {
+        uint32_t w_hit = 0;
+        for (uint32_t base = 0; base < w_n && !found; base += WAVE) {      // first unvisited entry :1425-1439
+          const uint32_t i = base + (uint32_t)lane;
+          const uint64_t mk = __ballot(i < w_n && s.wv[i < w_n ? i : 0] == 0);
+          if (mk) { w_hit = base + (uint32_t)__builtin_ctzll(mk); found = true; }
+        }
+        if (found) {
+          const float wdist = s.wd[w_hit];
+          if (bd < wdist) { parent = bid; from_best = true; }
+          else { parent = s.wi[w_hit]; if (lane == 0) s.wv[w_hit] = 1; }
+        } else if (w_n > 0) {                                  // corner case :1442-1446
+          if (bd < s.wd[w_n - 1]) { found = true; parent = bid; from_best = true; }
+        }
+      }
+      parent = uni(parent);
+      if (found) {
+        if (from_best) mark = parent;
+        if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride + cc] = parent;      // :1451-1458
+        ++cc;
+      }
+
+      // ---- the next adjacency row is requested NOW (graph resident in HBM): it travels while the filter is updated and the
+      // survivors are merged
+      uint32_t n_cnt = 0, n_x0 = 0;
+      if (found && iter < cap_iter) {
+        const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
+        n_cnt = nrow[0];
+        n_x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots
+      }
+
+      // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
+      {
+        bool pa = pass0, pb = pass0;
+        filter_commit(bloom, tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b);
+        const uint64_t left = __ballot(pa || pb || pass1);
+        if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
+          if (pa) (void)__hip_atomic_fetch_or(&bloom[h0a >> 5], 1u << (h0a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pb) (void)__hip_atomic_fetch_or(&bloom[h0b >> 5], 1u << (h0b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pass1) {
+            (void)__hip_atomic_fetch_or(&bloom[h1a >> 5], 1u << (h1a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_or(&bloom[h1b >> 5], 1u << (h1b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+
+      // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
+      if (n > 0 && iter < cap_iter) w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, lane);
+
+      // a query is active while it has a parent or unmerged survivors (CANON 4); the loop ends at the cap (:950-956)
+      if ((!found && n == 0) || iter == cap_iter) break;
+      have_row = found;
+      cnt_in = n_cnt; x0 = n_x0;
+    }
+    if (lane == 0) {
+      p.d_cand_cnt[q] = cc;
+      if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
+      if (p.d_qiters) p.d_qiters[q] = iters;
+    }
+  }
+  if (p.d_ktime) {
+    __syncthreads();
+    if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PSZ, int NDW, bool ALIGNED, int NHI>
+static int launch_inst(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  static bool attr_done[BANG_MAX_DEVICES] = {false};      // per kernel instance AND device
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)search_kernel<PSZ, NDW, ALIGNED, NHI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL((search_kernel<PSZ, NDW, ALIGNED, NHI>), grid, block, lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return BANG_OK;
+}
+
+template <int PSZ, int NDW>
+static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  const bool al = (a.p.m % 4u) == 0;
+  if (a.p.pq_nhi) {
+    // exact-size pivot table: compiled for the two layouts of the BASELINE configs (128 dims in 70 chunks: 58 x 2 + 12 x 1;
+    // 96 dims in 74 chunks: 22 x 2 + 52 x 1)
+    constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
+    if constexpr (NHI != 0) {
+      if ((int)a.p.pq_nhi == NHI && !al) return launch_inst<PSZ, NDW, false, NHI>(a, grid, block, lds, st);
+    }
+    bang_set_error("no search-kernel instance for the exact-size pivot table psz=%u mp=%u nhi=%u", a.p.psz, a.p.mp, a.p.pq_nhi);
+    return BANG_ERR_UNSUPPORTED;
+  }
+  return al ? launch_inst<PSZ, NDW, true, 0>(a, grid, block, lds, st) : launch_inst<PSZ, NDW, false, 0>(a, grid, block, lds, st);
+}
+
+// waves per workgroup that fit beside the pivot table (0: not even one)
+static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
+  const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
+  const size_t per_wave = (size_t)search_wave_words(L) * 4u;
+  const size_t cap = (size_t)160 * 1024;
+  if (piv_bytes + per_wave > cap) return 0;
+  const size_t w = (cap - piv_bytes) / per_wave;
+  return (uint32_t)(w > 16 ? 16 : w);
+}
+
+extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
+  if (psz == 0 || L == 0 || L > BANG_MAX_L) return 0;
+  return (int)waves_that_fit(psz, mp, nhi, L);
+}
+
+extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
+  if (!p) return BANG_ERR_ARG;
+  if (p->Q == 0) return BANG_OK;
+  if (p->R == 0 || p->R > BANG_MAX_R || p->L == 0 || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
+  if (p->psz == 0 || p->mp < p->m || (p->mp & 3u)) { bang_set_error("the search kernel needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
+  if (!p->d_codes || !p->d_pivots_packed || !p->d_qc || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
+      !p->d_next_query || !p->d_graph) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
+  if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
+  if (p->cap_iter == 0 || p->cap_iter > p->L + BANG_EXTRA_ITERS - 1) { bang_set_error("bad iteration cap"); return BANG_ERR_ARG; }
+  SearchArgs a;
+  a.p = *p;
+  a.lds_piv_floats = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
+  a.wl_words = search_wl_words(p->L);
+  a.wave_words = search_wave_words(p->L);
+  uint32_t waves = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L);
+  if (waves == 0) { bang_set_error("pivot table + one wave's worklist do not fit LDS at L=%u", p->L); return BANG_ERR_UNSUPPORTED; }
+  if (p->max_waves && p->max_waves < waves) waves = p->max_waves;
+  // One workgroup per CU at most (the pivot table takes most of the LDS).  A batch smaller than CUs x waves is spread over all
+  // CUs with fewer waves each: a wave's iteration is latency bound, and fewer waves per CU contend less for LDS and L1.
+  const uint32_t cus = (uint32_t)num_cus();
+  uint32_t grid_n = p->Q < cus ? p->Q : cus;
+  if (p->max_wgs && p->max_wgs < grid_n) grid_n = p->max_wgs;
+  {
+    const uint32_t per_wg = (p->Q + grid_n - 1) / grid_n;
+    if (per_wg < waves) waves = per_wg;
+  }
+  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4;
+  const dim3 grid(grid_n), block(waves * WAVE);
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t key = p->psz * 100u + p->mp / 4u;
+  switch (key) {
+    case 108: return launch_al<1, 8>(a, grid, block, lds, st);
+    case 116: return launch_al<1, 16>(a, grid, block, lds, st);
+    case 124: return launch_al<1, 24>(a, grid, block, lds, st);
+    case 132: return launch_al<1, 32>(a, grid, block, lds, st);
+    case 208: return launch_al<2, 8>(a, grid, block, lds, st);
+    case 216: return launch_al<2, 16>(a, grid, block, lds, st);
+    case 218: return launch_al<2, 18>(a, grid, block, lds, st);
+    case 219: return launch_al<2, 19>(a, grid, block, lds, st);
+    case 404: return launch_al<4, 4>(a, grid, block, lds, st);
+    case 408: return launch_al<4, 8>(a, grid, block, lds, st);
+    case 802: return launch_al<8, 2>(a, grid, block, lds, st);
+    case 804: return launch_al<8, 4>(a, grid, block, lds, st);
+    default: bang_set_error("no search-kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
+  }
+}

@@ -67,7 +67,8 @@ int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   
  *   "threads" : host walker threads per lane (>=1)
  *   "device"  : HIP device ordinal
  *   "pq"      : 0 = pivot-stationary fused distance (default when it fits LDS), 1 = LUT path (K1+K2)
- *   "timing"  : 1 = stamp every front-kernel launch in-kernel (s_memrealtime) for bang_get_stats */
+ *   "timing"  : 1 = stamp every front-kernel launch in-kernel (s_memrealtime) for bang_get_stats
+ *   "search"  : graph in HBM: 1 = the query-resident search kernel (bang_k_search), 0 = the round-1 loops, -1 = auto */
 int bang_set_option(bang_engine_t* e, const char* key, long value);
 
 /* bang_load, bang.h:51 / bang_search.cu:138-362 */
@@ -127,8 +128,13 @@ typedef struct {
   uint64_t workgroups;        /* persistent search kernel: workgroups of the launch, 0 otherwise */
   /* expansions (= graph hops = iterations in which the query had a parent) per query: median, 99th percentile, maximum */
   uint64_t hops_p50, hops_p99, hops_max;
+  uint64_t search_kernel;     /* 1: the batch ran on the query-resident search kernel (bang_k_search) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
+/* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
+ * adjacency ids offered to the filter, expanded nodes (candidate-log length) and -- search kernel only, else zeros -- the number
+ * of iterations the query ran.  Test hook: the oracle reports the same four numbers per query. */
+int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, uint32_t* fetched, uint32_t* candidates, uint32_t* iterations);
 
 /* The reference's own C mirror (bang.h:91-100), uint8 only, one process-global engine. */
 int bang_load_c(char* indexfile_path_prefix);
@@ -249,6 +255,37 @@ int bang_k_front(const bang_iter_params* p, void* stream);
  * workgroup ran.  No d_qmap.  BANG_ERR_UNSUPPORTED if the pivot table plus the waves' merge scratch do not fit the 160 KB of LDS. */
 int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
                              unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_local, void* stream);
+
+/* ---- the query-resident search kernel (csrc/bang_search.hip) ----
+ * ONE launch runs the whole search loop of a batch (bang_search.cu:650-958): K5 neighbor_filtering_new (:1140-1165) ->
+ * K2 compute_neighborDist_par (:1201-1241) -> K4 compute_parent1/2 (:1464-1521 / :1384-1459) -> K3a/K3b
+ * compute_BestLSets_par_sort_msort / _merge (:1533-1585 / :1605-1715), iteration after iteration.  A wavefront owns ONE query at a
+ * time from its first iteration to its last (worklist, survivors and counters stay in LDS / registers) and then pulls the next
+ * unstarted query from *d_next_query.  Graph resident in HBM (d_graph); the candidate log feeds bang_k_rerank.
+ * Same per-query results as bang_k_front / bang_k_back iterated by a host loop. */
+typedef struct {
+  uint32_t Q, R, m, L, medoid;
+  uint32_t cap_iter;                   /* last iteration a query may run: L + BANG_EXTRA_ITERS - 1 (bang_search.cu:950) */
+  uint32_t psz, mp, pq_nhi;            /* pivot layout (bang_pq_layout / bang_pack_pivots[_ragged]); psz != 0 */
+  uint32_t max_wgs, max_waves;         /* 0 = one workgroup per CU / as many waves per workgroup as LDS holds (<= 16) */
+  const uint32_t* d_seed;              /* [2 + R + 1] {count, MEDOID, adj(MEDOID)...} */
+  const uint8_t* d_codes;              /* [N][m] + 256 B slack */
+  const float* d_pivots_packed;
+  const float* d_qc;                   /* [Q][mp*psz] centred queries (bang_k_center_queries) */
+  const uint8_t* d_graph;              /* [N][entry_len] */
+  uint64_t entry_len;
+  uint32_t vec_bytes;
+  uint32_t* d_bloom;                   /* [Q][BANG_BF_WORDS] visited filters, zeroed (bang_init) */
+  uint32_t* d_cand_ids;                /* [Q][L + 50] out: expanded nodes in expansion order, [0] = MEDOID */
+  uint32_t* d_cand_cnt;                /* [Q] out */
+  uint32_t* d_qstats;                  /* [Q][2] out {distance evaluations, adjacency ids offered to the filter} or NULL */
+  uint32_t* d_qiters;                  /* [Q] out: iterations the query ran, or NULL */
+  uint32_t* d_next_query;              /* [1] hand-out counter, zeroed before the launch */
+  unsigned long long* d_ktime;         /* [workgroups][2] {start, end} s_memrealtime stamps (100 MHz), or NULL */
+} bang_search_params;
+int bang_k_search(const bang_search_params* p, void* stream);
+/* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */
+int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
 
 /* Fused K3a + K3b: compute_BestLSets_par_sort_msort (bang_search.cu:1533-1585) ->
  * compute_BestLSets_par_merge (:1605-1715), one wavefront per query. */

@@ -193,3 +193,59 @@ def test_query_smaller_than_allocation(request, libbang, small_f32):
             e.init(17)
             ids, dists = e.query(q[:17])
             assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("L", [10, 37, 64, 152, 300, 512])
+def test_search_kernel_matches_oracle_per_query(request, libbang, fixture, L):
+    """Graph in HBM, the query-resident search kernel ("search"=1): a wave owns one query from its first to its last
+    iteration, worklist and survivors stay in LDS, the filter is updated with plain stores.  Ids, distances and the PER-QUERY
+    counters (iterations, expanded nodes, distance evaluations, ids offered to the filter) equal the oracle's; the round-1
+    loops ("search"=0) return the same bits."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=1, search=1, timing=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, L)
+        e.alloc(q.shape[0])
+        for _ in range(2):
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            st = e.stats()
+            assert st["search_kernel"] == 1 and st["persistent"] == 1 and st["front_launches"] == 1
+            assert np.array_equal(ids, ids_o)
+            assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(q.shape[0]), st_o)
+            assert st["iterations"] == int(st_o[:, 0].max()) and 0 < st["front_ms"]
+        e.free()
+        e.unload()
+    ids0, dists0, st0 = _run_engine(ix, q, 10, L, graph=1, search=0)
+    assert st0["search_kernel"] == 0
+    assert np.array_equal(ids0, ids_o) and np.array_equal(dists0.view(np.uint32), dists_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("Q", [1, 2, 63, 700])
+def test_search_kernel_batch_sizes_and_handout(request, libbang, small_u8, Q):
+    """Fewer queries than waves (spread over the CUs), and more queries than resident waves on a small grid (max 2 workgroups
+    via BANG_SEARCH_MAX_WGS: every wave pulls follow-up queries from the hand-out counter)."""
+    import os
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    qq = np.ascontiguousarray(np.tile(q, ((Q + q.shape[0] - 1) // q.shape[0], 1))[:Q])
+    ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 48, with_stats=True)
+    for max_wgs in ("0", "2"):
+        os.environ["BANG_SEARCH_MAX_WGS"] = max_wgs
+        try:
+            with bang_amd.Engine(ix.dtype, graph=1, search=1) as e:
+                e.load_index(ix)
+                e.set_searchparams(10, 48)
+                e.alloc(Q)
+                e.init(Q)
+                ids, dists = e.query(qq)
+                assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+                assert np.array_equal(e.query_counters(Q), st_o)
+        finally:
+            os.environ.pop("BANG_SEARCH_MAX_WGS", None)
