@@ -58,7 +58,7 @@ class Stats(C.Structure):
                 ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64),
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
-                ("search_kernel", C.c_uint64)]
+                ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64)]
 
 
 def lib_path() -> str:

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -179,7 +180,9 @@ struct bang_engine {
   uint64_t medoid = 0, entry_len = 0;
   uint32_t D = 0, R = 0, N = 0, m = 0;
   const uint8_t* graph = nullptr;   // host
-  uint8_t* graph_owned = nullptr;
+  uint8_t* graph_owned = nullptr;   // private copy (fread), or
+  void* graph_map = nullptr;        // the graph file mapped MAP_SHARED: N processes of one node share ONE copy in the page cache
+  size_t graph_map_len = 0;
   uint8_t* d_graph = nullptr;       // BANG_GRAPH_DEVICE
   uint8_t* d_codes = nullptr;
   bool codes_owned = false;
@@ -244,9 +247,23 @@ struct bang_engine {
                                        // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
   bool persist_on = false;             // resolved at bang_alloc: the host-paced persistent kernel is used for this allocation
   bool persist_dev = false;            // resolved at bang_alloc: device-graph mode runs as ONE self-paced persistent kernel
+  int numa_opt = -1;                   // host-graph mode: pin the walker threads (and the caller for the duration of a query) to the CPUs
+                                       // of the GPU's NUMA node: 1 / 0, -1 = auto (on when the node is known and has CPUs we may use)
+  cpu_set_t numa_cpus;                 // resolved at bang_alloc
+  bool numa_on = false;
+  int numa_node = -1;
   int search_opt = -1;                 // device-graph mode: 1 = the query-resident search kernel (bang_search.hip), 0 = the round-1 loops,
                                        // -1 = auto (1 where the pivot table leaves LDS for at least 4 waves' worklists)
-  bool search_v2 = false;              // resolved at bang_alloc
+  bool search_v2 = false;              // resolved at bang_alloc: graph in HBM, self-paced form
+  bool search_host = false;            // resolved at bang_alloc: graph in host RAM, the host-paced form of the same kernel (BAR mode)
+  uint32_t sv_G = 0, sv_W = 0, sv_C = 1;   // its grid for the running query: workgroups, waves per workgroup, query contexts per wave
+  uint32_t sv_GS = 8, sv_NG = 0;           // waves per pacing group; pacing groups = workgroups x groups per workgroup x contexts
+  uint32_t* d_srows = nullptr;         // fine-grained device memory [2*256*16][64]: adjacency ids per slot, written through the BAR
+  uint32_t* d_sctl = nullptr;          // fine-grained device memory [2*256][16]: control line per pacing group {go, 16 count bytes}
+  uint32_t* h_pub_q = nullptr;         // mapped pinned [256][16]: query | row wanted << 31 per slot (vectors shipped by the walker)
+  uint32_t* h_pub_c = nullptr;         //                          candidate index per slot
+  uint32_t* d_pub_q = nullptr;         // device aliases
+  uint32_t* d_pub_c = nullptr;
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
   std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
@@ -435,12 +452,46 @@ void unload_index(bang_engine* e) {
   e->vec_on_device = false;
   free(e->graph_owned);
   e->graph_owned = nullptr;
+  if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
+  e->graph_map = nullptr; e->graph_map_len = 0;
   e->graph = nullptr;
   e->loaded = false;
   e->graph_mode = e->graph_opt;
 }
 
 void stop_threads(bang_engine* e);
+
+// CPUs of the NUMA node the GPU hangs off, intersected with what this process may use.  The walker threads read the host graph
+// and store into the GPU's BAR: on the far socket both cross the inter-socket fabric.
+bool gpu_numa_cpus(int device, cpu_set_t* out, int* node_out) {
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return false;
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  int node = -1;
+  if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  if (node < 0) return false;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  char list[4096] = "";
+  if (!fgets(list, sizeof(list), f)) { fclose(f); return false; }
+  fclose(f);
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+  for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int n = sscanf(tok, "%d-%d", &a, &b);
+    if (n == 1) b = a;
+    if (n >= 1) for (int c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &want);
+  }
+  if (CPU_COUNT(&want) == 0) return false;
+  *out = want;
+  *node_out = node;
+  return true;
+}
 
 void free_batch(bang_engine* e) {
   stop_threads(e);
@@ -467,8 +518,11 @@ void free_batch(bang_engine* e) {
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
   dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
-  dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_qiters);
+  dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_qiters); dfree(e->d_srows); dfree(e->d_sctl);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
+  if (e->h_pub_q) (void)hipHostFree(e->h_pub_q);
+  if (e->h_pub_c) (void)hipHostFree(e->h_pub_c);
+  e->h_pub_q = e->h_pub_c = e->d_pub_q = e->d_pub_c = nullptr;
   if (e->h_fp) (void)hipHostFree(e->h_fp);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_done) (void)hipHostFree(e->h_done);
@@ -556,20 +610,36 @@ int load_files(bang_engine* e, const char* prefix) {
     const size_t gsize = (size_t)ftell(fg);
     fseek(fg, 0, SEEK_SET);
     if (gsize < (size_t)e->N * e->entry_len) { bang_set_error("graph file too small"); rc = BANG_ERR_IO; break; }
-    // the walker reads one random entry per expanded node: ask for transparent huge pages (a 4 KB-page table walk per entry
-    // otherwise); free() releases posix_memalign memory, and the hint is harmless where THP is off
+    // The graph (+ vectors) stays in host RAM (:312-328).  It is MAPPED, shared and read-only, not copied: the ranks of a
+    // multi-GPU job (one process per GPU) then walk ONE copy in the page cache instead of one 388 GB copy each.  MAP_POPULATE
+    // reads the file in at load time, as the reference's fread does.  BANG_GRAPH_MMAP=0 (or a failing mmap) falls back to a
+    // private copy, which can ask for transparent huge pages (the walker reads one random entry per expanded node).
     {
-      void* gp = nullptr;
-      if (posix_memalign(&gp, (size_t)2 << 20, gsize) != 0) gp = nullptr;
-      e->graph_owned = (uint8_t*)gp;
-      if (gp) (void)madvise(gp, gsize, MADV_HUGEPAGE);
+      static const bool want_map = !(getenv("BANG_GRAPH_MMAP") && atoi(getenv("BANG_GRAPH_MMAP")) == 0);
+      void* mp = want_map ? mmap(nullptr, gsize, PROT_READ, MAP_SHARED | MAP_POPULATE, fileno(fg), 0) : MAP_FAILED;
+      if (mp != MAP_FAILED) {
+        e->graph_map = mp; e->graph_map_len = gsize;
+        (void)madvise(mp, gsize, MADV_RANDOM);
+        e->graph = (const uint8_t*)mp;
+      } else {
+        void* gp = nullptr;
+        if (posix_memalign(&gp, (size_t)2 << 20, gsize) != 0) gp = nullptr;
+        e->graph_owned = (uint8_t*)gp;
+        if (gp) (void)madvise(gp, gsize, MADV_HUGEPAGE);
+        if (!e->graph_owned) { printf("Error.. Malloc failed for Graph Index.\n"); bang_set_error("malloc(%zu) failed", gsize); rc = BANG_ERR_NOMEM; break; }
+        if (!read_exact(fg, e->graph_owned, gsize)) { bang_set_error("short graph file"); rc = BANG_ERR_IO; break; }
+        e->graph = e->graph_owned;
+      }
     }
-    if (!e->graph_owned) { printf("Error.. Malloc failed for Graph Index.\n"); bang_set_error("malloc(%zu) failed", gsize); rc = BANG_ERR_NOMEM; break; }
-    if (!read_exact(fg, e->graph_owned, gsize)) { bang_set_error("short graph file"); rc = BANG_ERR_IO; break; }
-    e->graph = e->graph_owned;
   } while (0);
   fclose(fp); fclose(fc); fclose(fg); fclose(fm);
-  if (rc != BANG_OK) { free(e->graph_owned); e->graph_owned = nullptr; e->graph = nullptr; return rc; }
+  if (rc != BANG_OK) {
+    free(e->graph_owned); e->graph_owned = nullptr;
+    if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
+    e->graph_map = nullptr; e->graph_map_len = 0;
+    e->graph = nullptr;
+    return rc;
+  }
   rc = upload_index(e, codes.data(), nullptr, pivots.data(), centroid.data(), chunk_off.data());
   if (rc != BANG_OK) unload_index(e);
   return rc;
@@ -754,11 +824,128 @@ void pwalk(bang_engine* e, Lane& ln, int t, int T) {
   while (cur < max_iter && !ln.pw_max_iter.compare_exchange_weak(cur, max_iter, std::memory_order_relaxed)) {}
 }
 
+// Host-paced search kernel (bang_search.hip, HOST form): walker thread t of T serves the workgroups [G*t/T, G*(t+1)/T) first and any
+// other workgroup when none of those is waiting.  A workgroup publishes the parents of its <= 16 waves (one 64-byte line) and then
+// its round number; the thread fetches those parents' graph entries -- adjacency rows into the waves' slots of d_stage through the
+// BAR, full-precision vectors into the vector log if they are not resident in HBM -- and releases the workgroup into its next
+// round by storing the round number into its pacing word.
+void swalk(bang_engine* e, Lane& ln, int t, int T) {
+  const uint32_t G = e->sv_NG, W = 16;                     // pacing groups (workgroups x wave groups x contexts), up to 16 slots each
+  const uint32_t w0 = (uint32_t)((uint64_t)G * (uint32_t)t / (uint32_t)T), w1 = (uint32_t)((uint64_t)G * (uint32_t)(t + 1) / (uint32_t)T);
+  constexpr uint32_t CLAIM = 0x80000000u, FIN = 0xFFFFFFFFu;
+  std::atomic<uint32_t>* expect = ln.pw_expect.get();      // per group: the round whose parents are awaited (< CLAIM); 0 = finished
+  volatile uint32_t* done = e->h_done;
+  uint32_t* ctl = e->d_sctl;                               // device memory, written through the BAR (write-combining)
+  const uint32_t* parents = e->h_parents;
+  const size_t vb = vec_bytes(e);
+  const uint64_t elen = e->entry_len;
+  const uint8_t* graph = e->graph;
+  const bool ship_vec = !e->vec_on_device;
+  uint8_t* fp = ship_vec ? (e->fp_direct ? e->d_fp : e->h_fp) : nullptr;
+  const uint32_t R = e->R, cstride = e->cand_stride;
+  const uint64_t pf0 = ship_vec ? 0 : (vb & ~(uint64_t)63);  // resident vectors: only the adjacency part of an entry is touched
+  uint64_t bytes = 0;
+  auto t_last = Clock::now();
+  uint32_t idle = 0;
+  bool served_unfenced = false;
+  static const bool prof = getenv("BANG_WALK_PROF") != nullptr;      // diagnostic: time spent serving vs polling, per thread
+  uint64_t prof_serve = 0, prof_n = 0, prof_rows = 0, prof_t0 = prof ? __rdtsc() : 0, prof_ts = 0;
+  auto try_serve = [&](uint32_t w) -> bool {
+    uint32_t it = expect[w].load(std::memory_order_relaxed);
+    if (it == 0 || (it & CLAIM)) return false;
+    const uint32_t d = done[(size_t)w * 16];
+    if (d != it && d != FIN) return false;
+    if (!expect[w].compare_exchange_strong(it, it | CLAIM, std::memory_order_acquire)) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (prof) prof_ts = __rdtsc();
+    if (d == FIN) {
+      expect[w].store(0, std::memory_order_release);
+      ln.pw_remaining.fetch_sub(1, std::memory_order_acq_rel);
+      return true;
+    }
+    const uint32_t* par = parents + (size_t)w * 16;
+    for (uint32_t i = 0; i < W; ++i) {
+      const uint32_t p_ = par[i];
+      if (p_ < BANG_IDLE_PARENT) {
+        const uint8_t* ent = graph + (uint64_t)p_ * elen;
+        for (uint64_t o = pf0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+      }
+    }
+    uint32_t counts[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < W; ++i) {
+      const uint32_t p_ = par[i];
+      if (p_ >= BANG_IDLE_PARENT) continue;
+      const uint8_t* ent = graph + (uint64_t)p_ * elen;
+      bool want_row = true;
+      if (ship_vec) {
+        const uint32_t qw = e->h_pub_q[(size_t)w * 16 + i], c = e->h_pub_c[(size_t)w * 16 + i];
+        want_row = (qw >> 31) != 0;
+        memcpy(fp + ((size_t)(ln.q0 + (qw & 0x7FFFFFFFu)) * cstride + c) * vb, ent, vb);      // :796-798
+        bytes += vb;
+      }
+      if (want_row) {
+        uint32_t* srow = e->d_srows + ((size_t)w * 16 + i) * 64;       // 256-byte aligned: whole 64-byte lines, one PCIe write each
+        uint32_t deg;
+        memcpy(&deg, ent + vb, 4);                                      // :801
+        if (deg > R) deg = R;
+        const size_t nbytes = std::min<size_t>(((size_t)deg * 4 + 63) & ~(size_t)63, (size_t)R * 4);   // ids beyond `deg` are never read
+        memcpy(srow, ent + vb + 4, nbytes);                             // :809-810
+        counts[i >> 2] |= deg << (8 * (i & 3u));
+        bytes += nbytes;
+      }
+    }
+    _mm_sfence();                                                       // rows before the control line
+    {
+      // one full 64-byte line {round number, 16 count bytes, 0...}: written whole, so the write-combining buffer goes out at once
+      uint32_t* cl = ctl + (size_t)w * 16;
+      cl[1] = counts[0]; cl[2] = counts[1]; cl[3] = counts[2]; cl[4] = counts[3];
+      for (int z = 5; z < 16; ++z) cl[z] = 0;
+      cl[0] = it;
+      bytes += 64;
+    }
+    served_unfenced = true;
+    expect[w].store(it + 1, std::memory_order_release);
+    if (prof) { prof_serve += __rdtsc() - prof_ts; ++prof_n; for (uint32_t i = 0; i < W; ++i) prof_rows += par[i] < BANG_IDLE_PARENT; }
+    return true;
+  };
+  while (ln.pw_remaining.load(std::memory_order_acquire) != 0) {
+    bool progress = false;
+    for (uint32_t w = w0; w < w1; ++w) progress |= try_serve(w);
+    if (!progress) {
+      for (uint32_t k = 0; k + (w1 - w0) < G; ++k) {
+        const uint32_t w = (w1 + k) % G;
+        if (try_serve(w)) { progress = true; break; }
+      }
+    }
+    if (served_unfenced) { _mm_sfence(); served_unfenced = false; }   // nothing lingers in a write-combining buffer while we poll
+    if (progress) { idle = 0; continue; }
+    _mm_pause();
+    if ((++idle & 0xFFFF) == 0) {
+      if (idle == 0x10000) t_last = Clock::now();
+      else if (ms_since(t_last) > BANG_HOST_WALK_TIMEOUT_MS || ln.pw_error.load(std::memory_order_relaxed)) {
+        ln.pw_error.store(1);
+        for (uint32_t w = 0; w < G; ++w) ctl[(size_t)w * 16] = 0xFFFFFFFFu;
+        _mm_sfence();
+        break;
+      }
+      std::this_thread::yield();
+    }
+  }
+  if (bytes) ln.h2d_bytes.fetch_add(bytes, std::memory_order_relaxed);
+  if (prof) {
+    const uint64_t tot = __rdtsc() - prof_t0;
+    fprintf(stderr, "[walk] thread %d/%d: %llu services, %llu rows, serving %.1f%% of %.2f Mcycles, %.0f cycles/service, %.0f cycles/row\n", t, T,
+            (unsigned long long)prof_n, (unsigned long long)prof_rows, 100.0 * (double)prof_serve / (double)tot, (double)tot * 1e-6,
+            prof_n ? (double)prof_serve / (double)prof_n : 0.0, prof_rows ? (double)prof_serve / (double)prof_rows : 0.0);
+  }
+}
+
 // helper thread t (1..T-1) of a lane's walker team
 // `seen` = the lane's job epoch at the time the thread was CREATED (captured by the creator: reading it here
 // would race with a first job posted before this thread gets to run, and that job would never be done)
 void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
   Pool& pool = e->pool;
+  if (e->numa_on) (void)sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus);
   for (;;) {
     // Batches usually follow each other within a millisecond or two (bang_init in between): keep spinning for a grace period
     // before parking on the condition variable -- waking eleven parked threads at the start of every batch costs 50-100 us at
@@ -783,6 +970,8 @@ void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
         seen = ep;
         if (ln->job_kind == 1) {
           pwalk(e, *ln, t, T);
+        } else if (ln->job_kind == 2) {
+          swalk(e, *ln, t, T);
         } else {
           uint32_t i0, i1, a = 0, np = 0;
           slice_of(*ln, t, T, &i0, &i1);
@@ -863,6 +1052,17 @@ int wait_flag(bang_engine* e, Lane& ln, uint32_t value) {
   std::atomic_thread_fence(std::memory_order_acquire);
   ln.sync_ms += ms_since(t0);
   return BANG_OK;
+}
+
+// diagnostic build (-DBANG_SEARCH_PHASE_PROF): per-iteration phase times of wave 0 of every workgroup, slots [8..15] of its record
+static void print_phase_prof(const std::vector<unsigned long long>& pr, uint32_t G) {
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t w = 0; w < G; ++w) for (int k = 0; k < 8; ++k) a[k] += (double)pr[(size_t)w * 16 + 8 + k];
+  if (a[7] <= 0) return;
+  const double n = a[7];
+  fprintf(stderr, "[search] phases of an iteration (wave 0 of %u workgroups, %.0f iterations each): row arrival + loop %.2f us, hashes + probes %.2f, "
+                  "compaction %.2f, filter update %.2f, code rows + distances %.2f, parent %.2f, publish + sort/merge %.2f\n", G, n / G,
+          a[0] * 0.01 / n, a[1] * 0.01 / n, a[2] * 0.01 / n, a[3] * 0.01 / n, a[4] * 0.01 / n, a[5] * 0.01 / n, a[6] * 0.01 / n);
 }
 
 static int g_dbg = -1;
@@ -951,10 +1151,91 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       sp.max_wgs = v1 ? (uint32_t)std::max(0, atoi(v1)) : (uint32_t)std::max(0, env_wgs);
       sp.max_waves = (uint32_t)std::max(0, env_waves);
     }
+    static const bool kprof_d = getenv("BANG_SEARCH_PROF") != nullptr;   // diagnostic build only (-DBANG_SEARCH_PHASE_PROF)
+    unsigned long long* d_prof = nullptr;
+    const uint32_t Gd = (uint32_t)std::min<int>((int)ln.nq, bang_num_cus());
+    if (kprof_d) { LANE_HIP(hipMalloc((void**)&d_prof, (size_t)Gd * 128)); LANE_HIP(hipMemsetAsync(d_prof, 0, (size_t)Gd * 128, ln.s_main)); sp.d_prof = d_prof; }
     ENQ_BEGIN();
     BANG_TRY(bang_k_search(&sp, ln.s_main));
     ENQ_END();
     ++ln.front_launches;
+    if (d_prof) {
+      std::vector<unsigned long long> pr((size_t)Gd * 16);
+      (void)hipStreamSynchronize(ln.s_main);
+      (void)hipMemcpy(pr.data(), d_prof, pr.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(d_prof);
+      print_phase_prof(pr, Gd);
+    }
+    iter = cap_iter;                                                         // refined from the per-query counts below
+  } else if (e->search_host) {
+    // graph in host RAM: ONE launch of the host-paced form; its workgroups are served round by round by the walker team
+    uint32_t G = 0, W = 0;
+    {
+      const char* v1 = getenv("BANG_SEARCH_MAX_WGS");
+      const char* v2 = getenv("BANG_SEARCH_MAX_WAVES");
+      const char* v3 = getenv("BANG_SEARCH_CTX");
+      const char* v4 = getenv("BANG_SEARCH_GS");
+      uint32_t C = v3 ? (uint32_t)std::max(0, atoi(v3)) : 0u, GS = v4 ? (uint32_t)std::max(0, atoi(v4)) : 0u;
+      BANG_TRY(bang_search_geometry(e->psz, e->mp, e->pq_nhi, (uint32_t)e->L, ln.nq, v1 ? (uint32_t)std::max(0, atoi(v1)) : 0u,
+                                    v2 ? (uint32_t)std::max(0, atoi(v2)) : 0u, 1, &G, &W, &C, &GS));
+      e->sv_C = C; e->sv_GS = GS;
+      e->sv_NG = G * ((W + GS - 1) / GS) * C;
+      if (e->sv_NG > 8 * KT_WGS) { bang_set_error("search kernel: %u pacing groups exceed the pacing buffers", e->sv_NG); return BANG_ERR_ARG; }
+    }
+    e->sv_G = G; e->sv_W = W;
+    const uint32_t NG = e->sv_NG;                                              // pacing groups
+    for (size_t i = 0; i < (size_t)NG * 16; ++i) e->h_parents[i] = BANG_NO_PARENT;
+    ln.pw_groups = NG;
+    ln.pw_error.store(0);
+    for (uint32_t w = 0; w < NG; ++w) ln.pw_expect[w].store(1u, std::memory_order_relaxed);
+    ln.pw_remaining.store(NG, std::memory_order_release);
+    for (uint32_t w = 0; w < NG; ++w) { e->h_done[(size_t)w * 16] = 0; e->d_sctl[(size_t)w * 16] = 0; }
+    _mm_sfence();
+    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
+    bang_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.Q = ln.nq; sp.R = e->R; sp.m = e->m; sp.L = (uint32_t)e->L; sp.medoid = (uint32_t)e->medoid; sp.cap_iter = cap_iter;
+    sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
+    sp.max_wgs = G; sp.max_waves = W; sp.nctx = e->sv_C; sp.group_waves = e->sv_GS;
+    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
+    sp.d_graph = nullptr; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
+    sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
+    sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1;
+    sp.d_ktime = ktime_slot(e, ln);
+    sp.d_rows = e->d_srows; sp.d_ctl = e->d_sctl; sp.h_done = e->h_done_dev; sp.h_parents = e->d_parents_map;
+    sp.h_pub_q = e->d_pub_q; sp.h_pub_c = e->d_pub_c; sp.ship_vectors = e->vec_on_device ? 0u : 1u;
+    static const bool kprof = getenv("BANG_SEARCH_PROF") != nullptr;     // diagnostic: phase times of the half-rounds (stderr)
+    unsigned long long* d_prof = nullptr;
+    if (kprof) { LANE_HIP(hipMalloc((void**)&d_prof, (size_t)G * 128)); LANE_HIP(hipMemsetAsync(d_prof, 0, (size_t)G * 128, ln.s_main)); sp.d_prof = d_prof; }
+    BANG_TRY(bang_k_search(&sp, ln.s_main));
+    ++ln.front_launches;
+    const auto t0 = Clock::now();
+    const int T = 1 + (int)ln.helpers.size();
+    ln.job_kind = 2;
+    if (T > 1) {
+      ln.pending.store((uint32_t)(T - 1), std::memory_order_relaxed);
+      ln.epoch.fetch_add(1, std::memory_order_release);
+    }
+    swalk(e, ln, 0, T);
+    if (T > 1) while (ln.pending.load(std::memory_order_acquire) != 0) _mm_pause();
+    ln.walker_ms += ms_since(t0);
+    if (ln.pw_error.load()) { bang_set_error("timeout waiting for the search kernel"); (void)hipStreamSynchronize(ln.s_main); return BANG_ERR_HIP; }
+    if (d_prof) {
+      std::vector<unsigned long long> pr((size_t)G * 16);
+      (void)hipStreamSynchronize(ln.s_main);
+      (void)hipMemcpy(pr.data(), d_prof, pr.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(d_prof);
+      print_phase_prof(pr, G);
+      double a[5] = {0, 0, 0, 0, 0};
+      for (uint32_t w = 0; w < G; ++w) for (int k = 0; k < 5; ++k) a[k] += (double)pr[(size_t)w * 16 + k];
+      const double n = a[4] > 0 ? a[4] : 1;
+      fprintf(stderr, "[search] %u workgroups x %u waves x %u contexts, %u waves per pacing group: %.0f half-rounds per group; per half-round: wait for rows %.2f us, "
+                      "front (to the publish barrier) %.2f us, publish %.2f us, sort/merge %.2f us\n", G, W, e->sv_C, e->sv_GS, a[4] / G,
+              a[0] * 0.01 / n, a[1] * 0.01 / n, a[2] * 0.01 / n, a[3] * 0.01 / n);
+    }
+    if (!e->fp_direct && !e->vec_on_device)     // vectors staged in pinned memory: one copy of this lane's part of the log
+      LANE_HIP(hipMemcpyAsync(e->d_fp + (size_t)ln.q0 * e->cand_stride * vb, e->h_fp + (size_t)ln.q0 * e->cand_stride * vb,
+                              (size_t)ln.nq * e->cand_stride * vb, hipMemcpyHostToDevice, ln.s_main));
     iter = cap_iter;                                                         // refined from the per-query counts below
   } else if (e->persist_dev) {
     // graph resident in HBM: the whole search is ONE self-paced launch, no host involvement until the re-rank
@@ -1088,6 +1369,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       BANG_TRY(bang_k_rerank_range(e->d_vecs, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, nullptr, e->d_cand_cnt,
                                    e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k, dim_adjust, e->d_ids_out,
                                    e->d_dists_out, ln.s_main));
+    else if (e->search_host)
+      BANG_TRY(bang_k_rerank_byquery(e->d_fp, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, e->d_cand_cnt,
+                                     e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k, dim_adjust, e->d_ids_out,
+                                     e->d_dists_out, ln.s_main));
     else
       BANG_TRY(bang_k_rerank_range(e->d_fp, vb, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids, e->d_cand_row,
                                    e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k,
@@ -1099,7 +1384,8 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
   if (persist || e->persist_dev) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt, 8, hipMemcpyDeviceToHost, ln.s_main));
-  if (e->search_v2) LANE_HIP(hipMemcpyAsync(e->h_qiters.data() + ln.q0, e->d_qiters + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main));
+  if (e->search_host) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
+  if (e->search_v2 || e->search_host) LANE_HIP(hipMemcpyAsync(e->h_qiters.data() + ln.q0, e->d_qiters + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main));
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
@@ -1111,7 +1397,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                        pr[7], pr[0] * 0.01 / pr[7], pr[1] * 0.01 / pr[7], pr[2] * 0.01 / pr[7], pr[3] * 0.01 / pr[7], pr[4] * 0.01 / pr[7]);
   }
   if (e->persist_dev && pw_stats[1]) ln.iterations = pw_stats[1];
-  if (e->search_v2) {
+  if (e->search_v2 || e->search_host) {
     uint32_t mx = 0;
     for (uint32_t i = 0; i < ln.nq; ++i) mx = std::max(mx, e->h_qiters[ln.q0 + i]);
     ln.iterations = mx;
@@ -1136,6 +1422,7 @@ void lane_job(bang_engine* e, Lane& ln) {
 
 void lane_thread_main(bang_engine* e, Lane* ln) {
   Pool& pool = e->pool;
+  if (e->numa_on) (void)sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus);
   uint64_t seen = 0;
   for (;;) {
     {
@@ -1209,6 +1496,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_COMPACT")) e->compact = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = std::min(1, std::max(-1, atoi(v)));
+  if (const char* v = getenv("BANG_NUMA")) e->numa_opt = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_SEARCH")) e->search_opt = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
@@ -1238,7 +1526,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   if (e->loaded && (k == "graph" || k == "device" || k == "pq" || k == "pq_ragged" || k == "vectors")) {
     bang_set_error("option %s must be set before bang_load", key); return BANG_ERR_ARG;
   }
-  if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "search" || k == "timing" || k == "front_wgs")) {
+  if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "search" || k == "numa" || k == "timing" || k == "front_wgs")) {
     bang_set_error("option %s must be set before bang_alloc", key); return BANG_ERR_ARG;
   }
   if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE && value != BANG_GRAPH_AUTO) return BANG_ERR_ARG; e->graph_mode = e->graph_opt = (int)value; }
@@ -1253,6 +1541,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "stagger_us") { if (value < 0) return BANG_ERR_ARG; e->stagger_us = (int)value; }
   else if (k == "compact") { e->compact = value ? 1 : 0; }
   else if (k == "persistent") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->persistent = (int)value; }
+  else if (k == "numa") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->numa_opt = (int)value; }
   else if (k == "search") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->search_opt = (int)value; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
@@ -1322,6 +1611,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
   const size_t vb = vec_bytes(e);
   const bool dev_graph = (e->graph_mode == BANG_GRAPH_DEVICE);
+  const size_t slots_cap = std::max<size_t>(nq, 8 * 16 * KT_WGS);   // rows / parent words: one per query, or one per context slot of the search kernel
   if (e->stage_zero_copy < 0) {                          // CPU-writable device memory (large BAR)?
     int large_bar = 0;
     int dev_id = 0;
@@ -1334,7 +1624,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   // launch (no kernel boundary between two reads of a row) could be served a stale line.  No fine-grained memory -> no BAR mode.
   e->stage_local = false;
   if (!dev_graph && e->stage_mode_eff == 2) {
-    if (hipExtMallocWithFlags((void**)&e->d_stage, std::max<size_t>(nq * BANG_STAGE_STRIDE * 4, 16), hipDeviceMallocFinegrained) == hipSuccess) {
+    if (hipExtMallocWithFlags((void**)&e->d_stage, slots_cap * BANG_STAGE_STRIDE * 4, hipDeviceMallocFinegrained) == hipSuccess) {
       e->stage_local = true;
     } else {
       (void)hipGetLastError();
@@ -1367,6 +1657,17 @@ static int alloc_buffers(bang_engine* e, int Q) {
       e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
     }
   }
+  // graph in host RAM: the host-paced form of the same kernel, where the walker can write device memory (BAR mode)
+  e->search_host = false;
+  if (!dev_graph && persist_want && e->use_flag && e->stage_mode_eff == 2 && e->search_opt != 0 && e->psz != 0) {
+    const int w_pad = bang_search_supported(e->psz, e->mp, 0, (uint32_t)e->L);
+    const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
+    if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
+      e->search_host = true;
+      e->persist_on = false;
+      e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
+    }
+  }
   e->fp_direct = false;
   if (e->persist_on || e->persist_dev) {
     const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
@@ -1395,26 +1696,41 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
   BANG_TRY(dmalloc(&e->d_parents_dev, nq));
-  if (e->search_v2) { BANG_TRY(dmalloc(&e->d_qiters, nq)); e->h_qiters.assign(nq, 0); }
+  if (e->search_v2 || e->search_host) { BANG_TRY(dmalloc(&e->d_qiters, nq)); e->h_qiters.assign(nq, 0); }
   if (dev_graph) {
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {
     BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
     if (e->vec_on_device) {
       e->d_fp = nullptr;                                                     // the re-rank reads d_vecs
-    } else if (e->persist_on && e->stage_mode_eff == 2 &&
+    } else if ((e->persist_on || e->search_host) && e->stage_mode_eff == 2 &&
         hipExtMallocWithFlags((void**)&e->d_fp, rows * nq * vb, hipDeviceMallocFinegrained) == hipSuccess) {
       e->fp_direct = true;                                                   // walker threads write the vector log through the BAR
     } else {
       (void)hipGetLastError();
       HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                  // :398
     }
-    HIP_TRY(hipHostMalloc((void**)&e->h_parents, nq * 4, hipHostMallocMapped));              // :419
+    HIP_TRY(hipHostMalloc((void**)&e->h_parents, slots_cap * 4, hipHostMallocMapped));       // :419
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
+    if (e->search_host) {
+      if (hipExtMallocWithFlags((void**)&e->d_srows, 8 * KT_WGS * 16 * 64 * 4, hipDeviceMallocFinegrained) != hipSuccess ||
+          hipExtMallocWithFlags((void**)&e->d_sctl, 8 * KT_WGS * 64, hipDeviceMallocFinegrained) != hipSuccess) {
+        bang_set_error("fine-grained device memory for the search kernel's staging rows: %s", hipGetErrorString(hipGetLastError()));
+        return BANG_ERR_HIP;
+      }
+      HIP_TRY(hipMemset(e->d_srows, 0, 8 * KT_WGS * 16 * 64 * 4));
+      HIP_TRY(hipMemset(e->d_sctl, 0, 8 * KT_WGS * 64));
+    }
+    if (e->search_host && !e->vec_on_device) {
+      HIP_TRY(hipHostMalloc((void**)&e->h_pub_q, 8 * 16 * KT_WGS * 4, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer((void**)&e->d_pub_q, e->h_pub_q, 0));
+      HIP_TRY(hipHostMalloc((void**)&e->h_pub_c, 8 * 16 * KT_WGS * 4, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer((void**)&e->d_pub_c, e->h_pub_c, 0));
+    }
     HIP_TRY(hipHostMalloc((void**)&e->h_stage, nq * BANG_STAGE_STRIDE * 4, hipHostMallocMapped));      // :416
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_stage_dev, e->h_stage, 0));
-    if (!e->d_stage) BANG_TRY(dmalloc(&e->d_stage, nq * BANG_STAGE_STRIDE));   // stage modes 0/1: filled by H2D copies / unused
-    HIP_TRY(hipMemset(e->d_stage, 0, nq * BANG_STAGE_STRIDE * 4));
+    if (!e->d_stage) BANG_TRY(dmalloc(&e->d_stage, slots_cap * BANG_STAGE_STRIDE));   // stage modes 0/1: filled by H2D copies / unused
+    HIP_TRY(hipMemset(e->d_stage, 0, slots_cap * BANG_STAGE_STRIDE * 4));
     memset(e->h_stage, 0, nq * BANG_STAGE_STRIDE * 4);
     if (!e->vec_on_device) HIP_TRY(hipHostMalloc((void**)&e->h_fp, rows * nq * vb, hipHostMallocDefault));          // :422
   }
@@ -1422,12 +1738,12 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->persist_on || e->persist_dev || e->search_v2) nl = 1;   // the persistent kernel's workgroups are the unit of overlap, not lanes
-  if (e->persist_on && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
+  if (e->persist_on || e->persist_dev || e->search_v2 || e->search_host) nl = 1;   // the persistent kernel's workgroups are the unit of overlap, not lanes
+  if ((e->persist_on || e->search_host) && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
   else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
   if (!dev_graph) {
-    const size_t n_flags = std::max<size_t>((size_t)nl, e->persist_on ? e->pw_G : 0);
+    const size_t n_flags = std::max<size_t>((size_t)nl, e->persist_on ? e->pw_G : e->search_host ? 8 * KT_WGS : 0);
     HIP_TRY(hipHostMalloc((void**)&e->h_done, n_flags * 16 * 4, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_done_dev, e->h_done, 0));
     memset(e->h_done, 0, n_flags * 16 * 4);
@@ -1463,14 +1779,15 @@ static int alloc_buffers(bang_engine* e, int Q) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
       }
     }
-    if (e->persist_dev || e->search_v2) {
+    if (e->persist_dev || e->search_v2 || e->search_host) {
       BANG_TRY(dmalloc(&ln.d_pcnt, 16));
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
     }
-    if (e->persist_on) {
-      ln.pw_expect.reset(new std::atomic<uint32_t>[std::max<uint32_t>(1u, e->pw_G)]);
-      const size_t go_bytes = (size_t)e->pw_G * 64;
-      BANG_TRY(dmalloc(&ln.d_pcnt, 16));
+    if (e->persist_on || e->search_host) {
+      const uint32_t n_go = e->search_host ? (uint32_t)(8 * KT_WGS) : e->pw_G;
+      ln.pw_expect.reset(new std::atomic<uint32_t>[std::max<uint32_t>(1u, n_go)]);
+      const size_t go_bytes = (size_t)n_go * 64;
+      if (!ln.d_pcnt) BANG_TRY(dmalloc(&ln.d_pcnt, 16));
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
       if (e->stage_mode_eff == 2 && hipExtMallocWithFlags((void**)&ln.go_host, go_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
         HIP_TRY(hipMemset(ln.go_host, 0, go_bytes));
@@ -1489,6 +1806,16 @@ static int alloc_buffers(bang_engine* e, int Q) {
       HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
       HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
     }
+  }
+  e->numa_on = false;
+  if (!dev_graph && e->numa_opt != 0) {
+    e->numa_on = gpu_numa_cpus(e->device, &e->numa_cpus, &e->numa_node);
+    // a node with fewer usable CPUs than walker threads would stack them on top of each other: leave them unpinned then
+    if (e->numa_on && CPU_COUNT(&e->numa_cpus) < e->threads_eff * nl && e->numa_opt < 1) e->numa_on = false;
+  }
+  if (getenv("BANG_DEBUG")) {
+    if (e->numa_on) fprintf(stderr, "[bang] walker threads pinned to NUMA node %d (%d usable CPUs)\n", e->numa_node, CPU_COUNT(&e->numa_cpus));
+    else if (!dev_graph) fprintf(stderr, "[bang] walker threads not pinned\n");
   }
   if (getenv("BANG_DEBUG"))
     fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d persist=%d B=%u G=%u fp_direct=%d vec_on_device=%d\n", Q, nl,
@@ -1533,6 +1860,10 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   if (Q <= 0 || Q > e->Qcap) { bang_set_error("bang_query: numQueries %d exceeds allocation %d", Q, e->Qcap); return BANG_ERR_ARG; }
   e->inited = false;   // state is consumed
   e->Qcur = Q;
+  // the calling thread is lane 0's walker: it joins the GPU's NUMA node for the duration of the query
+  cpu_set_t caller_cpus;
+  const bool repin = e->numa_on && sched_getaffinity(0, sizeof(caller_cpus), &caller_cpus) == 0 &&
+                     sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus) == 0;
   const auto t0 = Clock::now();
   const int nl = (int)e->lanes.size();
   for (int i = 0; i < nl; ++i) {                       // lanes were laid out for Qcap; re-slice for this Q
@@ -1574,6 +1905,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     pool.cv_done.wait(lk, [&] { return pool.lanes_done == nl - 1; });
   }
   if (wd.joinable()) { wd_stop.store(true); wd.join(); }
+  if (repin) (void)sched_setaffinity(0, sizeof(caller_cpus), &caller_cpus);
   int rc = BANG_OK;
   for (auto& lp : e->lanes)
     if (lp->rc != BANG_OK) { rc = lp->rc; bang_set_error("%s", lp->err.c_str()); break; }
@@ -1588,15 +1920,16 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
     s.h2d_bytes += ln.h2d_bytes.load();
   }
-  s.persistent = (e->persist_on || e->persist_dev || e->search_v2) ? 1 : 0;
+  s.persistent = (e->persist_on || e->persist_dev || e->search_v2 || e->search_host) ? 1 : 0;
   s.vectors_on_device = e->vec_on_device ? 1 : 0;
   s.graph_mode = (uint64_t)e->graph_mode;
   s.lanes = (uint64_t)nl;
   s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
-  s.wg_queries = (e->persist_on || e->persist_dev) ? e->pw_B : 0;
+  s.wg_queries = (e->persist_on || e->persist_dev) ? e->pw_B : e->search_host ? e->sv_W * e->sv_C : 0;
+  s.pacing_groups = e->search_host ? e->sv_NG : 0;
   s.workgroups = (e->persist_on || e->persist_dev) ? ((uint32_t)Q + e->pw_B - 1) / std::max<uint32_t>(1u, e->pw_B)
-               : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
-  s.search_kernel = e->search_v2 ? 1 : 0;
+               : e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
+  s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
   return rc;
 }
 
@@ -1702,7 +2035,7 @@ extern "C" int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, u
   }
   if (candidates) HIP_TRY(hipMemcpy(candidates, e->d_cand_cnt, Q * 4, hipMemcpyDeviceToHost));
   if (iterations) {
-    if (e->search_v2 && e->h_qiters.size() >= Q) memcpy(iterations, e->h_qiters.data(), Q * 4);
+    if ((e->search_v2 || e->search_host) && e->h_qiters.size() >= Q) memcpy(iterations, e->h_qiters.data(), Q * 4);
     else memset(iterations, 0, Q * 4);
   }
   return BANG_OK;

@@ -19,6 +19,12 @@ int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, const void*
                         uint32_t cand_stride, uint32_t q0, uint32_t nq, uint32_t Q_total, uint32_t D, uint32_t k,
                         uint32_t dim_adjust, uint64_t* d_ids_out, float* d_dists_out, void* stream);
 
+// the same with the vector log laid out [query][candidate index][vec_stride] (host-paced search kernel with shipped vectors)
+int bang_k_rerank_byquery(const void* d_fp, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries, int dtype,
+                          const uint32_t* d_cand_ids, const uint32_t* d_cand_cnt, uint32_t cand_stride, uint32_t q0, uint32_t nq,
+                          uint32_t Q_total, uint32_t D, uint32_t k, uint32_t dim_adjust, uint64_t* d_ids_out, float* d_dists_out,
+                          void* stream);
+
 // device side of bang_init: candidate log = [MEDOID], empty worklists, mark = 0x01010101
 int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_t* d_cand_ids, uint32_t* d_cand_row,
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,

@@ -946,6 +946,7 @@ struct RerankArgs {
   const uint32_t* cand_row;
   const uint32_t* cand_cnt;
   uint32_t cand_stride, q0, nq, Q_total, D, k, dim_adjust;
+  uint32_t by_query;      // 1: vec_base is a log [query][candidate index][vec_stride] (entry 0 = the medoid, taken from medoid_vec)
   uint64_t* ids_out;
   float* dists_out;
 };
@@ -966,7 +967,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t id = a.cand_ids[(size_t)q * a.cand_stride + i];
     const uint8_t* vec;
-    if (a.cand_row) {
+    if (a.by_query) {
+      vec = (i == 0) ? a.medoid_vec : a.vec_base + ((uint64_t)q * a.cand_stride + i) * a.vec_stride;
+    } else if (a.cand_row) {
       const uint32_t row = a.cand_row[(size_t)q * a.cand_stride + i];
       vec = (row == 0) ? a.medoid_vec : a.vec_base + ((uint64_t)row * a.Q_total + q) * a.vec_stride;
     } else {
@@ -1362,6 +1365,8 @@ extern "C" int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, 
   a.vec_base = (const uint8_t*)d_vec_base; a.vec_stride = vec_stride; a.medoid_vec = (const uint8_t*)d_medoid_vec;
   a.queries = d_queries; a.cand_ids = d_cand_ids; a.cand_row = d_cand_row; a.cand_cnt = d_cand_cnt;
   a.cand_stride = cand_stride; a.q0 = q0; a.nq = nq; a.Q_total = Q_total; a.D = D; a.k = k; a.dim_adjust = dim_adjust;
+  a.by_query = (d_cand_row == (const uint32_t*)(uintptr_t)1) ? 1u : 0u;
+  if (a.by_query) a.cand_row = nullptr;
   a.ids_out = d_ids_out; a.dists_out = d_dists_out;
   return dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
@@ -1370,6 +1375,14 @@ extern "C" int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, 
     HIP_TRY(hipGetLastError());
     return BANG_OK;
   });
+}
+
+extern "C" int bang_k_rerank_byquery(const void* d_fp, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries, int dtype,
+                                     const uint32_t* d_cand_ids, const uint32_t* d_cand_cnt, uint32_t cand_stride, uint32_t q0,
+                                     uint32_t nq, uint32_t Q_total, uint32_t D, uint32_t k, uint32_t dim_adjust, uint64_t* d_ids_out,
+                                     float* d_dists_out, void* stream) {
+  return bang_k_rerank_range(d_fp, vec_stride, d_medoid_vec, d_queries, dtype, d_cand_ids, (const uint32_t*)(uintptr_t)1, d_cand_cnt,
+                             cand_stride, q0, nq, Q_total, D, k, dim_adjust, d_ids_out, d_dists_out, stream);
 }
 
 extern "C" int bang_k_rerank(const void* d_vec_base, uint64_t vec_stride, const void* d_medoid_vec, const void* d_queries,

@@ -17,7 +17,8 @@
 //  * Both filter words of an id are probed in one round trip: the second word is needed anyway -- for the test when the first
 //    bit is set, for the update when it is not.
 //  * In graph-on-HBM mode the next adjacency row is requested the moment the parent is known, so its latency hides behind the
-//    filter update and the sort/merge.
+//    sort/merge.  In host-graph mode the parents of a workgroup's waves go to the host walker in one coalesced store per round,
+//    and the sort/merge overlaps the walker's round trip.
 //
 // Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
 // canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
@@ -36,14 +37,16 @@
 struct SearchArgs {
   bang_search_params p;
   uint32_t lds_piv_floats;
-  uint32_t wave_words;       // LDS words per wave: worklist (2L + ceil(L/4), rounded to 4) + 144 scratch
-  uint32_t wl_words;         // offset of the scratch inside a wave's region
+  uint32_t wave_words;       // LDS words per wave: nctx worklists + 144 scratch + 32 parked context state
+  uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
+  uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
+  uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
 };
 
 #define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (key[64] + acc[64]) aliases both
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
-__host__ __device__ inline uint32_t search_wave_words(uint32_t L) { return search_wl_words(L) + SRCH_SCRATCH_WORDS; }
+__host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx) { return nctx * search_wl_words(L) + SRCH_SCRATCH_WORDS + 32u; }
 
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -200,7 +203,44 @@ __device__ __forceinline__ uint32_t sort_and_merge(const WaveLds& s, uint32_t n,
 // ---------------------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PSZ, int NDW, bool ALIGNED, int NHI>
+// Barrier among the `n` waves of a pacing group (a subset of the workgroup, so s_barrier cannot be used): arrival counter +
+// generation word in LDS.  Everything the group hands over at the barrier lives in LDS, and a wave's LDS operations execute in
+// program order, so draining the wave's own LDS queue before it arrives is all the ordering that is needed.
+__device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (n > 1 && lane == 0) {
+    const uint32_t gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+    if (arrived == n) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(&bar[1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wave_sync();
+}
+
+// HOST = false: graph resident in HBM.  Every wave runs on its own: no barrier, no host involvement.
+// HOST = true : graph in host RAM (the north-star path).  The waves of a workgroup form PACING GROUPS of a.gs waves (default 8: two
+//   groups per workgroup, which run independently of each other -- while one waits for the host the other computes).  The waves
+//   of a group advance in lock-step HALF-ROUNDS.  A wave holds a.nctx (default 1; 2 measured slower) query CONTEXTS; half-round h
+//   works on context c = h mod nctx of every wave of the group:
+//     wait until the host walker has delivered context c's adjacency rows of its previous round (ctl[g].go, g = nctx * wg + c)
+//     -> every wave runs one iteration of its context-c query: K5, K2, K4 (front), then K3 (sort/merge)
+//     -> between the two the workgroup publishes the <= 16 parents in ONE coalesced store to mapped host memory, followed by the
+//        round number (h_done[16 g]).
+//   With two contexts the walker's round trip for context c (PCIe write of the parents, gather of 16 graph entries by a CPU
+//   thread, PCIe writes of the rows through the BAR) overlaps the whole half-round of the other context, so the CU never idles
+//   waiting for the host.  Workgroups do not wait for each other; a context whose query is finished starts its next one in its
+//   next half-round.
+#define SRCH_GO_STOP 0xFFFFFFFFu
+#define SRCH_FIN 0xFFFFFFFFu        // h_done value: this context group of the workgroup has no queries left
+#define SRCH_CTX_WORDS 16u          // parked per-context state of a wave, in LDS
+
+template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST>
 __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_search_params& p = a.p;
@@ -223,51 +263,150 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         if (i < n4) dst[i] = v[j];
       }
     }
-    __syncthreads();
   }
-  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-
   const int lane = lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
+  const uint32_t nctx = HOST ? a.nctx : 1u;
   const uint32_t L = p.L, medoid = p.medoid, cap_iter = p.cap_iter;
+  // a wave's LDS region: [worklist of context 0][worklist of context 1][scratch 144][parked context state 2 x 16]
   uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
-  WaveLds s;
-  s.wd = (float*)wbase; s.wi = wbase + L; s.wv = (uint8_t*)(wbase + 2 * L);
-  s.sd = (float*)(wbase + a.wl_words); s.ti = wbase + a.wl_words; s.td = (float*)(wbase + a.wl_words + 72);
-  uint32_t* sc = wbase + a.wl_words + 72;          // compaction scratch (== td: dead before the sort)
-  uint32_t* tbl = wbase + a.wl_words;              // filter claim table, 128 words (== sd + td: dead between the stages that use them)
+  uint32_t* scratch = wbase + (size_t)nctx * a.wl_words;
+  uint32_t* park = scratch + SRCH_SCRATCH_WORDS;
+  // pacing group of this wave
+  const uint32_t gs = HOST ? a.gs : nwaves;
+  const uint32_t grp_in_wg = HOST ? wave / gs : 0u;
+  const uint32_t gw0 = grp_in_wg * gs;                                   // first wave of the group
+  const uint32_t gsize = (nwaves - gw0) < gs ? (nwaves - gw0) : gs;      // waves in it
+  const uint32_t gslot = wave - gw0;
+  const uint32_t ngrp = HOST ? (nwaves + gs - 1) / gs : 1u;
+  // group-shared words behind the waves' regions (HOST only), 128 per group: [0] go value seen, [1..3] active-context counters (rotating
+  // per executed half-round); per context c (a context's FIRST round has no barrier in front of it, so the two contexts must not
+  // share a publish area): [4 + 48c ..] parents x 16, [20 + 48c ..] query | row wanted << 31, [36 + 48c ..] candidate index
+  // [120..121] the group's barrier
+  uint32_t* wg_lds = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words + (size_t)grp_in_wg * 128;
+  if (HOST && gslot == 0) { wg_lds[lane] = 0u; wg_lds[64 + lane] = 0u; }
+  if (HOST && lane < (int)(2 * SRCH_CTX_WORDS)) park[lane] = 0u;        // both contexts: inactive
+  __syncthreads();
+  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+
+  float* sd = (float*)scratch;
+  uint32_t* ti = scratch;
+  float* td = (float*)(scratch + 72);
+  uint32_t* sc = scratch + 72;                     // compaction scratch (== td: dead before the sort)
+  uint32_t* tbl = scratch;                         // filter claim table, 128 words (== sd + td: dead between the stages that use them)
   const uint32_t total_waves = gridDim.x * nwaves;
+  const uint32_t gw = blockIdx.x * nwaves + wave;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   constexpr int SB = (NDW >= 18) ? 6 : 0;          // long rows (70 .. 128 chunks): consumed 6 code dwords (24 chunks) at a time
 
-  // ---- queries of this wave: the first one by position, the following ones from the hand-out counter
-  bool first_q = true;
-  for (;;) {
-    uint32_t q;
-    if (first_q) q = blockIdx.x * nwaves + wave;
-    else {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
-      q = total_waves + uni(t);
-    }
-    first_q = false;
-    if (q >= p.Q) break;
+  // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
+  bool active = false, exhausted = false;
+  uint32_t q = 0, iter = 0, w_n = 0, cc = 0, mark = 0, evals = 0, fetched = 0;
+  uint32_t cnt_in = 0, x0 = 0, x1 = 0;
+  bool have_row = false;
+  uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
+  uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
+  uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
+  uint32_t tick = 0;                               // HOST: half-rounds this workgroup has EXECUTED (a finished context's are skipped)
 
+  // diagnostic (p.d_prof != NULL, host-paced form): thread 0 of every workgroup accumulates where its half-rounds spend their time
+  unsigned long long pf_poll = 0, pf_front = 0, pf_pub = 0, pf_back = 0, pf_n = 0, pf_t = 0;
+  const bool prof = HOST && p.d_prof != nullptr && threadIdx.x == 0;       // (first wave of the workgroup's first group)
+#define PF_STAMP(acc) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc += t_ - pf_t; pf_t = t_; } } while (0)
+  if (prof) pf_t = __builtin_amdgcn_s_memrealtime();
+
+#ifdef BANG_SEARCH_PHASE_PROF
+  // diagnostic build (make CXXFLAGS+=-DBANG_SEARCH_PHASE_PROF): wave 0 of every workgroup stamps the phase boundaries of its
+  // iterations (no draining: a phase ends where the compiler had to wait for its results anyway) into p.d_prof[wg][8 + k]
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_n = 0;
+#define PH(k) do { if (wave == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph_acc[k] += t_ - ph_t; ph_t = t_; } } while (0)
+#else
+#define PH(k) do {} while (0)
+#endif
+
+  for (uint32_t half = 0;; ++half) {
+    const uint32_t c = HOST ? (nctx == 2 ? (half & 1u) : 0u) : 0u;
+    if (HOST) {
+      if (dead_mask == (nctx == 2 ? 3u : 1u)) break;
+      if ((dead_mask >> c) & 1u) continue;
+    }
+    const uint32_t round = HOST ? (c ? rounds1 : rounds0) + 1u : 0u;
+    const uint32_t grp = HOST ? (blockIdx.x * ngrp + grp_in_wg) * nctx + c : 0u;   // pacing group of (workgroup, wave group, context)
+    WaveLds s;
+    s.wd = (float*)(wbase + (size_t)c * a.wl_words); s.wi = wbase + (size_t)c * a.wl_words + L; s.wv = (uint8_t*)(wbase + (size_t)c * a.wl_words + 2 * L);
+    s.sd = sd; s.ti = ti; s.td = td;
+    if (HOST) {
+      if (nctx == 2) {                                                  // un-park context c
+        const uint32_t* pk = park + c * SRCH_CTX_WORDS;
+        active = pk[0] != 0u; q = pk[1]; iter = pk[2]; w_n = pk[3]; cc = pk[4]; mark = pk[5]; evals = pk[6]; fetched = pk[7];
+        have_row = pk[8] != 0u;
+      }
+      // ---------------- wait for the rows of this context's previous round
+      if (round > 1) {
+        if (gslot == 0 && lane == 0) {
+          const uint32_t* go = p.d_ctl + (size_t)grp * 16;
+          uint32_t v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          while (v < round - 1u) {                           // SRCH_GO_STOP is the largest value: it also ends the wait
+            __builtin_amdgcn_s_sleep(4);
+            v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > BANG_KERNEL_GO_TIMEOUT_TICKS) {   // the host is gone (it gives up first)
+              v = SRCH_GO_STOP;
+              if (p.d_abort) *p.d_abort = 1u;
+              break;
+            }
+          }
+          wg_lds[0] = v;
+          // rows the CPU wrote through the BAR since the last round must not be served from this CU's L1 (they live in
+          // fine-grained LOCAL memory: L2 copies are invalidated by the fabric when the PCIe writes land)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        group_barrier(wg_lds + 120, gsize, lane);
+        PF_STAMP(pf_poll);
+        if (wg_lds[0] == SRCH_GO_STOP) break;
+        if (active && have_row) {
+          // control line of the group: {go, count bytes x 16, ...}; rows: 64 ids each, 256-byte aligned
+          const uint32_t cw = p.d_ctl[(size_t)grp * 16 + 1 + (gslot >> 2)];
+          cnt_in = (cw >> (8 * (gslot & 3u))) & 0xFFu;
+          x0 = p.d_rows[((size_t)grp * 16 + gslot) * 64 + lane];
+        }
+      }
+    }
+
+    // ---------------- a finished context takes its next query: the first one by position, then from the hand-out counter
+    if (!active && !exhausted) {
+      if (!((started >> c) & 1u)) q = c * total_waves + gw;
+      else {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
+        q = nctx * total_waves + uni(t);
+      }
+      started |= 1u << c;
+      if (q < p.Q) {
+        active = true;
+        w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
+        evals = 0; fetched = 0; iter = 1;
+        if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
+        // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
+        cnt_in = p.d_seed[0]; x0 = p.d_seed[1 + lane]; x1 = p.d_seed[65];
+        have_row = true;
+      } else exhausted = true;
+    }
+    if (!HOST && !active) break;
     uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
     cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q * (NDW * 4 * PSZ));
-    uint32_t w_n = 0, cc = 1, mark = 0x01010101u;      // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
-    uint32_t evals = 0, fetched = 0, iters = 0;
-    if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
-    // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
-    uint32_t cnt_in = p.d_seed[0], x0 = p.d_seed[1 + lane], x1 = p.d_seed[65];
-    bool have_row = true;
 
-    for (uint32_t iter = 1;; ++iter) {
-      const bool first = (iter == 1);
-      iters = iter;
+    // results of the front half, consumed by the back half below
+    uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
+    float d0 = BIG_DIST, d1 = BIG_DIST;
+    bool found = false;
+    const bool first = (iter == 1);
+    if (active) {
       // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
       uint32_t ci = have_row ? uni(cnt_in) : 0u;
+      PH(0);   // the adjacency row has arrived (and: query hand-out, loop overhead)
       {
         const uint32_t cap = p.R + (first ? 1u : 0u);
         if (ci > cap) ci = cap;
@@ -288,9 +427,9 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       const uint64_t m0 = __ballot(pass0);
       const uint64_t m1 = __ballot(pass1);
       const uint32_t n0 = (uint32_t)__popcll(m0);
-      const uint32_t n = n0 + (uint32_t)__popcll(m1);
+      n = n0 + (uint32_t)__popcll(m1);
+      PH(1);   // hashes + filter probes returned
       // ordered compaction through LDS: survivors keep input order (CANON; the reference emits in atomicAdd order :1161)
-      uint32_t sid0 = 0, sid1 = 0;
       if (pass0) sc[lanes_below(m0)] = x0;
       if (pass1) sc[n0] = x1;
       wave_sync();
@@ -298,9 +437,27 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       if (lane == 0 && n > 64) sid1 = sc[64];
       wave_sync();
       evals += n;
+      PH(2);   // compaction
 
+      // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
+      // (before the distance stage: the hashes and the probed words die here instead of living through the register-hungry K2)
+      {
+        bool pa = pass0, pb = pass0;
+        filter_commit(bloom, tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b);
+        const uint64_t left = __ballot(pa || pb || pass1);
+        if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
+          if (pa) (void)__hip_atomic_fetch_or(&bloom[h0a >> 5], 1u << (h0a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pb) (void)__hip_atomic_fetch_or(&bloom[h0b >> 5], 1u << (h0b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pass1) {
+            (void)__hip_atomic_fetch_or(&bloom[h1a >> 5], 1u << (h1a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_or(&bloom[h1b >> 5], 1u << (h1b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+
+      PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
-      float d0 = BIG_DIST, d1 = BIG_DIST;
       {
         PqRow<NDW, ALIGNED> row;
         if ((uint32_t)lane < n) {
@@ -319,6 +476,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ----------------
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
       const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
+      PH(4);   // code rows returned + distances
       float bd = elig ? d0 : BIG_DIST;
       uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
       uint32_t bid = sid0;
@@ -337,8 +495,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       }
       const bool have_best = (bi != 0xFFFFu);
       if (!have_best) bd = BIG_DIST;
-      bool found = false, from_best = false;
-      uint32_t parent = 0;
+      bool from_best = false;
       if (first) {
         if (have_best) { found = true; parent = bid; from_best = true; }
       } else {
@@ -362,46 +519,105 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride + cc] = parent;      // :1451-1458
         ++cc;
       }
+    }
+    const bool want_row = active && found && iter < cap_iter;
+    PH(5);     // parent selection
 
-      // ---- the next adjacency row is requested NOW (graph resident in HBM): it travels while the filter is updated and the
-      // survivors are merged
-      uint32_t n_cnt = 0, n_x0 = 0;
-      if (found && iter < cap_iter) {
+    // ---------------- hand the parent over
+    uint32_t n_cnt = 0, n_x0 = 0;
+    if (!HOST) {
+      // graph resident in HBM: the next adjacency row is requested NOW; it travels while the survivors are merged
+      if (want_row) {
         const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
         n_cnt = nrow[0];
-        n_x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots
+        n_x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
       }
-
-      // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
-      {
-        bool pa = pass0, pb = pass0;
-        filter_commit(bloom, tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b);
-        const uint64_t left = __ballot(pa || pb || pass1);
-        if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
-          if (pa) (void)__hip_atomic_fetch_or(&bloom[h0a >> 5], 1u << (h0a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pb) (void)__hip_atomic_fetch_or(&bloom[h0b >> 5], 1u << (h0b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pass1) {
-            (void)__hip_atomic_fetch_or(&bloom[h1a >> 5], 1u << (h1a & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_or(&bloom[h1b >> 5], 1u << (h1b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      uint32_t* cnt_act = wg_lds + 1 + (tick % 3u);
+      if (lane == 0) {
+        // parents travel to the host in one coalesced store per workgroup.  A parent whose vector the walker must ship (vectors
+        // not resident) is published even when no row is needed any more (the one chosen at the iteration cap, CANON 6).
+        const bool tell = active && found && (want_row || p.ship_vectors);
+        wg_lds[4 + 48 * c + gslot] = tell ? parent : BANG_NO_PARENT;
+        wg_lds[20 + 48 * c + gslot] = q | (want_row ? 0x80000000u : 0u);
+        wg_lds[36 + 48 * c + gslot] = cc - 1u;
+        if (active) (void)__hip_atomic_fetch_add(cnt_act, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      group_barrier(wg_lds + 120, gsize, lane);
+      PF_STAMP(pf_front);
+      const bool grp_alive = (*cnt_act != 0u);               // none active => every wave found the hand-out counter exhausted: final
+      if (gslot == 0) {
+        if (grp_alive) {
+          if ((uint32_t)lane < gsize) {
+            __hip_atomic_store(&p.h_parents[(size_t)grp * 16 + lane], wg_lds[4 + 48 * c + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.ship_vectors) {
+              __hip_atomic_store(&p.h_pub_q[(size_t)grp * 16 + lane], wg_lds[20 + 48 * c + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(&p.h_pub_c[(size_t)grp * 16 + lane], wg_lds[36 + 48 * c + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
           }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the parents (MI355X guide)
+        }
+        if (lane == 0) {
+          __hip_atomic_store(p.h_done + (size_t)grp * 16, grp_alive ? round : SRCH_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // three counters in rotation: the one reset here was last read before this half-round's barrier and is next
+          // incremented two executed half-rounds from now, i.e. behind the next half-round's barrier (a context's FIRST round has
+          // no wait-for-rows barrier in front, so the counter of the very next half-round may already be in use)
+          wg_lds[1 + ((tick + 2u) % 3u)] = 0u;
         }
       }
+      ++tick;
+      PF_STAMP(pf_pub);
+      if (prof) ++pf_n;
+      if (!grp_alive) { dead_mask |= 1u << c; continue; }
+      if (c) rounds1 = round; else rounds0 = round;
+    }
 
+    if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
       if (n > 0 && iter < cap_iter) w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, lane);
+      PH(6);   // (publish +) sort/merge
+#ifdef BANG_SEARCH_PHASE_PROF
+      if (wave == 0) ++ph_n;
+#endif
 
+      // ---------------- next iteration of this query, or the query is finished
       // a query is active while it has a parent or unmerged survivors (CANON 4); the loop ends at the cap (:950-956)
-      if ((!found && n == 0) || iter == cap_iter) break;
-      have_row = found;
-      cnt_in = n_cnt; x0 = n_x0;
+      if ((!found && n == 0) || iter == cap_iter) {
+        if (lane == 0) {
+          p.d_cand_cnt[q] = cc;
+          if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
+          if (p.d_qiters) p.d_qiters[q] = iter;
+        }
+        active = false;
+      } else {
+        ++iter;
+        have_row = found;
+        cnt_in = n_cnt; x0 = n_x0;
+      }
     }
-    if (lane == 0) {
-      p.d_cand_cnt[q] = cc;
-      if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
-      if (p.d_qiters) p.d_qiters[q] = iters;
+    if (HOST && nctx == 2) {                                             // park context c
+      uint32_t* pk = park + c * SRCH_CTX_WORDS;
+      if (lane == 0) {
+        pk[0] = active ? 1u : 0u; pk[1] = q; pk[2] = iter; pk[3] = w_n; pk[4] = cc; pk[5] = mark; pk[6] = evals; pk[7] = fetched;
+        pk[8] = have_row ? 1u : 0u;
+      }
+      wave_sync();
     }
+    PF_STAMP(pf_back);
   }
+  if (prof) {
+    unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
+    o[0] = pf_poll; o[1] = pf_front; o[2] = pf_pub; o[3] = pf_back; o[4] = pf_n;
+  }
+#undef PF_STAMP
+#ifdef BANG_SEARCH_PHASE_PROF
+  if (p.d_prof && wave == 0 && lane == 0) {
+    unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16 + 8;
+    for (int k = 0; k < 7; ++k) o[k] = ph_acc[k];
+    o[7] = ph_n;
+  }
+#endif
+#undef PH
   if (p.d_ktime) {
     __syncthreads();
     if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -411,18 +627,24 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PSZ, int NDW, bool ALIGNED, int NHI>
+template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST>
 static int launch_inst(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done[BANG_MAX_DEVICES] = {false};      // per kernel instance AND device
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)search_kernel<PSZ, NDW, ALIGNED, NHI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void*)search_kernel<PSZ, NDW, ALIGNED, NHI, HOST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((search_kernel<PSZ, NDW, ALIGNED, NHI>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((search_kernel<PSZ, NDW, ALIGNED, NHI, HOST>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
+}
+
+template <int PSZ, int NDW, bool ALIGNED, int NHI>
+static int launch_hd(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  return a.p.d_graph ? launch_inst<PSZ, NDW, ALIGNED, NHI, false>(a, grid, block, lds, st)
+                     : launch_inst<PSZ, NDW, ALIGNED, NHI, true>(a, grid, block, lds, st);
 }
 
 template <int PSZ, int NDW>
@@ -433,19 +655,22 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
     // 96 dims in 74 chunks: 22 x 2 + 52 x 1)
     constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
     if constexpr (NHI != 0) {
-      if ((int)a.p.pq_nhi == NHI && !al) return launch_inst<PSZ, NDW, false, NHI>(a, grid, block, lds, st);
+      if ((int)a.p.pq_nhi == NHI && !al) return launch_hd<PSZ, NDW, false, NHI>(a, grid, block, lds, st);
     }
     bang_set_error("no search-kernel instance for the exact-size pivot table psz=%u mp=%u nhi=%u", a.p.psz, a.p.mp, a.p.pq_nhi);
     return BANG_ERR_UNSUPPORTED;
   }
-  return al ? launch_inst<PSZ, NDW, true, 0>(a, grid, block, lds, st) : launch_inst<PSZ, NDW, false, 0>(a, grid, block, lds, st);
+  return al ? launch_hd<PSZ, NDW, true, 0>(a, grid, block, lds, st) : launch_hd<PSZ, NDW, false, 0>(a, grid, block, lds, st);
 }
 
-// waves per workgroup that fit beside the pivot table (0: not even one)
-static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
+#define SRCH_WG_SHARED_BYTES 2048u     // group-shared LDS behind the waves' regions (host-paced form): 128 words per pacing group, up to 4 groups
+#define SRCH_DEFAULT_GROUP_WAVES 8u
+
+// waves per workgroup that fit beside the pivot table with nctx query contexts each (0: not even one)
+static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx) {
   const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
-  const size_t per_wave = (size_t)search_wave_words(L) * 4u;
-  const size_t cap = (size_t)160 * 1024;
+  const size_t per_wave = (size_t)search_wave_words(L, nctx) * 4u;
+  const size_t cap = (size_t)160 * 1024 - SRCH_WG_SHARED_BYTES;
   if (piv_bytes + per_wave > cap) return 0;
   const size_t w = (cap - piv_bytes) / per_wave;
   return (uint32_t)(w > 16 ? 16 : w);
@@ -453,7 +678,39 @@ static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t
 
 extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
   if (psz == 0 || L == 0 || L > BANG_MAX_L) return 0;
-  return (int)waves_that_fit(psz, mp, nhi, L);
+  return (int)waves_that_fit(psz, mp, nhi, L, 1);
+}
+
+// One workgroup per CU at most (the pivot table takes most of the LDS).  A batch smaller than CUs x waves is spread over all
+// CUs with fewer waves each: a wave's iteration is latency bound, and fewer waves per CU contend less for LDS and L1.
+// Host-paced form: *nctx_io = query contexts per wave (0 = auto = 1), *group_waves_io = waves per pacing group (0 = auto = 8).
+extern "C" int bang_search_geometry(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t Q, uint32_t max_wgs,
+                                    uint32_t max_waves, int host_paced, uint32_t* workgroups, uint32_t* waves_out, uint32_t* nctx_io,
+                                    uint32_t* group_waves_io) {
+  if (!workgroups || !waves_out || !nctx_io || !group_waves_io || Q == 0) return BANG_ERR_ARG;
+  if (psz == 0 || L == 0 || L > BANG_MAX_L) { bang_set_error("bad pq layout / L"); return BANG_ERR_ARG; }
+  uint32_t nctx = *nctx_io;
+  if (!host_paced) nctx = 1;
+  else if (nctx == 0) nctx = 1;     // two contexts per wave measured slower (more, emptier half-rounds): kept as an experiment knob
+  else if (nctx > 2) nctx = 2;
+  uint32_t waves = waves_that_fit(psz, mp, nhi, L, nctx);
+  if (waves == 0) { bang_set_error("pivot table + one wave's worklist do not fit LDS at L=%u", L); return BANG_ERR_UNSUPPORTED; }
+  if (max_waves && max_waves < waves) waves = max_waves;
+  const uint32_t cus = (uint32_t)num_cus();
+  uint32_t grid_n = Q < cus ? Q : cus;
+  if (max_wgs && max_wgs < grid_n) grid_n = max_wgs;
+  const uint32_t per_wg = ((Q + grid_n - 1) / grid_n + nctx - 1) / nctx;       // waves a workgroup needs to hold its share at once
+  if (per_wg < waves) waves = per_wg;
+  // pacing groups: 8 waves by default, at least 4 (the group-shared LDS area holds 4 groups), the whole workgroup if it is small
+  uint32_t gs = *group_waves_io ? *group_waves_io : SRCH_DEFAULT_GROUP_WAVES;
+  if (gs > 16) gs = 16;
+  if (gs < 4) gs = 4;
+  if (gs > waves) gs = waves;
+  *workgroups = grid_n;
+  *waves_out = waves;
+  *nctx_io = nctx;
+  *group_waves_io = host_paced ? gs : waves;
+  return BANG_OK;
 }
 
 extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
@@ -462,27 +719,23 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (p->R == 0 || p->R > BANG_MAX_R || p->L == 0 || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
   if (p->psz == 0 || p->mp < p->m || (p->mp & 3u)) { bang_set_error("the search kernel needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
   if (!p->d_codes || !p->d_pivots_packed || !p->d_qc || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
-      !p->d_next_query || !p->d_graph) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
+      !p->d_next_query) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
+  if (!p->d_graph && (!p->d_rows || !p->d_ctl || !p->h_done || !p->h_parents || (p->ship_vectors && (!p->h_pub_q || !p->h_pub_c)))) {
+    bang_set_error("host-paced search kernel: null pacing buffer"); return BANG_ERR_ARG;
+  }
   if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
   if (p->cap_iter == 0 || p->cap_iter > p->L + BANG_EXTRA_ITERS - 1) { bang_set_error("bad iteration cap"); return BANG_ERR_ARG; }
   SearchArgs a;
   a.p = *p;
   a.lds_piv_floats = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
+  uint32_t grid_n = 0, waves = 0, nctx = p->nctx, gs = p->group_waves;
+  const int rc = bang_search_geometry(p->psz, p->mp, p->pq_nhi, p->L, p->Q, p->max_wgs, p->max_waves, p->d_graph ? 0 : 1, &grid_n, &waves, &nctx, &gs);
+  if (rc != BANG_OK) return rc;
+  a.nctx = nctx;
+  a.gs = gs;
   a.wl_words = search_wl_words(p->L);
-  a.wave_words = search_wave_words(p->L);
-  uint32_t waves = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L);
-  if (waves == 0) { bang_set_error("pivot table + one wave's worklist do not fit LDS at L=%u", p->L); return BANG_ERR_UNSUPPORTED; }
-  if (p->max_waves && p->max_waves < waves) waves = p->max_waves;
-  // One workgroup per CU at most (the pivot table takes most of the LDS).  A batch smaller than CUs x waves is spread over all
-  // CUs with fewer waves each: a wave's iteration is latency bound, and fewer waves per CU contend less for LDS and L1.
-  const uint32_t cus = (uint32_t)num_cus();
-  uint32_t grid_n = p->Q < cus ? p->Q : cus;
-  if (p->max_wgs && p->max_wgs < grid_n) grid_n = p->max_wgs;
-  {
-    const uint32_t per_wg = (p->Q + grid_n - 1) / grid_n;
-    if (per_wg < waves) waves = per_wg;
-  }
-  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4;
+  a.wave_words = search_wave_words(p->L, nctx);
+  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + SRCH_WG_SHARED_BYTES;
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + p->mp / 4u;

@@ -68,6 +68,8 @@ int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   
  *   "device"  : HIP device ordinal
  *   "pq"      : 0 = pivot-stationary fused distance (default when it fits LDS), 1 = LUT path (K1+K2)
  *   "timing"  : 1 = stamp every front-kernel launch in-kernel (s_memrealtime) for bang_get_stats
+ *   "numa"    : graph in host RAM: 1 = pin the walker threads (and the caller during bang_query) to the CPUs of the GPU's NUMA node,
+ *               0 = leave them where the OS puts them, -1 = auto (pin when the node is known and offers enough usable CPUs)
  *   "search"  : graph in HBM: 1 = the query-resident search kernel (bang_k_search), 0 = the round-1 loops, -1 = auto */
 int bang_set_option(bang_engine_t* e, const char* key, long value);
 
@@ -129,6 +131,7 @@ typedef struct {
   /* expansions (= graph hops = iterations in which the query had a parent) per query: median, 99th percentile, maximum */
   uint64_t hops_p50, hops_p99, hops_max;
   uint64_t search_kernel;     /* 1: the batch ran on the query-resident search kernel (bang_k_search) */
+  uint64_t pacing_groups;     /* host-paced search kernel: groups of waves the walker threads serve (0 otherwise) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -282,10 +285,35 @@ typedef struct {
   uint32_t* d_qiters;                  /* [Q] out: iterations the query ran, or NULL */
   uint32_t* d_next_query;              /* [1] hand-out counter, zeroed before the launch */
   unsigned long long* d_ktime;         /* [workgroups][2] {start, end} s_memrealtime stamps (100 MHz), or NULL */
+  /* host-paced form (d_graph == NULL: graph in host RAM, bang_search.cu:771-813 stays on the CPU).  A wave holds nctx (1 or 2)
+   * query contexts and the W waves of a workgroup (bang_search_geometry) form groups of group_waves waves; pacing GROUP grp =
+   * (g * groups_per_workgroup + group) * nctx + c, whose v-th wave owns slot 16*grp + v.  Every round of a group the workgroup stores its parents to h_parents[slot] (BANG_NO_PARENT: nothing to fetch) and
+   * then the round number to h_done[16 grp] (0xFFFFFFFF: the group has finished).  The walker writes the parents' adjacency ids to
+   * d_rows[slot][64] and then the group's control line d_ctl[grp][16] = {round number (0xFFFFFFFF = stop), 16 count bytes, 0...} --
+   * both in LOCAL fine-grained device memory, through the PCIe BAR, rows before the control line.  ship_vectors: the walker also
+   * needs to know where an expanded node's full-precision vector goes in the vector log ([Q][L + 50][vec_bytes], by query and
+   * candidate index): h_pub_q[slot] = query | (row wanted) << 31, h_pub_c[slot] = candidate index. */
+  const uint32_t* d_rows;              /* [G*nctx*16][64] */
+  const uint32_t* d_ctl;               /* [G*nctx][16] */
+  uint32_t* h_done;                    /* mapped pinned [G*nctx][16] */
+  uint32_t* h_parents;                 /* mapped pinned [G*nctx][16] */
+  uint32_t* h_pub_q;                   /* mapped pinned [G*nctx][16] (ship_vectors) */
+  uint32_t* h_pub_c;                   /* mapped pinned [G*nctx][16] (ship_vectors) */
+  uint32_t* d_abort;                   /* [1] set when a workgroup gave up waiting for the host, or NULL */
+  uint32_t ship_vectors;
+  uint32_t nctx;                       /* 0 = auto (bang_search_geometry) */
+  uint32_t group_waves;                /* waves per pacing group, 4..16 (0 = 8): a workgroup's W waves form ceil(W / group_waves) groups that
+                                          advance independently; pacing group index = (g * groups_per_workgroup + group) * nctx + c */
+  unsigned long long* d_prof;          /* diagnostic, host-paced form: [G][8] 100 MHz ticks thread 0 of each workgroup spent {waiting for
+                                          rows, in the front half up to the publish barrier, publishing, in sort/merge}, [4] = half-rounds; or NULL */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */
 int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
+/* grid of a bang_k_search launch over Q queries: workgroups (<= CUs, <= max_wgs if nonzero), waves per workgroup and query
+ * contexts per wave (*nctx in: 0 = auto, out: 1 or 2) and, host-paced form, waves per pacing group (*group_waves in: 0 = auto = 8) */
+int bang_search_geometry(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t Q, uint32_t max_wgs, uint32_t max_waves,
+                         int host_paced, uint32_t* workgroups, uint32_t* waves, uint32_t* nctx, uint32_t* group_waves);
 
 /* Fused K3a + K3b: compute_BestLSets_par_sort_msort (bang_search.cu:1533-1585) ->
  * compute_BestLSets_par_merge (:1605-1715), one wavefront per query. */

@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a host <-> kernel hand-shake gone wrong spins forever) must not take the box with it: every gpu test
+    gets a hard limit.  method="thread": the limit fires even while the main thread sits inside a C call (os._exit)."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except Exception:
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(420, method="thread"))
+
+
 def _make(N, D, dtype, R, m, Q, seed):
     from bang_amd import synth
     return synth.make_index(N, D, dtype, R, m, Q, K=10, n_clusters=32, seed=seed, device="cpu", pq_iters=4)

@@ -249,3 +249,58 @@ def test_search_kernel_batch_sizes_and_handout(request, libbang, small_u8, Q):
                 assert np.array_equal(e.query_counters(Q), st_o)
         finally:
             os.environ.pop("BANG_SEARCH_MAX_WGS", None)
+
+
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("L", [10, 64, 152, 400])
+@pytest.mark.parametrize("vectors", [0, 1])
+def test_search_kernel_host_paced_matches_oracle_per_query(request, libbang, fixture, L, vectors):
+    """Graph in host RAM (the north-star path), host-paced form of the query-resident search kernel: the waves of a workgroup
+    publish their parents in one store per round, the C++ walker writes the adjacency rows (and, "vectors"=0, the
+    full-precision vectors) through the PCIe BAR.  Per-query counters, ids and distances equal the oracle's."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=0, search=1, vectors=vectors, timing=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, L)
+        e.alloc(q.shape[0])
+        for _ in range(2):
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            st = e.stats()
+            if not st["search_kernel"]:
+                pytest.skip("device memory is not CPU-writable here (no large BAR): the host-paced search kernel is not used")
+            assert st["persistent"] == 1 and st["front_launches"] == 1 and st["vectors_on_device"] == vectors
+            assert np.array_equal(ids, ids_o)
+            assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(q.shape[0]), st_o)
+            assert st["h2d_bytes"] > 0
+        e.free()
+        e.unload()
+
+
+@pytest.mark.parametrize("Q,threads", [(1, 1), (5, 3), (63, 2), (700, 0)])
+def test_search_kernel_host_paced_batch_sizes(request, libbang, small_u8, Q, threads):
+    import os
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    qq = np.ascontiguousarray(np.tile(q, ((Q + q.shape[0] - 1) // q.shape[0], 1))[:Q])
+    ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 48, with_stats=True)
+    for max_wgs in ("0", "2"):
+        os.environ["BANG_SEARCH_MAX_WGS"] = max_wgs
+        try:
+            with bang_amd.Engine(ix.dtype, graph=0, search=1, threads=threads) as e:
+                e.load_index(ix)
+                e.set_searchparams(10, 48)
+                e.alloc(Q)
+                e.init(Q)
+                ids, dists = e.query(qq)
+                if not e.stats()["search_kernel"]:
+                    pytest.skip("no large BAR")
+                assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+                assert np.array_equal(e.query_counters(Q), st_o)
+        finally:
+            os.environ.pop("BANG_SEARCH_MAX_WGS", None)
