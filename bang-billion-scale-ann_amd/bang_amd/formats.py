@@ -156,12 +156,16 @@ def write_index(prefix: str, ix: Index) -> None:
     write_graph_metadata(prefix + GRAPH_META_SUFFIX, ix.medoid, ix.entry_len, ix.dtype, ix.D, ix.R, ix.N)
 
 
-def read_index(prefix: str, dtype: str) -> Index:
+def read_index(prefix: str, dtype: str, mmap_graph: bool = False) -> Index:
+    """mmap_graph=True maps `_disk.bin` read-only instead of reading it (the ranks of a multi-GPU job share one copy)."""
     md = read_graph_metadata(prefix + GRAPH_META_SUFFIX)
     codes = read_pq_compressed(prefix + PQ_COMPRESSED_SUFFIX)
     N, m = codes.shape
     pivots, centroid, chunk_off = read_pq_pivots(prefix + PQ_PIVOTS_SUFFIX, md["D"], m)
-    graph = np.fromfile(prefix + GRAPH_SUFFIX, dtype=np.uint8).reshape(md["N"], md["entry_len"])
+    if mmap_graph:
+        graph = np.memmap(prefix + GRAPH_SUFFIX, dtype=np.uint8, mode="r").reshape(md["N"], md["entry_len"])
+    else:
+        graph = np.fromfile(prefix + GRAPH_SUFFIX, dtype=np.uint8).reshape(md["N"], md["entry_len"])
     return Index(dtype=dtype, N=md["N"], D=md["D"], R=md["R"], m=m, medoid=md["medoid"], graph=graph,
                  codes=codes, pivots=pivots, centroid=centroid, chunk_off=chunk_off)
 

@@ -250,6 +250,7 @@ struct bang_engine {
   int numa_opt = -1;                   // host-graph mode: pin the walker threads (and the caller for the duration of a query) to the CPUs
                                        // of the GPU's NUMA node: 1 / 0, -1 = auto (on when the node is known and has CPUs we may use)
   cpu_set_t numa_cpus;                 // resolved at bang_alloc
+  std::vector<int> numa_cores;         // one CPU per distinct physical core of that node (walker thread i is pinned to numa_cores[i % n])
   bool numa_on = false;
   int numa_node = -1;
   int search_opt = -1;                 // device-graph mode: 1 = the query-resident search kernel (bang_search.hip), 0 = the round-1 loops,
@@ -491,6 +492,37 @@ bool gpu_numa_cpus(int device, cpu_set_t* out, int* node_out) {
   *out = want;
   *node_out = node;
   return true;
+}
+
+// one CPU per physical core among `cpus` (SMT siblings share a core's pipelines: two spinning walker threads on one core halve each other)
+std::vector<int> distinct_cores(const cpu_set_t& cpus) {
+  std::vector<int> out;
+  std::vector<long long> seen;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &cpus)) continue;
+    char path[128];
+    int core = -1, pkg = -1;
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/core_id", c);
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &core) != 1) core = -1; fclose(f); }
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/physical_package_id", c);
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &pkg) != 1) pkg = -1; fclose(f); }
+    const long long key = core < 0 ? -(long long)c - 1 : ((long long)pkg << 32) | (unsigned)core;
+    if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
+    seen.push_back(key);
+    out.push_back(c);
+  }
+  return out;
+}
+
+void pin_walker_thread(const bang_engine* e, int index) {
+  if (!e->numa_on) return;
+  if (!e->numa_cores.empty()) {
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(e->numa_cores[(size_t)index % e->numa_cores.size()], &one);
+    if (sched_setaffinity(0, sizeof(one), &one) == 0) return;
+  }
+  (void)sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus);
 }
 
 void free_batch(bang_engine* e) {
@@ -945,7 +977,7 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
 // would race with a first job posted before this thread gets to run, and that job would never be done)
 void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
   Pool& pool = e->pool;
-  if (e->numa_on) (void)sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus);
+  pin_walker_thread(e, ln->index * T + t);
   for (;;) {
     // Batches usually follow each other within a millisecond or two (bang_init in between): keep spinning for a grace period
     // before parking on the condition variable -- waking eleven parked threads at the start of every batch costs 50-100 us at
@@ -1422,7 +1454,7 @@ void lane_job(bang_engine* e, Lane& ln) {
 
 void lane_thread_main(bang_engine* e, Lane* ln) {
   Pool& pool = e->pool;
-  if (e->numa_on) (void)sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus);
+  pin_walker_thread(e, ln->index * std::max(1, e->threads_eff));
   uint64_t seen = 0;
   for (;;) {
     {
@@ -1809,9 +1841,14 @@ static int alloc_buffers(bang_engine* e, int Q) {
   }
   e->numa_on = false;
   if (!dev_graph && e->numa_opt != 0) {
-    e->numa_on = gpu_numa_cpus(e->device, &e->numa_cpus, &e->numa_node);
-    // a node with fewer usable CPUs than walker threads would stack them on top of each other: leave them unpinned then
-    if (e->numa_on && CPU_COUNT(&e->numa_cpus) < e->threads_eff * nl && e->numa_opt < 1) e->numa_on = false;
+    // "auto" = off: on the measured box (2 x EPYC 9575F, 16-CPU cgroup quota) pinning the 12 walker threads to the GPU's node
+    // was 6 % SLOWER than letting the scheduler spread them over both sockets; the option is there for hosts where it pays.
+    e->numa_on = e->numa_opt == 1 && gpu_numa_cpus(e->device, &e->numa_cpus, &e->numa_node);
+    e->numa_cores.clear();
+    if (e->numa_on) {
+      e->numa_cores = distinct_cores(e->numa_cpus);
+      if ((int)e->numa_cores.size() < e->threads_eff * nl) e->numa_cores.clear();       // not enough cores: node-wide mask instead
+    }
   }
   if (getenv("BANG_DEBUG")) {
     if (e->numa_on) fprintf(stderr, "[bang] walker threads pinned to NUMA node %d (%d usable CPUs)\n", e->numa_node, CPU_COUNT(&e->numa_cpus));
@@ -1862,8 +1899,8 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   e->Qcur = Q;
   // the calling thread is lane 0's walker: it joins the GPU's NUMA node for the duration of the query
   cpu_set_t caller_cpus;
-  const bool repin = e->numa_on && sched_getaffinity(0, sizeof(caller_cpus), &caller_cpus) == 0 &&
-                     sched_setaffinity(0, sizeof(e->numa_cpus), &e->numa_cpus) == 0;
+  const bool repin = e->numa_on && sched_getaffinity(0, sizeof(caller_cpus), &caller_cpus) == 0;
+  if (repin) pin_walker_thread(e, 0);
   const auto t0 = Clock::now();
   const int nl = (int)e->lanes.size();
   for (int i = 0; i < nl; ++i) {                       // lanes were laid out for Qcap; re-slice for this Q

@@ -68,27 +68,85 @@ class Ctx:
 
 
 # ---------------------------------------------------------------------------------------------------------- workloads
+def shared_dir(ctx):
+    """Where the ranks of one node share the host graph: a directory in /dev/shm (tmpfs = page cache), /tmp if that is too small."""
+    tag = f"bang_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    for base in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):
+        try:
+            st = os.statvfs(base)
+            if st.f_bavail * st.f_frsize > (1 << 30):
+                return os.path.join(base, tag)
+        except OSError:
+            pass
+    return os.path.join("/tmp", tag)
+
+
 def build_workload(name, ctx, Q=0, shape_n=0):
-    """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), release()."""
+    """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), prefix (index files, N > 1), release().
+
+    N > 1 (one process per GPU): ONE host graph for the node (the reference keeps one pIndex in host RAM,
+    bang_search.cu:312-328).  Structured workloads: rank 0 builds the index and writes the reference-format FILES into a tmpfs
+    directory; every rank loads them through bang_load, which maps `_disk.bin` shared and read-only.  Shape-only workloads: rank 0
+    fills one shared mapping, the others map it; every rank generates the (identical, seeded) PQ codes on its own GPU."""
     import torch
-    from bang_amd import synth
+    import torch.distributed as dist
+    from bang_amd import formats, synth
     t0 = time.time()
+    world, rank = ctx.world, ctx.rank
+    prefix = None
+    sdir = shared_dir(ctx) if world > 1 else None
+    if sdir and rank == 0:
+        os.makedirs(sdir, exist_ok=True)
     if name.endswith("_shape"):
         from tools import shape_workload
+        shared = None
+        if world > 1:
+            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
+            dist.broadcast(n_plan, 0)
+            shape_n = int(n_plan.item())
+            shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
         ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
-            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log)
-        rel = lambda: shape_workload.release(ix)   # noqa: E731
+            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared)
+
+        def rel():
+            shape_workload.release(ix)
+            if world > 1:
+                dist.barrier()
+                if rank == 0:
+                    try:
+                        os.unlink(shared[0])
+                    except OSError:
+                        pass
     else:
         N, D, dtype, R, m, Qd, ncl = WORKLOADS[name]
-        ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
-        d_codes, shape_graph = None, "host"
         wl_name = (f"{name}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
                    f"Q={Q or Qd} k={ctx.k} (kNN+random-link graph, trained PQ, brute-force GT)")
-        rel = lambda: None   # noqa: E731
+        d_codes, shape_graph = None, "host"
+        if world == 1:
+            ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+            rel = lambda: None   # noqa: E731
+        else:
+            prefix = os.path.join(sdir, name)
+            if rank == 0:
+                ix0, q0_, gi0, gd0 = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+                formats.write_index(prefix, ix0)
+                np.save(prefix + "_queries.npy", q0_)
+                np.save(prefix + "_gt_ids.npy", gi0)
+                np.save(prefix + "_gt_dists.npy", gd0)
+                del ix0
+            dist.barrier()
+            ix = formats.read_index(prefix, dtype, mmap_graph=True)       # host-side view for the oracle spot check; graph = shared map
+            queries, gt_i, gt_d = np.load(prefix + "_queries.npy"), np.load(prefix + "_gt_ids.npy"), np.load(prefix + "_gt_dists.npy")
+
+            def rel():
+                dist.barrier()
+                if rank == 0:
+                    import shutil
+                    shutil.rmtree(sdir, ignore_errors=True)
     torch.cuda.synchronize()
     log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
     return dict(ix=ix, queries=queries, gt_i=gt_i, gt_d=gt_d, d_codes=d_codes, name=wl_name, graph=shape_graph, release=rel,
-                key=name)
+                key=name, prefix=prefix)
 
 
 # ---------------------------------------------------------------------------------------------------------- one measurement
@@ -96,7 +154,10 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1):
     import bang_amd
     gm = {"host": bang_amd.GRAPH_HOST, "device": bang_amd.GRAPH_DEVICE, "auto": bang_amd.GRAPH_AUTO}[graph]
     eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing)
-    eng.load_index(wl["ix"], d_codes=wl["d_codes"])
+    if wl.get("prefix"):
+        eng.load(wl["prefix"])                   # bang_load on the shared index files: `_disk.bin` is mapped, not copied
+    else:
+        eng.load_index(wl["ix"], d_codes=wl["d_codes"])
     return eng
 
 
@@ -111,7 +172,7 @@ def run_once(eng, my_q, ctx, timed=False, gather=True):
         torch.cuda.synchronize()
     t_a = time.perf_counter()
     ids, dists = eng.query(my_q)
-    if ctx.world > 1 and gather:                         # the single RCCL collective of the job
+    if ctx.world > 1 and gather and not ctx.weak:        # the single RCCL collective of the job (none in throughput mode)
         shard.gather_ids(ids, ctx.Q_total, ctx.k, ctx.rank, ctx.world, device=ctx.cdev)
     if timed:
         torch.cuda.synchronize()
@@ -337,6 +398,7 @@ def main():
     ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     ctx.k = k = args.k
+    ctx.weak = False
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -367,6 +429,7 @@ def main():
     graph = args.graph or wl["graph"]          # sift1m: "host" = the north-star path
     ctx.Q_total = Q = queries.shape[0]
     weak = world > 1 and args.batches > 1
+    ctx.weak = weak
     if weak:
         q0, q1 = 0, Q                          # throughput mode: every rank searches whole batches
     else:

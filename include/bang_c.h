@@ -69,7 +69,8 @@ int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   
  *   "pq"      : 0 = pivot-stationary fused distance (default when it fits LDS), 1 = LUT path (K1+K2)
  *   "timing"  : 1 = stamp every front-kernel launch in-kernel (s_memrealtime) for bang_get_stats
  *   "numa"    : graph in host RAM: 1 = pin the walker threads (and the caller during bang_query) to the CPUs of the GPU's NUMA node,
- *               0 = leave them where the OS puts them, -1 = auto (pin when the node is known and offers enough usable CPUs)
+ *               one physical core each; 0 = leave them where the OS puts them; -1 = auto = 0 (pinning measured slower on the
+ *               2-socket measurement box)
  *   "search"  : graph in HBM: 1 = the query-resident search kernel (bang_k_search), 0 = the round-1 loops, -1 = auto */
 int bang_set_option(bang_engine_t* e, const char* key, long value);
 

@@ -1,0 +1,57 @@
+"""The N > 1 path of bench.py on a 1-GPU box: two ranks (one process each, launched exactly as the driver launches them) share
+GPU 0 (BANG_BENCH_SHARE_GPU) and ONE host graph -- rank 0 writes the index files into tmpfs, both ranks load them through
+bang_load, which maps `_disk.bin` shared.  Each rank searches its shard with the real engine; the result ids are gathered with
+the job's single collective (gloo here: RCCL refuses two ranks on one device).  Every rank checks its shard against the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(nproc, extra, timeout=380):
+    env = dict(os.environ, BANG_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    base = ["bench.py", "--gpus", str(nproc), "--workload", "tiny", "--L", "46", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--no-legs", "--backend", "gloo"] + extra
+    if nproc == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + base
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("graph", ["host", "device"])
+def test_two_ranks_one_gpu_one_host_graph(libbang, graph):
+    one = _bench(1, ["--graph", graph])
+    two = _bench(2, ["--graph", graph])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["config"]["parity_vs_oracle_first_64"] is True and two["config"]["parity_vs_oracle_first_64"] is True
+    assert two["config"]["graph"] == graph and two["config"]["L"] == 46
+    # the sharded job answers the same 1000 queries: the worst shard's recall cannot beat the whole batch's by much, nor fall far
+    assert abs(two["config"]["recall_at_10"] - one["config"]["recall_at_10"]) < 3.0
+    assert two["value"] > 0 and two["ms_per_step"] > 0
+
+
+def test_two_ranks_throughput_mode(libbang):
+    """--batches 2: every rank streams two WHOLE batches per step, no collective on the data path ("scaling": "weak")."""
+    two = _bench(2, ["--graph", "device", "--batches", "2"])
+    assert two["scaling"] == "weak" and two["config"]["batches_per_step"] == 2
+    assert two["config"]["parity_vs_oracle_first_64"] is True

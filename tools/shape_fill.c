@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <omp.h>
 
 static inline uint64_t splitmix(uint64_t *s) {
@@ -23,6 +25,19 @@ void *shape_alloc(size_t bytes) {
   return p;
 }
 void shape_free(void *p, size_t bytes) { if (p) munmap(p, bytes); }
+
+/* A mapping of the file `path` shared by all processes that map it (the ranks of a multi-GPU job walk ONE host graph).
+ * create != 0: the file is created and sized (its pages are filled by the creator); otherwise it must exist.  NULL on failure. */
+void *shape_map_shared(const char *path, size_t bytes, int create) {
+  int fd = open(path, create ? (O_CREAT | O_RDWR | O_TRUNC) : O_RDWR, 0600);
+  if (fd < 0) return NULL;
+  if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return NULL; }
+  void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return NULL;
+  madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
+}
 
 /* vec_float != 0: the vector part holds vec_bytes/4 floats, uniform in [-1, 1) (random bytes are not sane floats) */
 void shape_fill_graph(uint8_t *graph, uint64_t N, uint32_t vec_bytes, uint32_t R, uint64_t seed, int nthreads, int vec_float) {

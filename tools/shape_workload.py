@@ -34,6 +34,8 @@ def _lib():
     lib.shape_alloc.restype = C.c_void_p
     lib.shape_alloc.argtypes = [C.c_size_t]
     lib.shape_free.argtypes = [C.c_void_p, C.c_size_t]
+    lib.shape_map_shared.restype = C.c_void_p
+    lib.shape_map_shared.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
     lib.shape_fill_graph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
     lib.shape_fill_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     return lib
@@ -65,6 +67,21 @@ def usable_host_bytes() -> int:
     return avail
 
 
+def plan_n(name, dev, n_override=0):
+    """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything."""
+    import torch
+    sh = SHAPES[name]
+    isz = 4 if sh["dtype"] == "float" else 1
+    entry = sh["D"] * isz + 4 + 4 * sh["R"]
+    N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
+    if sh["graph"] == "host":
+        N = min(N, int(usable_host_bytes() * 0.75) // entry)
+    else:
+        free, _ = torch.cuda.mem_get_info(dev)
+        N = min(N, (int(free * 0.85) - (8 << 30)) // (entry + sh["m"]), int(usable_host_bytes() * 0.75) // entry)
+    return int(N)
+
+
 class ShapeIndex:
     """Duck-types bang_amd.formats.Index for Engine.load_index (graph is a numpy view of the mmap'ed image)."""
 
@@ -76,9 +93,11 @@ class ShapeIndex:
         return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
 
 
-def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False):
+def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None):
     """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
-    can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent."""
+    can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent.
+    shared=(path, is_creator, barrier): the graph image lives in ONE mapping of the file `path` shared by every rank of the node
+    (the creator fills it, the others map it after `barrier()`); N is derived from the memory of the node, not of a rank."""
     import torch
     from bang_amd.synth import chunk_offsets
     sh = dict(SHAPES[name])
@@ -89,7 +108,9 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     lib = _lib()
     ncpu = usable_cpus()
     note = ""
-    if sh["graph"] == "host":
+    if shared is not None and n_override:
+        pass                                   # N was planned once for the node (plan_n on the creator) and handed to every rank
+    elif sh["graph"] == "host":
         budget = int(usable_host_bytes() * 0.75)
         if N * entry > budget:
             N2 = budget // entry
@@ -109,10 +130,24 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
             N = N2
     t0 = time.time()
     gbytes = N * entry
-    ptr = lib.shape_alloc(gbytes)
-    if not ptr:
-        raise MemoryError(f"cannot map {gbytes} bytes")
-    lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu, 1 if sh["dtype"] == "float" else 0)   # floats: uniform in [-1, 1)
+    if shared is not None:
+        path, creator, barrier = shared
+        if creator:
+            ptr = lib.shape_map_shared(path.encode(), gbytes, 1)
+            if not ptr:
+                raise MemoryError(f"cannot create the shared mapping {path} ({gbytes} bytes)")
+            lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu, 1 if sh["dtype"] == "float" else 0)
+            barrier()
+        else:
+            barrier()
+            ptr = lib.shape_map_shared(path.encode(), gbytes, 0)
+            if not ptr:
+                raise MemoryError(f"cannot map the shared graph {path}")
+    else:
+        ptr = lib.shape_alloc(gbytes)
+        if not ptr:
+            raise MemoryError(f"cannot map {gbytes} bytes")
+        lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu, 1 if sh["dtype"] == "float" else 0)   # floats: uniform in [-1, 1)
     graph = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(gbytes,)).reshape(N, entry)
     log(f"[shape] graph image {gbytes / 2**30:.1f} GiB filled in {time.time() - t0:.1f}s with {ncpu} threads{note}")
     t0 = time.time()
