@@ -10,7 +10,8 @@ One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
 * N = 1 (the default): the workload is BASELINE.json configs[1] (SIFT1M-like, 10 000 queries) on the north-star path (graph in
   host RAM, C++ walker).  The same JSON line carries, under `config`, the other single-GPU configurations as LEGS, each timed
   the same way on its own index: `at_device_graph` (configs[1] with the graph in HBM), `at_L200` (configs[1]'s L = 200),
-  `at_deep100m_shape` (configs[2]) and `at_sift1b_shape` (configs[3]: the shape the target number is quoted on).
+  `at_deep100m_shape` (configs[2]), `at_sift1b_shape` (configs[3]: the shape the target number is quoted on) and `at_sift10m`
+  (a recall-verified structured index whose code table no longer fits the Infinity Cache).
 * N > 1: the 10K-query batch is split into contiguous shards, one per rank; every rank searches its shard on its own replica of
   the PQ table, all ranks share ONE read-only host graph, and ONE RCCL all-gather of the result ids ends the step
   ("scaling": "strong": the total work is fixed).  `--batches B` instead streams B whole 10K batches per rank and step
@@ -38,6 +39,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); 6
 WORKLOADS = {
     # name: (N, D, dtype, R, m, Q, clusters)
     "sift1m": (1_000_000, 128, "uint8", 64, 32, 10_000, 256),   # BASELINE.json configs[1]
+    "sift10m": (10_000_000, 128, "uint8", 64, 32, 10_000, 1024),  # structured index beyond the Infinity Cache (320 MB of codes, 3.9 GB graph):
+                                                                  # Vamana-style build on the GPU (bang_amd/index_build.py), SURVEY 8 f-3
     "small": (100_000, 128, "uint8", 64, 32, 10_000, 64),       # quick functional run
     "tiny": (20_000, 128, "uint8", 64, 32, 1_000, 32),
 }
@@ -122,13 +125,21 @@ def build_workload(name, ctx, Q=0, shape_n=0):
         wl_name = (f"{name}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
                    f"Q={Q or Qd} k={ctx.k} (kNN+random-link graph, trained PQ, brute-force GT)")
         d_codes, shape_graph = None, "host"
+        def make():
+            if N > 2_000_000:                    # exact kNN by brute force stops being practical: partitioned search + robust prune
+                from bang_amd import index_build
+                return index_build.make_index_large(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev, log=log)
+            return synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+        if N > 2_000_000:
+            wl_name = wl_name.replace("SIFT1M-like structured synthetic", "SIFT-like structured synthetic").replace(
+                "kNN+random-link graph", "robust-pruned (alpha 1.2) approximate-kNN + random-link graph")
         if world == 1:
-            ix, queries, gt_i, gt_d = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+            ix, queries, gt_i, gt_d = make()
             rel = lambda: None   # noqa: E731
         else:
             prefix = os.path.join(sdir, name)
             if rank == 0:
-                ix0, q0_, gi0, gd0 = synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
+                ix0, q0_, gi0, gd0 = make()
                 formats.write_index(prefix, ix0)
                 np.save(prefix + "_queries.npy", q0_)
                 np.save(prefix + "_gt_ids.npy", gi0)
@@ -583,6 +594,38 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:                          # a leg must never take the primary line down
                 cfg[f"at_{name}"] = {"error": repr(ex)[:300]}
+        # a structured index beyond the Infinity Cache (N = 10 M: 320 MB of codes, 3.9 GB graph), recall-verified, both placements
+        try:
+            w3 = build_workload("sift10m", ctx)
+            q3 = np.ascontiguousarray(w3["queries"])
+            orc3 = O.Oracle(w3["ix"])
+            L3 = 0
+            for gname in ("host", "device"):
+                e4 = make_engine(w3, gname, ctx, timing=0 if args.no_events else 1)
+                if L3 == 0:
+                    for cand in range(k, 513, 12):           # smallest L on the harness grid with recall >= target
+                        e4.set_searchparams(k, cand)
+                        e4.alloc(q3.shape[0])
+                        ids_c, _, _ = run_once(e4, q3, ctx)
+                        e4.free()
+                        if O.recall(w3["gt_i"], w3["gt_d"], ids_c, k) >= args.recall_target:
+                            L3 = cand
+                            break
+                    if L3 == 0:
+                        raise RuntimeError("recall target not reached")
+                e4.set_searchparams(k, L3)
+                e4.alloc(q3.shape[0])
+                r5 = measure(e4, w3, q3, L3, leg_steps, leg_warm, ctx, gname)
+                ids_o3, _ = orc3.search(q3[:64], k, L3)
+                cfg["at_sift10m" if gname == "host" else "at_sift10m_device_graph"] = leg_summary(
+                    r5, w3, gname, recall=O.recall(w3["gt_i"], w3["gt_d"], r5["ids"], k),
+                    extra={"parity_vs_oracle_first_64": bool(np.array_equal(r5["ids"][:64], ids_o3))})
+                e4.free(); e4.unload(); e4.close()
+            w3["release"]()
+            del w3, q3, orc3
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            cfg["at_sift10m"] = {"error": repr(ex)[:300]}
         if out is not None and out["roofline"] is not None:
             out["roofline"]["k2_alone"] = k2.get(f"m{WORKLOADS[args.workload][4]}")
             out["roofline"]["k2_alone_other_layouts"] = {kk: v for kk, v in k2.items() if kk != f"m{WORKLOADS[args.workload][4]}"}
