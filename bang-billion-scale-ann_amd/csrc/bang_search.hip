@@ -52,6 +52,26 @@ __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // globa
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Wave-wide minimum of a 64-bit key {hi, lo} (lexicographic, unsigned), returned to every lane.  Six DPP steps (quad swaps, row
+// half-mirror / mirror, two row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar per operand.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(uint32_t& hi, uint32_t& lo) {
+  const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+  const bool take = ohi < hi || (ohi == hi && olo < lo);
+  if (take) { hi = ohi; lo = olo; }
+}
+__device__ __forceinline__ void wave_min_key(uint32_t& hi, uint32_t& lo) {
+  dpp_min_step<0xB1, 0xf>(hi, lo);      // quad_perm [1,0,3,2]
+  dpp_min_step<0x4E, 0xf>(hi, lo);      // quad_perm [2,3,0,1]
+  dpp_min_step<0x141, 0xf>(hi, lo);     // row_half_mirror
+  dpp_min_step<0x140, 0xf>(hi, lo);     // row_mirror            -> every lane of a 16-lane row holds the row's minimum
+  dpp_min_step<0x142, 0xa>(hi, lo);     // row_bcast15 into rows 1 and 3
+  dpp_min_step<0x143, 0xc>(hi, lo);     // row_bcast31 into rows 2 and 3 -> lane 63 holds the minimum of the wave
+  hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+  lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K5, second half (:1159-1160): set the two filter bits of every survivor -- plain stores, same-word lanes merged in LDS
 // ---------------------------------------------------------------------------------------------------------------------
@@ -477,17 +497,13 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
       const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
       PH(4);   // code rows returned + distances
-      float bd = elig ? d0 : BIG_DIST;
-      uint32_t bi = elig ? (uint32_t)lane : 0xFFFFu;
-      uint32_t bid = sid0;
-#pragma unroll
-      for (int off = 1; off < WAVE; off <<= 1) {
-        const float od = __shfl_xor(bd, off);
-        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
-        const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
-        const bool take = (oi != 0xFFFFu) && (bi == 0xFFFFu || od < bd || (od == bd && oi < bi));
-        if (take) { bd = od; bi = oi; bid = oid; }
-      }
+      // (PQ distances are sums of squares: non-negative floats order like their bit patterns, so {distance bits, lane} is a key
+      // whose minimum is "smallest distance, first lane wins")
+      uint32_t khi = elig ? __float_as_uint(d0) : 0xFFFFFFFFu, klo = (uint32_t)lane;
+      wave_min_key(khi, klo);
+      uint32_t bi = (khi != 0xFFFFFFFFu) ? klo : 0xFFFFu;
+      float bd = (khi != 0xFFFFFFFFu) ? __uint_as_float(khi) : BIG_DIST;
+      uint32_t bid = (uint32_t)__builtin_amdgcn_readlane((int)sid0, (int)(klo & 63u));
       if (n > 64) {                                            // element 64 can only win with a strictly smaller distance
         const float e_d = __shfl(d1, 0);
         const uint32_t e_id = (uint32_t)__shfl((int)sid1, 0);
