@@ -62,8 +62,19 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // popcount of
 // second term, which is what the padded table computes for it (fmaf(0, 0, t) == t).  NHI is a template parameter so that every
 // entry address stays "code * size + immediate" (a runtime split costs an address register per chunk: measured as 100-200
 // spilled VGPRs in every 2-float instance).
-template <int PSZ, int NHI>
-__device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, cfloat_p qc, uint32_t c, uint32_t code) {
+// QC: where the centred query comes from -- anything indexable by the padded dimension number.  `cfloat_p` (constant address
+// space: scalar loads) or QcRegs (the wave's registers, one v_readlane per element: no memory wait at all; scalar loads return
+// out of order, so every use of one forces `s_waitcnt lgkmcnt(0)` and with it a drain of the LDS reads in flight).
+template <int NV>
+struct QcRegs {
+  float v[NV];                                  // lane l of v[r] holds qc[64 r + l]
+  __device__ __forceinline__ float operator[](uint32_t i) const {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v[i >> 6]), (int)(i & 63u)));
+  }
+};
+
+template <int PSZ, int NHI, class QC>
+__device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, const QC& qc, uint32_t c, uint32_t code) {
   float t = 0.0f;
   if (PSZ == 2 && NHI > 0) {
     if (c < (uint32_t)NHI) {
@@ -136,9 +147,9 @@ __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_
 // SB > 0: the row is consumed in segments of SB code dwords; a dependency fence between segments keeps the compiler from hoisting
 // the LDS reads of the whole row (72 chunks of the 70/74-chunk layouts) in front of the first add -- that is what pushed those
 // instances past 128 VGPRs.
-template <int PSZ, int NDW, bool ALIGNED, int NHI, int SB = 0>
+template <int PSZ, int NDW, bool ALIGNED, int NHI, int SB = 0, class QC = cfloat_p>
 __device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds,
-                                               cfloat_p qc) {
+                                               const QC& qc) {
   float s[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = 0.0f;

@@ -325,6 +325,21 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   uint32_t q = 0, iter = 0, w_n = 0, cc = 0, mark = 0, evals = 0, fetched = 0;
   uint32_t cnt_in = 0, x0 = 0, x1 = 0;
   bool have_row = false;
+  // the centred query of the current context, in registers (lane l of qc.v[r] = element 64 r + l; read with v_readlane): loaded
+  // once per query instead of streamed through scalar loads in every iteration's distance stage
+  constexpr int QW = NDW * 4 * PSZ;
+  constexpr int NV = (QW + 63) / 64;
+  QcRegs<NV> qc;
+#pragma unroll
+  for (int r = 0; r < NV; ++r) qc.v[r] = 0.0f;
+  auto load_qc = [&](uint32_t qq) {
+    const float* src = p.d_qc + (size_t)qq * QW;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+      qc.v[r] = src[i < (uint32_t)QW ? i : 0u];
+    }
+  };
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -361,6 +376,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         const uint32_t* pk = park + c * SRCH_CTX_WORDS;
         active = pk[0] != 0u; q = pk[1]; iter = pk[2]; w_n = pk[3]; cc = pk[4]; mark = pk[5]; evals = pk[6]; fetched = pk[7];
         have_row = pk[8] != 0u;
+        if (active) load_qc(q);
       }
       // ---------------- wait for the rows of this context's previous round
       if (round > 1) {
@@ -409,6 +425,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
+        load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
         cnt_in = p.d_seed[0]; x0 = p.d_seed[1 + lane]; x1 = p.d_seed[65];
         have_row = true;
@@ -416,7 +433,6 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
     }
     if (!HOST && !active) break;
     uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
-    cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q * (NDW * 4 * PSZ));
 
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
@@ -637,6 +653,138 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   if (p.d_ktime) {
     __syncthreads();
     if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2 alone, streaming form (compute_neighborDist_par :1201-1241): dist[q][j] for the cnt[q] <= 64 neighbours of every query
+// ---------------------------------------------------------------------------------------------------------------------
+// The stage the BASELINE metric quotes an HBM figure for.  One wave per query row at a time, the NEXT row's ids and code rows in
+// flight while the current one is reduced (two register sets, ping-pong), pivot table in LDS, centred query through scalar loads:
+// the launch is bound by how fast the memory system returns random 32-74-byte rows, not by dependent round trips.
+template <int PSZ, int NDW, bool ALIGNED, int NHI, int MAXT>
+__global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_params p, uint32_t lds_piv_floats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* piv_lds = lds;
+  {
+    const float4* src = (const float4*)p.d_pivots_packed;
+    float4* dst = (float4*)piv_lds;
+    const uint32_t n4 = lds_piv_floats >> 2;
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  constexpr int SB = (NDW >= 18) ? 6 : 0;
+  const int lane = lane_id();
+  const uint32_t nwaves = blockDim.x >> 6;
+  const uint32_t step = gridDim.x * nwaves;
+  uint32_t q = blockIdx.x * nwaves + uni(threadIdx.x >> 6);
+  if (q >= p.Q) return;
+  PqRow<NDW, ALIGNED> rowA, rowB;
+  constexpr int QW = NDW * 4 * PSZ;                 // floats of a centred query (padded layout)
+  constexpr int NV = (QW + 63) / 64;
+  QcRegs<NV> qcA, qcB;                              // the centred query in registers: no scalar-load waits inside the reduce
+  auto load_qc = [&](QcRegs<NV>& dst, uint32_t qq) {
+    const float* src = p.d_qc + (size_t)qq * QW;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+      dst.v[r] = src[i < (uint32_t)QW ? i : 0u];
+    }
+  };
+  uint32_t nA = uni(p.d_cnt[q]), nB = 0;
+  if (nA > 64) nA = 64;
+  uint32_t idA = p.d_nbrs[(size_t)q * BANG_NBR_STRIDE + lane], idB = 0;
+  load_qc(qcA, q);
+  if ((uint32_t)lane < nA) pq_row_load(rowA, p.d_codes, p.m, idA);
+  for (;;) {
+    // ---- issue B (the row after A), reduce A
+    const uint32_t qB = q + step;
+    const bool hasB = qB < p.Q;
+    if (hasB) {
+      nB = uni(p.d_cnt[qB]);
+      if (nB > 64) nB = 64;
+      idB = p.d_nbrs[(size_t)qB * BANG_NBR_STRIDE + lane];
+      load_qc(qcB, qB);
+      if ((uint32_t)lane < nB) pq_row_load(rowB, p.d_codes, p.m, idB);
+    }
+    {
+      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowA, piv_lds, qcA);     // all lanes: v_readlane needs no exec mask games
+      if ((uint32_t)lane < nA) p.d_dist[(size_t)q * BANG_NBR_STRIDE + lane] = d;
+    }
+    if (!hasB) break;
+    // ---- issue A (the row after B), reduce B
+    q = qB + step;
+    const bool hasA = q < p.Q;
+    if (hasA) {
+      nA = uni(p.d_cnt[q]);
+      if (nA > 64) nA = 64;
+      idA = p.d_nbrs[(size_t)q * BANG_NBR_STRIDE + lane];
+      load_qc(qcA, q);
+      if ((uint32_t)lane < nA) pq_row_load(rowA, p.d_codes, p.m, idA);
+    }
+    {
+      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowB, piv_lds, qcB);
+      if ((uint32_t)lane < nB) p.d_dist[(size_t)qB * BANG_NBR_STRIDE + lane] = d;
+    }
+    if (!hasA) break;
+  }
+}
+
+template <int PSZ, int NDW, bool ALIGNED, int NHI>
+static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
+  constexpr int MAXT = (NDW >= 18) ? 512 : 1024;          // two long rows in flight need the 256-VGPR budget
+  static bool attr_done[BANG_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_done[dev] = true;
+  }
+  const uint32_t cus = (uint32_t)num_cus();
+  const uint32_t waves = MAXT / WAVE;
+  uint32_t grid = (p.Q + waves - 1) / waves;
+  if (grid > cus) grid = cus;
+  hipLaunchKernelGGL((pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>), dim3(grid), dim3(MAXT), (size_t)piv_floats * 4, st, p, piv_floats);
+  HIP_TRY(hipGetLastError());
+  return BANG_OK;
+}
+
+template <int PSZ, int NDW>
+static int launch_pqdist_al(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
+  const bool al = (p.m % 4u) == 0;
+  if (p.pq_nhi) {
+    constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
+    if constexpr (NHI != 0) {
+      if ((int)p.pq_nhi == NHI && !al) return launch_pqdist_inst<PSZ, NDW, false, NHI>(p, piv_floats, st);
+    }
+    bang_set_error("no K2 instance for the exact-size pivot table psz=%u mp=%u nhi=%u", p.psz, p.mp, p.pq_nhi);
+    return BANG_ERR_UNSUPPORTED;
+  }
+  return al ? launch_pqdist_inst<PSZ, NDW, true, 0>(p, piv_floats, st) : launch_pqdist_inst<PSZ, NDW, false, 0>(p, piv_floats, st);
+}
+
+extern "C" int bang_k_pqdist_stream(const bang_iter_params* p, void* stream) {
+  if (!p) return BANG_ERR_ARG;
+  if (p->Q == 0) return BANG_OK;
+  if (p->psz == 0 || p->mp < p->m || (p->mp & 3u) || p->m == 0) { bang_set_error("K2 streaming form needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
+  if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_pivots_packed || !p->d_qc) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
+  if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
+  const uint32_t pf = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
+  hipStream_t st = (hipStream_t)stream;
+  switch (p->psz * 100u + p->mp / 4u) {
+    case 108: return launch_pqdist_al<1, 8>(*p, pf, st);
+    case 116: return launch_pqdist_al<1, 16>(*p, pf, st);
+    case 124: return launch_pqdist_al<1, 24>(*p, pf, st);
+    case 132: return launch_pqdist_al<1, 32>(*p, pf, st);
+    case 208: return launch_pqdist_al<2, 8>(*p, pf, st);
+    case 216: return launch_pqdist_al<2, 16>(*p, pf, st);
+    case 218: return launch_pqdist_al<2, 18>(*p, pf, st);
+    case 219: return launch_pqdist_al<2, 19>(*p, pf, st);
+    case 404: return launch_pqdist_al<4, 4>(*p, pf, st);
+    case 408: return launch_pqdist_al<4, 8>(*p, pf, st);
+    case 802: return launch_pqdist_al<8, 2>(*p, pf, st);
+    case 804: return launch_pqdist_al<8, 4>(*p, pf, st);
+    default: bang_set_error("no K2 instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
   }
 }
 

@@ -7,9 +7,10 @@ kernel and of the PQ-distance stage (K2) alone, and the CPU baseline.
 
 One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
 
-* N = 1 (the default): the workload is BASELINE.json configs[1] (SIFT1M-like, 10 000 queries) on the north-star path (graph in
-  host RAM, C++ walker).  The same JSON line carries, under `config`, the other single-GPU configurations as LEGS, each timed
-  the same way on its own index: `at_device_graph` (configs[1] with the graph in HBM), `at_L200` (configs[1]'s L = 200),
+* N = 1 (the default): the workload is BASELINE.json configs[1] (SIFT1M-like, 10 000 queries) with the engine's default
+  placement ("auto": a 388 MB graph goes to HBM).  The same JSON line carries, under `config`, the other single-GPU
+  configurations as LEGS, each timed the same way on its own index: `at_host_graph` (configs[1] on the north-star path: graph
+  in host RAM, C++ walker, adjacency rows through the PCIe BAR), `at_L200` (configs[1]'s L = 200),
   `at_deep100m_shape` (configs[2]), `at_sift1b_shape` (configs[3]: the shape the target number is quoted on) and `at_sift10m`
   (a recall-verified structured index whose code table no longer fits the Infinity Cache).
 * N > 1: the 10K-query batch is split into contiguous shards, one per rank; every rank searches its shard on its own replica of
@@ -350,27 +351,22 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
     p.d_nbrs, p.d_dist, p.d_cnt, p.d_seed = nbrs.data_ptr(), dist_o.data_ptr(), cnt.data_ptr(), seed.data_ptr()
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
-    entry = B.lib().bang_k_pqdist if not nhi else None
-    if entry is None:
-        # the exact-size table only has the fused production instance; the stage-only entry uses the padded table
-        packed = torch.from_numpy(B.pack_pivots(pivots, chunk_off, D, m, psz, mp).reshape(-1)).to(dev)
-        p.d_pivots_packed, p.pq_nhi = packed.data_ptr(), 0
-        entry = B.lib().bang_k_pqdist
+    entry = B.lib().bang_k_pqdist_stream          # K2 alone, streaming form (next row in flight while the current one is reduced)
     for _ in range(2):
-        B._check(entry(C.byref(p), sp), "bang_k_pqdist")
+        B._check(entry(C.byref(p), sp), "bang_k_pqdist_stream")
     torch.cuda.synchronize()
     us = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        B._check(entry(C.byref(p), sp), "bang_k_pqdist")
+        B._check(entry(C.byref(p), sp), "bang_k_pqdist_stream")
         e1.record(stream)
         e1.synchronize()
         us.append(e0.elapsed_time(e1) * 1e3)
     avg = float(np.mean(us))
     evals = Qk * 64
     ach = evals * (m + 8) / (avg * 1e-6) / 1e9
-    out = {"kernel": "front_kernel<stage = K2 only> via bang_k_pqdist", "m": m, "D": D, "psz_mp": [psz, mp],
+    out = {"kernel": "pqdist_stream_kernel (K2 alone) via bang_k_pqdist_stream", "m": m, "D": D, "psz_mp": [psz, mp],
            "code_table_bytes": N * m, "evals_per_launch": evals, "algorithmic_bytes_per_launch": evals * (m + 8),
            "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "achieved": round(ach, 1), "unit": "GB/s",
            "peak": HBM_PEAK_GBPS, "frac": round(ach / HBM_PEAK_GBPS, 4), "rows_per_s": round(evals / (avg * 1e-6) / 1e9, 2),
@@ -437,7 +433,9 @@ def main():
 
     wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n)
     ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
-    graph = args.graph or wl["graph"]          # sift1m: "host" = the north-star path
+    # placement: the engine's own default ("auto": the whole graph in HBM when it fits next to the PQ codes with 16 GB to spare,
+    # else host RAM + C++ walker) for the structured workloads; the shape-only workloads use the placement BASELINE.json names
+    graph = args.graph or ("auto" if gt_i is not None else wl["graph"])
     ctx.Q_total = Q = queries.shape[0]
     weak = world > 1 and args.batches > 1
     ctx.weak = weak
@@ -450,7 +448,7 @@ def main():
 
     lanes = args.lanes or int(os.environ.get("BANG_LANES", "0"))
     threads = args.threads or int(os.environ.get("BANG_THREADS", "0"))
-    if world > 1 and graph == "host":
+    if world > 1 and graph in ("host", "auto"):
         # all ranks of the node share one CPU quota: size the walker team from this rank's share of it
         share = max(1, usable_cpus() // world)
         if not threads:
@@ -488,6 +486,11 @@ def main():
     # ------------------------------------------------------------------ timed steps of the primary workload
     eng.set_searchparams(k, L)
     eng.alloc(Qr)
+    placement_note = None
+    if graph == "auto":                                  # what did "auto" resolve to?
+        run_once(eng, my_q, ctx)
+        graph = "device" if eng.stats()["graph_mode"] == 1 else "host"
+        placement_note = f"auto -> {graph} (engine default: graph in HBM when it fits next to the PQ codes with 16 GB to spare)"
     res = measure(eng, wl, my_q, L, args.steps, args.warmup, ctx, graph, traffic_key=f"{args.workload}_{graph}",
                   batches=args.batches if weak else 1)
     ids, dists, agg = res["ids"], res["dists"], res["agg"]
@@ -526,7 +529,8 @@ def main():
                              f"the CPU quota of this box; {os.cpu_count()} hardware threads visible), same timed region "
                              f"(search only)"}
         cfg = {"workload": wl["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
-               "graph": graph, "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
+               "graph": graph, "graph_placement": placement_note or f"{graph} (requested)",
+               "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
                "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
                "iterations": agg["iterations"], "hops_p50_p99_max": [agg["hops_p50"], agg["hops_p99"], agg["hops_max"]],
                "host_loop": "persistent search kernel" if agg["persistent"] else "launch per iteration",

@@ -324,6 +324,10 @@ int bang_k_back(const bang_iter_params* p, void* stream);
 int bang_k_filter(const bang_iter_params* p, void* stream);   /* K5 only: d_stage/d_seed -> d_nbrs, d_cnt */
 int bang_k_pqdist(const bang_iter_params* p, void* stream);   /* K2 only: d_nbrs,d_cnt -> d_dist */
 int bang_k_parent(const bang_iter_params* p, void* stream);   /* K4 only */
+/* K2 only, streaming form (csrc/bang_search.hip): the same distances as bang_k_pqdist for the first min(d_cnt[q], 64) neighbours of
+ * every query (R <= 64: every row the search path ever produces but the 65-entry seed list), with the next row's ids and code rows in
+ * flight while the current one is reduced.  This is the launch the K2-alone HBM roofline figure is measured on. */
+int bang_k_pqdist_stream(const bang_iter_params* p, void* stream);
 
 /* Fused K6 + K7: compute_L2Dist (bang_search.cu:1254-1299) -> compute_NearestNeighbours (:1312-1368).
  * Candidate i of query q has its vector at d_vec_base + (row*Q + q)*vec_stride (row = d_cand_row, host-graph

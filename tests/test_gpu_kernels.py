@@ -197,3 +197,37 @@ def test_persistent_search_kernel_alone(request, libbang, fixture, L, ragged):
     ids, dists = st.rerank(10)
     assert np.array_equal(ids, ids_o)
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("fixture,ragged", [("small_f32", False), ("small_u8", False), ("small_u8", True), ("small_deep", True),
+                                            ("small_i8", False)])
+def test_pqdist_streaming_form_matches_oracle(request, libbang, fixture, ragged):
+    """bang_k_pqdist_stream (the launch the K2-alone roofline figure is measured on): same canonical float order, bit for bit,
+    with ragged neighbour counts (0..64) and more queries than one sweep of the grid's waves handles (the ping-pong loop)."""
+    import ctypes as C
+    from bang_amd import binding as B
+    from bang_amd.binding import IterState
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    orc = O.Oracle(ix)
+    Q = 700
+    qq = np.ascontiguousarray(np.tile(q, ((Q + q.shape[0] - 1) // q.shape[0], 1))[:Q])
+    st = IterState(ix, qq, 16, ragged=ragged)
+    rng = np.random.default_rng(11)
+    cnt = rng.integers(0, 65, Q).astype(np.uint32)
+    cnt[:3] = (64, 0, 1)
+    nb = np.zeros((Q, B.NBR_STRIDE), np.uint32)
+    for i in range(Q):
+        nb[i, :cnt[i]] = rng.choice(ix.N, cnt[i], replace=False)
+    st.d_nbrs.upload(nb)
+    st.d_cnt.upload(cnt)
+    st.d_dist.zero()
+    p = st.params()
+    B._check(B.lib().bang_k_pqdist_stream(C.byref(p), None), "bang_k_pqdist_stream")
+    B.sync()
+    _, _, dist = st.nbrs()
+    for i in list(range(0, Q, 37)) + [0, 1, 2, Q - 1]:
+        lut = orc.lut_build(qq[i])
+        want = orc.pqdist(lut, nb[i, :cnt[i]])
+        assert np.array_equal(dist[i, :cnt[i]].view(np.uint32), want.view(np.uint32)), i
+        assert not dist[i, cnt[i]:].any()

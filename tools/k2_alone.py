@@ -65,8 +65,30 @@ def run(N, D, m, dtype, Q=10_000, reps=20):
             "code_bytes_GBps": round(evals * m / us / 1e3, 1)}
 
 
+def big():
+    """>= 1 ms per launch on a 4 GB code table (far beyond the 256 MB Infinity Cache): what bench.py reports as roofline.k2_alone."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Ctx:
+        pass
+    ctx = Ctx()
+    ctx.dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    out = []
+    for D, m, dt in ((128, 32, "uint8"), (128, 70, "uint8"), (96, 74, "float")):
+        r = bench.k2_alone(D, m, dt, ctx, reps=10)
+        out.append(r)
+        print(json.dumps(r), flush=True)
+    return out
+
+
 if __name__ == "__main__":
     bang_amd.build()
+    if "--big" in sys.argv:
+        big()
+        sys.exit(0)
     if os.environ.get("K2_SIZE_SWEEP"):      # table size vs the 32 MB of L2 and the 256 MB Infinity Cache (m = 32: 32 B rows)
         res = [run(n, 128, 32, "uint8") for n in (1_000_000, 3_000_000, 6_000_000, 12_000_000, 40_000_000)]
     else:

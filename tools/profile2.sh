@@ -14,16 +14,18 @@ run_pass() {   # name, rocprof options...
   local name=$1; shift
   rocprofv3 "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
 }
-run_pass trace --stats
-if [ -z "${PROFILE_TRACE_ONLY:-}" ]; then
-run_pass pmc_fetch --pmc FETCH_SIZE
-run_pass pmc_write --pmc WRITE_SIZE
-run_pass pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_REQ_sum
-run_pass pmc_ea --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_32B_sum
-run_pass pmc_tcp --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum
-run_pass pmc_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
-run_pass pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_INSTS_SALU
-fi
+# PROFILE_PASSES selects the passes (default: all); e.g. PROFILE_PASSES="trace fetch write" for the 240 GB workloads
+PASSES=${PROFILE_PASSES:-trace fetch write l2 ea tcp sq1 sq2}
+for ps in $PASSES; do case $ps in
+  trace) run_pass trace --stats ;;
+  fetch) run_pass pmc_fetch --pmc FETCH_SIZE ;;
+  write) run_pass pmc_write --pmc WRITE_SIZE ;;
+  l2) run_pass pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_REQ_sum ;;
+  ea) run_pass pmc_ea --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_32B_sum ;;
+  tcp) run_pass pmc_tcp --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum ;;
+  sq1) run_pass pmc_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA ;;
+  sq2) run_pass pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_INSTS_SALU ;;
+esac; done
 python3 tools/summarize_pmc.py "$OUT" "$TTAG" > "$OUT/summary.md" 2> "$OUT/summary.err"
 cp "$OUT/summary.md" gpurun_out/profiles_out/${TAG}_summary.md
 cp "$OUT/traffic_${TTAG}.json" gpurun_out/profiles_out/ 2>/dev/null

@@ -1,0 +1,61 @@
+#!/bin/bash
+# rocprofv3 evidence for the PQ-distance stage ALONE (K2, compute_neighborDist_par, bang_search.cu:1201-1241):
+#   tools/k2_alone.py --big = bang_k_pqdist_stream over 40 M (query, neighbour) pairs per launch on a 4 GB code table, m = 32 / 70 / 74.
+# Pass 1: kernel trace + stats; pass 2: FETCH_SIZE; pass 3: L2 hit / miss / requests.  Output: gpurun_out/profiles_out/<tag>_k2_alone.md
+set -u
+TAG=${1:-r02}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof_k2
+rm -rf "$OUT"; mkdir -p "$OUT" gpurun_out/profiles_out
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/k2_alone.py --big > "$OUT/k2_trace.jsonl" 2> "$OUT/k2_trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/k2_alone.py --big > "$OUT/k2_fetch.jsonl" 2> "$OUT/k2_fetch.err"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d "$OUT/pmc_l2" -- python3 tools/k2_alone.py --big > "$OUT/k2_l2.jsonl" 2> "$OUT/k2_l2.err"
+python3 - "$OUT" > gpurun_out/profiles_out/${TAG}_k2_alone.md <<'PY'
+import csv, glob, json, os, sys
+out = sys.argv[1]
+print("# K2 alone (bang_k_pqdist_stream: pqdist_stream_kernel) under rocprofv3\n")
+print("`tools/k2_alone.py --big`: 40 M (query, neighbour) pairs per launch, random rows of a 4 GB code table, 12 launches per layout "
+      "(2 warm-up + 10 timed with HIP events).  Algorithmic bytes per evaluation = m + 8 (SURVEY 8(d)).\n")
+print("## the tool's own lines (HIP events), un-profiled pass = the kernel-trace pass\n")
+for l in open(os.path.join(out, "k2_trace.jsonl")):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print(f"* m = {d['m']}: {d['avg_launch_us']} us per launch (min {d['min_launch_us']}), {d['achieved']} GB/s algorithmic = {d['frac']:.3f} of 8 TB/s, "
+              f"{d['rows_per_s']} G rows/s, table {d['code_table_bytes']/1e9:.1f} GB")
+print()
+f = glob.glob(os.path.join(out, "trace/**/*kernel_trace.csv"), recursive=True)
+if f:
+    rows = [r for r in csv.DictReader(open(f[0])) if "pqdist_stream_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    print("## rocprofv3 --kernel-trace: launches of pqdist_stream_kernel, in order (12 per layout: m = 32, 70, 74)\n")
+    print("| layout | launches | avg us (last 10) | min us | max us | kernel |")
+    print("|---|---|---|---|---|---|")
+    for i, m in enumerate((32, 70, 74)):
+        grp = rows[i * 12:(i + 1) * 12][2:]
+        if not grp:
+            continue
+        du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp]
+        print(f"| m = {m} | {len(grp)} | {sum(du)/len(du):.1f} | {min(du):.1f} | {max(du):.1f} | {grp[0]['Kernel_Name'].split('(')[0][:60]} |")
+    print()
+for name, label in (("pmc_fetch", "FETCH_SIZE (KB; raw -- random 32-74-byte rows are 64-byte requests, the gfx950 x2 correction for wide coalesced reads does not apply)"),
+                    ("pmc_l2", "L2 / fabric counters")):
+    f = glob.glob(os.path.join(out, name + "/**/*counter_collection.csv"), recursive=True)
+    if not f:
+        continue
+    rows = [r for r in csv.DictReader(open(f[0])) if "pqdist_stream_kernel" in r["Kernel_Name"]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    print(f"## {label}, per launch (own pass)\n")
+    print("| layout | counter | avg per launch |")
+    print("|---|---|---|")
+    for i, m in enumerate((32, 70, 74)):
+        keep = set(ids[i * 12:(i + 1) * 12][2:])
+        agg = {}
+        for r in rows:
+            if int(r["Dispatch_Id"]) in keep:
+                agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for c, v in sorted(agg.items()):
+            print(f"| m = {m} | {c} | {v/max(1,len(keep)):,.0f} |")
+    print()
+PY
+cat gpurun_out/profiles_out/${TAG}_k2_alone.md | head -60
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_l2"
