@@ -44,6 +44,21 @@ class IterParams(C.Structure):
     ]
 
 
+class SearchParams(C.Structure):
+    """bang_search_params (include/bang_c.h)."""
+    _fields_ = [
+        ("Q", C.c_uint32), ("R", C.c_uint32), ("m", C.c_uint32), ("L", C.c_uint32), ("medoid", C.c_uint32), ("cap_iter", C.c_uint32),
+        ("psz", C.c_uint32), ("mp", C.c_uint32), ("pq_nhi", C.c_uint32), ("max_wgs", C.c_uint32), ("max_waves", C.c_uint32),
+        ("d_seed", C.c_void_p), ("d_codes", C.c_void_p), ("d_pivots_packed", C.c_void_p), ("d_qc", C.c_void_p),
+        ("d_graph", C.c_void_p), ("entry_len", C.c_uint64), ("vec_bytes", C.c_uint32),
+        ("d_bloom", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_cnt", C.c_void_p), ("d_qstats", C.c_void_p),
+        ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
+        ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
+        ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
+        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p),
+    ]
+
+
 class IndexDesc(C.Structure):
     _fields_ = [("medoid", C.c_uint64), ("entry_len", C.c_uint64), ("D", C.c_uint32), ("R", C.c_uint32),
                 ("N", C.c_uint32), ("m", C.c_uint32), ("graph", C.c_void_p), ("codes", C.c_void_p),
@@ -383,20 +398,24 @@ class IterState:
         _check(getattr(lib(), "bang_k_" + entry)(C.byref(p), None), "bang_k_" + entry)
         sync()
 
-    def run_persistent(self, wg_queries: int = 16):
-        """The whole search loop in ONE self-paced launch (graph resident in HBM: needs device_graph=True).  Returns the highest
-        iteration any workgroup ran."""
-        assert self.d_graph is not None
-        self.iter, self.first = 1, 1
-        p = self.params()
-        d_abort = DeviceBuffer(8)
-        cap = self.L + EXTRA_ITERS - 1
-        _check(lib().bang_k_search_persistent(C.byref(p), cap, wg_queries, None, None, C.c_void_p(d_abort.ptr), 1, None),
-               "bang_k_search_persistent")
+    def run_search(self):
+        """The whole search loop in ONE launch of the query-resident search kernel (graph resident in HBM: needs
+        device_graph=True).  Fills the candidate log; returns the per-query iteration counts."""
+        assert self.d_graph is not None and self.psz != 0
+        ix = self.ix
+        sp = SearchParams()
+        sp.Q, sp.R, sp.m, sp.L, sp.medoid, sp.cap_iter = self.Q, ix.R, ix.m, self.L, ix.medoid, self.L + EXTRA_ITERS - 1
+        sp.psz, sp.mp, sp.pq_nhi = self.psz, self.mp, self.pq_nhi
+        sp.d_seed, sp.d_codes, sp.d_pivots_packed, sp.d_qc = self.d_seed.ptr, self.d_codes.ptr, self.d_pivots_packed.ptr, self.d_qc.ptr
+        sp.d_graph, sp.entry_len = self.d_graph.ptr, ix.entry_len
+        sp.vec_bytes = ix.D * np.dtype(NP_DTYPE[ix.dtype]).itemsize
+        sp.d_bloom, sp.d_cand_ids, sp.d_cand_cnt, sp.d_qstats = self.d_bloom.ptr, self.d_cand_ids.ptr, self.d_cand_cnt.ptr, self.d_qstats.ptr
+        d_iters = DeviceBuffer(self.Q * 4)
+        d_next = DeviceBuffer(64)
+        sp.d_qiters, sp.d_next_query = d_iters.ptr, d_next.ptr
+        _check(lib().bang_k_search(C.byref(sp), None), "bang_k_search")
         sync()
-        st = d_abort.download(np.uint32, (2,))
-        assert st[0] == 0
-        return int(st[1])
+        return d_iters.download(np.uint32, (self.Q,))
 
     def stage(self, lists):
         """Upload per-query adjacency lists (what the host walker stages every iteration)."""

@@ -108,7 +108,7 @@ struct Lane {
   hipStream_t s_main = nullptr, s_fp = nullptr;
   hipEvent_t ev_front = nullptr, ev_fp = nullptr;
   unsigned long long* d_ktime = nullptr;   // [max launches][KT_WGS][2] in-kernel stamps, "timing"=1
-  size_t kt_launches = 0, kt_used = 0, kt_words = 2;
+  size_t kt_launches = 0, kt_used = 0;
   // walker team of this lane: the lane thread + (threads-1) helpers, spin-synchronised while a query runs
   std::vector<std::thread> helpers;
   std::atomic<uint32_t> epoch{0};
@@ -121,16 +121,10 @@ struct Lane {
   uint32_t* qmap_dev[2] = {nullptr, nullptr};    // what the kernels read
   bool qmap_is_device = false;
   std::vector<uint32_t> parents_tmp;             // device-graph mode: parents fetched at a poll
-  // persistent search kernel ("persistent"=1): per-workgroup pacing words (CPU-written: BAR or mapped pinned) and the
-  // kernel's gave-up flag
-  uint32_t* go_host = nullptr;
-  uint32_t* go_dev = nullptr;
-  bool go_is_device = false;
   uint32_t* d_pcnt = nullptr;
-  int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 1 = persistent walk
-  uint32_t pw_groups = 0;                        // workgroups of the running persistent kernel
-  std::atomic<uint32_t> pw_max_iter{0};
-  std::unique_ptr<std::atomic<uint32_t>[]> pw_expect;   // [workgroups] shared by the walker team (see pwalk)
+  int job_kind = 0;                              // what the walker team does on the next epoch: 0 = slice walk, 2 = search-kernel walk (swalk)
+  uint32_t pw_groups = 0;                        // pacing groups of the running search kernel
+  std::unique_ptr<std::atomic<uint32_t>[]> pw_expect;   // [pacing groups] shared by the walker team (see swalk)
   std::atomic<uint32_t> pw_remaining{0};
   mutable std::atomic<uint64_t> h2d_bytes{0};   // bumped by the walker through a const Lane&
   std::atomic<int> pw_error{0};
@@ -245,24 +239,22 @@ struct bang_engine {
   int compact = 1;                     // straggler compaction on/off
   int persistent = -1;                 // host-graph mode: 1 = ONE persistent search kernel per batch, its workgroups paced by the walker threads;
                                        // 0 = a front + back launch per iteration and lane; -1 = auto (1 where the walker can write device memory: BAR)
-  bool persist_on = false;             // resolved at bang_alloc: the host-paced persistent kernel is used for this allocation
-  bool persist_dev = false;            // resolved at bang_alloc: device-graph mode runs as ONE self-paced persistent kernel
-  int numa_opt = -1;                   // host-graph mode: pin the walker threads (and the caller for the duration of a query) to the CPUs
-                                       // of the GPU's NUMA node: 1 / 0, -1 = auto (on when the node is known and has CPUs we may use)
+  int numa_opt = -1;                   // host-graph mode: 1 = pin the walker threads (and the caller for the duration of a query) to the CPUs
+                                       // of the GPU's NUMA node, one physical core each; 0 / -1 (auto) = leave them to the scheduler
   cpu_set_t numa_cpus;                 // resolved at bang_alloc
   std::vector<int> numa_cores;         // one CPU per distinct physical core of that node (walker thread i is pinned to numa_cores[i % n])
   bool numa_on = false;
   int numa_node = -1;
-  int search_opt = -1;                 // device-graph mode: 1 = the query-resident search kernel (bang_search.hip), 0 = the round-1 loops,
+  int search_opt = -1;                 // 1 = the query-resident search kernel (bang_search.hip), 0 = a launch per iteration,
                                        // -1 = auto (1 where the pivot table leaves LDS for at least 4 waves' worklists)
   bool search_v2 = false;              // resolved at bang_alloc: graph in HBM, self-paced form
   bool search_host = false;            // resolved at bang_alloc: graph in host RAM, the host-paced form of the same kernel (BAR mode)
   uint32_t sv_G = 0, sv_W = 0, sv_C = 1;   // its grid for the running query: workgroups, waves per workgroup, query contexts per wave
   uint32_t sv_GS = 8, sv_NG = 0;           // waves per pacing group; pacing groups = workgroups x groups per workgroup x contexts
-  uint32_t* d_srows = nullptr;         // fine-grained device memory [2*256*16][64]: adjacency ids per slot, written through the BAR
-  uint32_t* d_sctl = nullptr;          // fine-grained device memory [2*256][16]: control line per pacing group {go, 16 count bytes}
-  uint32_t* h_pub_q = nullptr;         // mapped pinned [256][16]: query | row wanted << 31 per slot (vectors shipped by the walker)
-  uint32_t* h_pub_c = nullptr;         //                          candidate index per slot
+  uint32_t* d_srows = nullptr;         // fine-grained device memory [groups*16][64]: adjacency ids per slot, written through the BAR
+  uint32_t* d_sctl = nullptr;          // fine-grained device memory [groups][16]: control line per pacing group {round, 16 count bytes}
+  uint32_t* h_pub_q = nullptr;         // mapped pinned [groups][16]: query | row wanted << 31 per slot (vectors shipped by the walker)
+  uint32_t* h_pub_c = nullptr;         //                             candidate index per slot
   uint32_t* d_pub_q = nullptr;         // device aliases
   uint32_t* d_pub_c = nullptr;
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
@@ -278,7 +270,6 @@ struct bang_engine {
   bool vec_on_device = false;          // resolved at load
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
-  uint32_t pw_B = 0, pw_G = 0;         // queries per workgroup / workgroups at the allocated batch size
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
   bang_stats stats{};
@@ -538,8 +529,6 @@ void free_batch(bang_engine* e) {
     ln.pw_groups = 0;
     if (ln.d_pcnt) (void)hipFree(ln.d_pcnt);
     ln.d_pcnt = nullptr;
-    if (ln.go_host) { if (ln.go_is_device) (void)hipFree(ln.go_host); else (void)hipHostFree(ln.go_host); }
-    ln.go_host = ln.go_dev = nullptr; ln.go_is_device = false;
     for (int b = 0; b < 2; ++b) {
       if (ln.qmap_host[b]) { if (ln.qmap_is_device) (void)hipFree(ln.qmap_host[b]); else (void)hipHostFree(ln.qmap_host[b]); }
       ln.qmap_host[b] = ln.qmap_dev[b] = nullptr;
@@ -791,71 +780,6 @@ inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
   *i1 = (uint32_t)((uint64_t)ln.nq * (uint32_t)(t + 1) / (uint32_t)T);
 }
 
-// Persistent mode: walker thread t of T serves the workgroups [G*t/T, G*(t+1)/T) of the running kernel.  Whenever one of
-// them has published the parents of its iteration, the thread fetches that block's graph entries (rows + vectors), then
-// releases the workgroup into its next iteration -- every block of queries advances at its own pace.
-void pwalk(bang_engine* e, Lane& ln, int t, int T) {
-  const uint32_t G = ln.pw_groups, B = e->pw_B;
-  const uint32_t w0 = (uint32_t)((uint64_t)G * (uint32_t)t / (uint32_t)T), w1 = (uint32_t)((uint64_t)G * (uint32_t)(t + 1) / (uint32_t)T);
-  const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;
-  constexpr uint32_t CLAIM = 0x80000000u;
-  std::atomic<uint32_t>* expect = ln.pw_expect.get();      // per workgroup: the iteration whose parents are awaited; 0 = finished;
-                                                           // | CLAIM while a thread is serving it
-  uint32_t max_iter = 1;
-  volatile uint32_t* done = e->h_done;
-  volatile uint32_t* go = ln.go_host;
-  auto t_last = Clock::now();
-  uint32_t idle = 0;
-  // serve workgroup w if its parents are there and nobody else has taken it
-  auto try_serve = [&](uint32_t w) -> bool {
-    uint32_t it = expect[w].load(std::memory_order_relaxed);
-    if (it == 0 || (it & CLAIM) || done[(size_t)w * 16] != it) return false;
-    if (!expect[w].compare_exchange_strong(it, it | CLAIM, std::memory_order_acquire)) return false;
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const uint32_t i0 = w * B, i1 = std::min(ln.nq, i0 + B);
-    uint32_t active = 0, np = 0;
-    walk_slice(e, ln, i0, i1, it, it < cap_iter, &active, &np);            // ends with an sfence in BAR mode
-    if (it > max_iter) max_iter = it;
-    if (it == cap_iter || active == 0) {
-      if (it < cap_iter) { go[(size_t)w * 16] = 0xFFFFFFFFu; _mm_sfence(); }
-      expect[w].store(0, std::memory_order_release);
-      ln.pw_remaining.fetch_sub(1, std::memory_order_acq_rel);
-    } else {
-      go[(size_t)w * 16] = it + 1;
-      _mm_sfence();
-      expect[w].store(it + 1, std::memory_order_release);
-    }
-    return true;
-  };
-  while (ln.pw_remaining.load(std::memory_order_acquire) != 0) {
-    bool progress = false;
-    for (uint32_t w = w0; w < w1; ++w) progress |= try_serve(w);
-    static const bool steal = !(getenv("BANG_PW_STEAL") && atoi(getenv("BANG_PW_STEAL")) == 0);
-    if (!progress && steal) {
-      // nothing of my own is waiting: help out -- a walker thread that the OS has descheduled for a millisecond would
-      // otherwise stall its workgroups (and with them the batch) for that long
-      for (uint32_t k = 0; k + (w1 - w0) < G; ++k) {
-        const uint32_t w = (w1 + k) % G;
-        if (try_serve(w)) { progress = true; break; }
-      }
-    }
-    if (progress) { idle = 0; continue; }
-    _mm_pause();
-    if ((++idle & 0xFFFF) == 0) {
-      if (idle == 0x10000) t_last = Clock::now();
-      else if (ms_since(t_last) > BANG_HOST_WALK_TIMEOUT_MS || ln.pw_error.load(std::memory_order_relaxed)) {
-        ln.pw_error.store(1);
-        for (uint32_t w = 0; w < G; ++w) go[(size_t)w * 16] = 0xFFFFFFFFu;
-        _mm_sfence();
-        break;
-      }
-      std::this_thread::yield();
-    }
-  }
-  uint32_t cur = ln.pw_max_iter.load(std::memory_order_relaxed);
-  while (cur < max_iter && !ln.pw_max_iter.compare_exchange_weak(cur, max_iter, std::memory_order_relaxed)) {}
-}
-
 // Host-paced search kernel (bang_search.hip, HOST form): walker thread t of T serves the workgroups [G*t/T, G*(t+1)/T) first and any
 // other workgroup when none of those is waiting.  A workgroup publishes the parents of its <= 16 waves (one 64-byte line) and then
 // its round number; the thread fetches those parents' graph entries -- adjacency rows into the waves' slots of d_stage through the
@@ -1000,9 +924,7 @@ void helper_main(bang_engine* e, Lane* ln, int t, int T, uint32_t seen) {
       const uint32_t ep = ln->epoch.load(std::memory_order_acquire);
       if (ep != seen) {
         seen = ep;
-        if (ln->job_kind == 1) {
-          pwalk(e, *ln, t, T);
-        } else if (ln->job_kind == 2) {
+        if (ln->job_kind == 2) {
           swalk(e, *ln, t, T);
         } else {
           uint32_t i0, i1, a = 0, np = 0;
@@ -1109,7 +1031,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const size_t qbytes = qdim * e->tsize;
   const size_t vb = vec_bytes(e);
   const uint32_t cap_iter = (uint32_t)e->L + BANG_EXTRA_ITERS - 1;          // :950
-  if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words); ln.kt_used = 0; }   // stats not collected
+  if (ln.kt_used) { (void)hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16); ln.kt_used = 0; }   // stats not collected
   if (e->h_fin.size() >= (size_t)ln.q0 + ln.nq) memset(e->h_fin.data() + ln.q0, 0, ln.nq);
   ln.h2d_bytes.store(0); ln.iterations = 0; ln.front_launches = 0; ln.walker_ms = 0; ln.sync_ms = 0; ln.enqueue_ms = 0;
   auto t_enq = Clock::now();
@@ -1149,7 +1071,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                               e->D, e->m, dim_adjust, ln.s_main));
 
   uint32_t iter = 1;                                                         // :596
-  const bool persist = e->persist_on;
   // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
   uint32_t fp_lo = 0, fp_hi = 0;
   bool fp_pending = false, fp_any = false;
@@ -1269,48 +1190,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       LANE_HIP(hipMemcpyAsync(e->d_fp + (size_t)ln.q0 * e->cand_stride * vb, e->h_fp + (size_t)ln.q0 * e->cand_stride * vb,
                               (size_t)ln.nq * e->cand_stride * vb, hipMemcpyHostToDevice, ln.s_main));
     iter = cap_iter;                                                         // refined from the per-query counts below
-  } else if (e->persist_dev) {
-    // graph resident in HBM: the whole search is ONE self-paced launch, no host involvement until the re-rank
-    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
-    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq; p.max_wgs = 0; p.d_active = nullptr;
-    unsigned long long* kt_base = (e->timing && ln.d_ktime && ln.kt_launches >= (size_t)cap_iter + 1) ? ln.d_ktime : nullptr;
-    ENQ_BEGIN();
-    BANG_TRY(bang_k_search_persistent(&p, cap_iter, e->pw_B, nullptr, kt_base, ln.d_pcnt, 1u, ln.s_main));
-    ENQ_END();
-    ++ln.front_launches;
-    iter = cap_iter;                                                         // refined from the kernel's own count below
-    if (kt_base) ln.kt_used = (size_t)cap_iter + 1;
-  } else if (persist) {
-    // ONE launch per batch: every workgroup owns a block of pw_B queries and runs front(t) -> parents + flag -> back(t) for
-    // t = 1..cap on its own clock; before front(t) it waits until a walker thread has stored t into its `go` word (after that
-    // block's rows of iteration t-1 are in device memory).  No lanes, no per-iteration launches, no batch-wide step.
-    const uint32_t B = e->pw_B, G = (ln.nq + B - 1) / B;
-    ln.pw_groups = G;
-    ln.pw_max_iter.store(1);
-    ln.pw_error.store(0);
-    for (uint32_t w = 0; w < G; ++w) ln.pw_expect[w].store(1u, std::memory_order_relaxed);
-    ln.pw_remaining.store(G, std::memory_order_release);
-    for (uint32_t w = 0; w < G; ++w) { e->h_done[(size_t)w * 16] = 0; ln.go_host[(size_t)w * 16] = 1; }
-    _mm_sfence();
-    LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
-    p.first = 1; p.iter = 1; p.done_value = 1; p.d_qmap = nullptr; p.Q = ln.nq; p.max_wgs = 0;
-    unsigned long long* kt_base = (e->timing && ln.d_ktime && ln.kt_launches >= (size_t)cap_iter + 1) ? ln.d_ktime : nullptr;
-    BANG_TRY(bang_k_search_persistent(&p, cap_iter, B, ln.go_dev, kt_base, ln.d_pcnt, (e->stage_mode_eff == 2) ? 1u : 0u, ln.s_main));
-    ++ln.front_launches;
-    const auto t0 = Clock::now();
-    const int T = 1 + (int)ln.helpers.size();
-    ln.job_kind = 1;
-    if (T > 1) {
-      ln.pending.store((uint32_t)(T - 1), std::memory_order_relaxed);
-      ln.epoch.fetch_add(1, std::memory_order_release);
-    }
-    pwalk(e, ln, 0, T);
-    if (T > 1) while (ln.pending.load(std::memory_order_acquire) != 0) _mm_pause();
-    ln.walker_ms += ms_since(t0);
-    iter = ln.pw_max_iter.load();
-    if (ln.pw_error.load()) { bang_set_error("timeout waiting for the persistent search kernel"); (void)hipStreamSynchronize(ln.s_main); return BANG_ERR_HIP; }
-    if (!e->fp_direct && !e->vec_on_device) { fp_lo = 1; fp_hi = iter; fp_pending = true; }   // staged vectors: one copy of all rows
-    if (kt_base) ln.kt_used = (size_t)iter + 1;
   } else {
   p.first = 1; p.iter = iter; p.done_value = iter;
   if (dev_graph) p.d_active = e->d_active + iter;
@@ -1415,20 +1294,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                           (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
   LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
                             (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
-  if (persist || e->persist_dev) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt, 8, hipMemcpyDeviceToHost, ln.s_main));
   if (e->search_host) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
   if (e->search_v2 || e->search_host) LANE_HIP(hipMemcpyAsync(e->h_qiters.data() + ln.q0, e->d_qiters + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main));
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
-  if (pw_stats[0]) { bang_set_error("persistent search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
-  if ((persist || e->persist_dev) && getenv("BANG_PHASE_PROBE")) {   // diagnostic build (-DBANG_PHASE_PROBE) only: d_pcnt[4..11]
-    uint32_t pr[8] = {0};
-    (void)hipMemcpy(pr, ln.d_pcnt + 4, sizeof(pr), hipMemcpyDeviceToHost);
-    if (pr[7]) fprintf(stderr, "[bang] phase probe, wave 0 of workgroup 0, %u query-iterations: A %.2f us, filter %.2f, distances %.2f, parent %.2f, ORs %.2f\n",
-                       pr[7], pr[0] * 0.01 / pr[7], pr[1] * 0.01 / pr[7], pr[2] * 0.01 / pr[7], pr[3] * 0.01 / pr[7], pr[4] * 0.01 / pr[7]);
-  }
-  if (e->persist_dev && pw_stats[1]) ln.iterations = pw_stats[1];
+  if (pw_stats[0]) { bang_set_error("search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
   if (e->search_v2 || e->search_host) {
     uint32_t mx = 0;
     for (uint32_t i = 0; i < ln.nq; ++i) mx = std::max(mx, e->h_qiters[ln.q0 + i]);
@@ -1669,15 +1540,8 @@ static int alloc_buffers(bang_engine* e, int Q) {
   // LDS for the pivot table plus the merge scratch of all waves (otherwise: the launch-per-iteration loop)
   // (mapped-host rows need cache-bypassing loads, which are issued per lane: measured 2x slower than the per-iteration loop,
   // so "auto" takes the persistent kernel only in BAR mode)
-  const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);
+  const bool persist_want = e->persistent < 0 ? (e->stage_mode_eff == 2) : (e->persistent != 0);   // host graph: one launch per batch?
   e->pq_nhi = 0;
-  bool persist_fits = bang_persistent_supported(e->psz, e->mp, 0, (uint32_t)e->L) != 0;
-  if (!persist_fits && e->pq_nhi_avail && bang_persistent_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L)) {
-    persist_fits = true;                                  // only the exact-size pivot table leaves room for the merge scratch
-    e->pq_nhi = e->pq_nhi_avail;
-  }
-  e->persist_on = persist_want && !dev_graph && e->use_flag && e->stage_mode_eff != 0 && persist_fits;
-  e->persist_dev = dev_graph && e->persistent != 0 && persist_fits;
   // graph in HBM: the query-resident search kernel, with whichever pivot table (padded / exact-size) leaves LDS for more waves
   e->search_v2 = false;
   if (dev_graph && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
@@ -1685,7 +1549,6 @@ static int alloc_buffers(bang_engine* e, int Q) {
     const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
     if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
       e->search_v2 = true;
-      e->persist_dev = false;
       e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
     }
   }
@@ -1696,20 +1559,10 @@ static int alloc_buffers(bang_engine* e, int Q) {
     const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
     if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
       e->search_host = true;
-      e->persist_on = false;
       e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
     }
   }
   e->fp_direct = false;
-  if (e->persist_on || e->persist_dev) {
-    const uint32_t cus = (uint32_t)std::max(1, std::min(bang_num_cus(), (int)KT_WGS));
-    e->pw_B = std::max<uint32_t>(16u, ((uint32_t)Q + cus - 1) / cus);
-    if (const char* v = getenv("BANG_PW_B")) {               // experiment knob: queries per workgroup (>= the default, so that all fit)
-      const uint32_t b = (uint32_t)atoi(v);
-      if (b > e->pw_B) e->pw_B = b;
-    }
-    e->pw_G = ((uint32_t)Q + e->pw_B - 1) / e->pw_B;
-  }
   HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));
   else BANG_TRY(dmalloc(&e->d_lut, nq * e->m * 256));                       // :380
@@ -1735,7 +1588,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
     BANG_TRY(dmalloc(&e->d_cand_row, nq * rows));
     if (e->vec_on_device) {
       e->d_fp = nullptr;                                                     // the re-rank reads d_vecs
-    } else if ((e->persist_on || e->search_host) && e->stage_mode_eff == 2 &&
+    } else if (e->search_host && e->stage_mode_eff == 2 &&
         hipExtMallocWithFlags((void**)&e->d_fp, rows * nq * vb, hipDeviceMallocFinegrained) == hipSuccess) {
       e->fp_direct = true;                                                   // walker threads write the vector log through the BAR
     } else {
@@ -1770,12 +1623,12 @@ static int alloc_buffers(bang_engine* e, int Q) {
   int nl = e->lanes_opt;
   if (nl <= 0) nl = dev_graph ? 1 : std::max(1, std::min(4, Q / 512));   // measured best on a 16-CPU-quota MI355X box
   nl = std::min(nl, Q);
-  if (e->persist_on || e->persist_dev || e->search_v2 || e->search_host) nl = 1;   // the persistent kernel's workgroups are the unit of overlap, not lanes
-  if ((e->persist_on || e->search_host) && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
+  if (e->search_v2 || e->search_host) nl = 1;            // the search kernel's waves are the unit of overlap, not lanes
+  if (e->search_host && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
   else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
   if (!dev_graph) {
-    const size_t n_flags = std::max<size_t>((size_t)nl, e->persist_on ? e->pw_G : e->search_host ? 8 * KT_WGS : 0);
+    const size_t n_flags = std::max<size_t>((size_t)nl, e->search_host ? 8 * KT_WGS : 0);
     HIP_TRY(hipHostMalloc((void**)&e->h_done, n_flags * 16 * 4, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&e->h_done_dev, e->h_done, 0));
     memset(e->h_done, 0, n_flags * 16 * 4);
@@ -1811,32 +1664,15 @@ static int alloc_buffers(bang_engine* e, int Q) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.qmap_dev[b], ln.qmap_host[b], 0));
       }
     }
-    if (e->persist_dev || e->search_v2 || e->search_host) {
+    if (e->search_v2 || e->search_host) {
       BANG_TRY(dmalloc(&ln.d_pcnt, 16));
       HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
     }
-    if (e->persist_on || e->search_host) {
-      const uint32_t n_go = e->search_host ? (uint32_t)(8 * KT_WGS) : e->pw_G;
-      ln.pw_expect.reset(new std::atomic<uint32_t>[std::max<uint32_t>(1u, n_go)]);
-      const size_t go_bytes = (size_t)n_go * 64;
-      if (!ln.d_pcnt) BANG_TRY(dmalloc(&ln.d_pcnt, 16));
-      HIP_TRY(hipMemset(ln.d_pcnt, 0, 64));
-      if (e->stage_mode_eff == 2 && hipExtMallocWithFlags((void**)&ln.go_host, go_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
-        HIP_TRY(hipMemset(ln.go_host, 0, go_bytes));
-        ln.go_dev = ln.go_host;
-        ln.go_is_device = true;
-      } else {
-        (void)hipGetLastError();
-        HIP_TRY(hipHostMalloc((void**)&ln.go_host, go_bytes, hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&ln.go_dev, ln.go_host, 0));
-        memset(ln.go_host, 0, go_bytes);
-      }
-    }
+    if (e->search_host) ln.pw_expect.reset(new std::atomic<uint32_t>[8 * KT_WGS]);
     if (e->timing) {
       ln.kt_launches = rows + 4;
-      ln.kt_words = (e->persist_on || e->persist_dev) ? 4 : 2;                   // stamps per workgroup and launch/iteration
-      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
-      HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 8 * ln.kt_words));
+      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));     // {start, end} stamp per workgroup and launch
+      HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 16));
     }
   }
   e->numa_on = false;
@@ -1855,8 +1691,8 @@ static int alloc_buffers(bang_engine* e, int Q) {
     else if (!dev_graph) fprintf(stderr, "[bang] walker threads not pinned\n");
   }
   if (getenv("BANG_DEBUG"))
-    fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d persist=%d B=%u G=%u fp_direct=%d vec_on_device=%d\n", Q, nl,
-            e->threads_eff, e->stage_mode_eff, (int)e->persist_on, e->pw_B, e->pw_G, (int)e->fp_direct, (int)e->vec_on_device);
+    fprintf(stderr, "[bang] alloc Q=%d lanes=%d threads=%d stage_mode=%d search_kernel=%d/%d fp_direct=%d vec_on_device=%d\n", Q, nl,
+            e->threads_eff, e->stage_mode_eff, (int)e->search_v2, (int)e->search_host, (int)e->fp_direct, (int)e->vec_on_device);
   start_threads(e);
   return BANG_OK;
 }
@@ -1957,56 +1793,24 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
     s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
     s.h2d_bytes += ln.h2d_bytes.load();
   }
-  s.persistent = (e->persist_on || e->persist_dev || e->search_v2 || e->search_host) ? 1 : 0;
+  s.persistent = (e->search_v2 || e->search_host) ? 1 : 0;
   s.vectors_on_device = e->vec_on_device ? 1 : 0;
   s.graph_mode = (uint64_t)e->graph_mode;
   s.lanes = (uint64_t)nl;
   s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
-  s.wg_queries = (e->persist_on || e->persist_dev) ? e->pw_B : e->search_host ? e->sv_W * e->sv_C : 0;
+  s.wg_queries = e->search_host ? e->sv_W * e->sv_C : 0;
   s.pacing_groups = e->search_host ? e->sv_NG : 0;
-  s.workgroups = (e->persist_on || e->persist_dev) ? ((uint32_t)Q + e->pw_B - 1) / std::max<uint32_t>(1u, e->pw_B)
-               : e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
+  s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
   s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
   return rc;
 }
 
 // reduce the in-kernel stamps of a lane: per launch max(end) - min(start) over the workgroups that ran
-static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals, bool persist) {
+static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals) {
   if (!ln.d_ktime || ln.kt_used == 0) return BANG_OK;
-  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * ln.kt_words);
+  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * 2);
   HIP_TRY(hipMemcpy(kt.data(), ln.d_ktime, kt.size() * 8, hipMemcpyDeviceToHost));
   ln.front_ms = 0;
-  if (persist) {
-    // persistent kernel: slot [iteration][workgroup]; workgroups are not in step, so the figure is the mean over the
-    // workgroups of the time each spent in its front phases (waiting for the walker and sort/merge excluded)
-    unsigned long long sum = 0;
-    size_t wgs = 0;
-    for (size_t w = 0; w < KT_WGS; ++w) {
-      unsigned long long busy = 0;
-      for (size_t l = 0; l < ln.kt_used; ++l) {
-        const unsigned long long a = kt[(l * KT_WGS + w) * 4], b = kt[(l * KT_WGS + w) * 4 + 1];
-        if (a != 0 && b > a) busy += b - a;
-      }
-      if (busy) { sum += busy; ++wgs; }
-    }
-    if (wgs) {
-      ln.front_ms = (double)(sum / wgs) * 1e-5;
-      unsigned long long lo = ~0ull, hi = 0;               // the launch: first go-seen stamp .. last stamp of any workgroup
-      for (unsigned long long v : kt) if (v) { lo = std::min(lo, v); hi = std::max(hi, v); }
-      if (hi > lo) intervals.emplace_back(lo, hi);
-    }
-    if (const char* path = getenv("BANG_PW_TRACE")) {          // raw stamps for offline analysis (tools/dev/pw_trace.py)
-      if (FILE* f = fopen(path, "wb")) {
-        const uint64_t hdr[2] = {(uint64_t)ln.kt_used, (uint64_t)KT_WGS};
-        fwrite(hdr, 8, 2, f);
-        fwrite(kt.data(), 8, kt.size(), f);
-        fclose(f);
-      }
-    }
-    HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 8 * ln.kt_words));
-    ln.kt_used = 0;
-    return BANG_OK;
-  }
   for (size_t l = 0; l < ln.kt_used; ++l) {
     unsigned long long lo = ~0ull, hi = 0;
     for (size_t w = 0; w < KT_WGS; ++w) {
@@ -2035,7 +1839,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
   bang_stats& s = e->stats;
   if (e->allocated && e->timing && s.front_ms == 0) {
     std::vector<std::pair<unsigned long long, unsigned long long>> iv;
-    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv, e->persist_on || e->persist_dev)); s.front_ms += lp->front_ms; }
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv)); s.front_ms += lp->front_ms; }
     std::sort(iv.begin(), iv.end());                   // the stamps of all lanes share one 100 MHz clock: merge the intervals
     unsigned long long cur_lo = 0, cur_hi = 0, busy = 0;
     for (auto& p : iv) {

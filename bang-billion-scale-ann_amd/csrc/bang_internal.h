@@ -36,8 +36,6 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
 #define BANG_KERNEL_GO_TIMEOUT_TICKS 3000000000ull   /* 30 s of the 100 MHz s_memrealtime clock */
 
 int bang_num_cus(void);
-// 1 if the persistent search kernel can run this PQ layout at worklist length L with all its waves (LDS budget)
-int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
 // 1 if the fused kernel has an instance for the exact-size ("ragged") pivot table of this layout
 int bang_ragged_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t m);
 

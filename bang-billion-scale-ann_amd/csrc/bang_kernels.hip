@@ -59,21 +59,10 @@ struct __attribute__((aligned(16))) BackLds {
   float wd[BANG_MAX_L];           // worklist distances (binary-searched); its flags and the first 256 ids stay in registers
   uint32_t wi_hi[BANG_MAX_L - BACK_WI_REGS * WAVE];   // ids of entries 256.. (L > 256 only)
 };
-// per-wave LDS view used by back_one_query (static BackLds in back_kernel, carved from dynamic LDS in the persistent kernel)
+// per-wave LDS view used by back_one_query (the static BackLds of back_kernel)
 struct BackView {
   float* sd; uint32_t* si; float* td; uint32_t* ti; float* wd; uint32_t* wi_hi;
 };
-// LDS words a wave needs for a BackView at worklist length L (16-byte multiple)
-__host__ __device__ inline uint32_t back_view_words(uint32_t L) {
-  return (4u * BANG_NBR_STRIDE + L + (L > BACK_WI_REGS * WAVE ? L - BACK_WI_REGS * WAVE : 0u) + 3u) & ~3u;
-}
-__device__ __forceinline__ BackView back_view_at(uint32_t* base, uint32_t L) {
-  BackView v;
-  v.sd = (float*)base; v.si = base + BANG_NBR_STRIDE; v.td = (float*)(base + 2 * BANG_NBR_STRIDE); v.ti = base + 3 * BANG_NBR_STRIDE;
-  v.wd = (float*)(base + 4 * BANG_NBR_STRIDE);
-  v.wi_hi = base + 4 * BANG_NBR_STRIDE + L;
-  return v;
-}
 
 // Everything back_one_query reads from global memory: depends on the query only, so a wave can have the NEXT query's loads
 // in flight while it sorts and merges the current one.
@@ -224,46 +213,6 @@ __device__ __forceinline__ void back_one_query(const bang_iter_params& p, uint32
   wave_sync();
 }
 
-// Sort + merge of all unfinished queries a wave owns in a persistent launch.  For L <= 128 (WLR <= 2: a BackIn is a dozen
-// registers; L <= 256 in the 256-VGPR builds) the NEXT query's loads are in flight while the current one is sorted and merged -- two register sets, ping-pong,
-// no copies; the memory round trip (about half of a query's 4.5 us) is paid once per wave instead of once per query.
-template <int WLR, bool BIGREGS>      // BIGREGS: the 256-VGPR builds can afford two register sets up to L = 256
-__device__ __forceinline__ void back_block(const bang_iter_params& p, uint32_t q_begin, uint32_t q_end, uint32_t q_step,
-                                           uint32_t fin_mask, uint32_t iter, const BackView& bv, int lane) {
-  uint32_t slot = q_begin, ord = 0;
-#define BACK_SKIP_FINISHED() while (slot < q_end && ord < 32u && ((fin_mask >> ord) & 1u)) { slot += q_step; ++ord; }
-  BACK_SKIP_FINISHED();
-  if constexpr (WLR <= 2 || (BIGREGS && WLR <= 4)) {
-    BackIn<WLR> A, B;
-    if (slot < q_end) back_load<WLR>(p, slot, lane, A);
-    while (slot < q_end) {
-      const uint32_t s0 = slot;
-      slot += q_step; ++ord;
-      BACK_SKIP_FINISHED();
-      const bool m1 = slot < q_end;
-      if (m1) back_load<WLR>(p, slot, lane, B);
-      back_one_query<WLR>(p, s0, iter, bv, lane, A);
-      if (!m1) break;
-      const uint32_t s1 = slot;
-      slot += q_step; ++ord;
-      BACK_SKIP_FINISHED();
-      const bool m2 = slot < q_end;
-      if (m2) back_load<WLR>(p, slot, lane, A);
-      back_one_query<WLR>(p, s1, iter, bv, lane, B);
-      if (!m2) break;
-    }
-  } else {
-    while (slot < q_end) {
-      BackIn<WLR> in;
-      back_load<WLR>(p, slot, lane, in);
-      back_one_query<WLR>(p, slot, iter, bv, lane, in);
-      slot += q_step; ++ord;
-      BACK_SKIP_FINISHED();
-    }
-  }
-#undef BACK_SKIP_FINISHED
-}
-
 __global__ __launch_bounds__(BACK_WAVES* WAVE) void back_kernel(const bang_iter_params p) {
   __shared__ BackLds lds_all[BACK_WAVES];
   const int lane = lane_id();
@@ -287,51 +236,23 @@ struct FrontArgs {
   uint32_t stages;      // bit0 filter, bit1 distance, bit2 parent
   uint32_t debug;       // timing-only ablations (BANG_FRONT_DEBUG): 1 no filter updates, 2 no distance math, 4 no pivot staging
   uint32_t lds_piv_floats;
-  // persistent mode: one launch runs iterations p.iter .. iter_end.  Every workgroup owns a contiguous block of wg_queries
-  // queries and is paced on its own by the host walker (no grid-wide step): before front(t) it waits until go[16*wg] >= t.
-  const uint32_t* go;          // [gridDim.x * 16] words written by the host (64 B apart); 0xFFFFFFFF = stop
-  uint32_t iter_end;           // last iteration (the cap)
-  uint32_t scratch_words;      // LDS words per wave (front compaction scratch and back view share them)
-  uint32_t wg_queries;         // queries per workgroup
-  unsigned long long* ktime_base;   // [iter][KT_WGS][4] stamps {go seen, front end, flag published, sort/merge end} or NULL
-  uint32_t* abort_flag;        // set to 1 if a workgroup gave up waiting for `go`
-  uint32_t persist;            // host side: pick the persistent instance
-  uint32_t rows_uncached;      // 1: d_stage is LOCAL device memory written by the CPU through the BAR -> plain coalesced loads (see the row loads)
 };
-#define KT_WGS_DEV 256u
-#define BANG_GO_STOP 0xFFFFFFFFu
 
 // per-wave LDS scratch (uint32 words): compacted ids [0..71]
 #define FRONT_SCRATCH_WORDS 72
-// -DBANG_PHASE_PROBE: diagnostic build -- wave 0 of workgroup 0 drains its memory queue at every phase boundary of the front
-// loop and accumulates the phase durations (100 MHz ticks) into d_abort[4 + k]; serialises that wave, never used in production.
-#ifdef BANG_PHASE_PROBE
-#define PHASE_PROBE(k)                                                                                  \
-  do {                                                                                                  \
-    if (PERSIST && blockIdx.x == 0 && wave == 0) {                                                      \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
-      const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();                                \
-      probe_acc[k] += (uint32_t)(t_now - probe_t);                                                      \
-      probe_t = t_now;                                                                                  \
-    }                                                                                                   \
-  } while (0)
-#else
-#define PHASE_PROBE(k) do {} while (0)
-#endif
-
 // ALL = true: the production instantiation (filter + distance + parent, no stage branches).  ALL = false:
 // stage mask taken from a.stages (kernel-level parity tests).
 // NQW = queries a wave works on AT THE SAME TIME.  The kernel is bound by dependent memory latency (row ->
 // filter words -> code rows, ~2 us each) with at most 16 waves per CU (the pivot table owns the LDS), so every
 // phase is executed for NQW independent queries back to back: their loads are in flight together and the wave
 // pays each round trip once per NQW queries.
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST, int NHI>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, int NHI>
 __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_iter_params& p = a.p;
   float* piv_lds = lds;
   uint32_t* scratch_all = (uint32_t*)(lds + a.lds_piv_floats);
-  if (!PERSIST && p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const bool do_filter = ALL || (a.stages & 1u);
   const bool do_dist = ALL || (a.stages & 2u);
   const bool do_parent = ALL || (a.stages & 4u);
@@ -361,96 +282,30 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   const int lane = lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
-  uint32_t* scratch = scratch_all + wave * (PERSIST ? a.scratch_words : FRONT_SCRATCH_WORDS * NQW);
+  uint32_t* scratch = scratch_all + wave * (FRONT_SCRATCH_WORDS * NQW);
   const uint32_t medoid = p.medoid;
   const uint32_t L = p.L;
   const uint32_t lane_l = (uint32_t)lane < L ? (uint32_t)lane : L - 1;
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
-  // slots of this wave: q_begin, q_begin + q_step, ... < q_end (persistent: inside the workgroup's own block of queries)
-  const bool own_blk = PERSIST;
-  const uint32_t wg_q0 = PERSIST ? blockIdx.x * a.wg_queries : 0u;
-  const uint32_t wg_q1 = PERSIST ? (wg_q0 + a.wg_queries < p.Q ? wg_q0 + a.wg_queries : p.Q) : p.Q;
-  const uint32_t q_end = own_blk ? wg_q1 : p.Q;
-  const uint32_t q_begin = own_blk ? wg_q0 + wave : gw;
-  const uint32_t q_step = own_blk ? nwaves : total_waves;
+  // slots of this wave: gw, gw + total_waves, ... < Q
+  const uint32_t q_end = p.Q, q_begin = gw, q_step = total_waves;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
+  const uint32_t cur_iter = p.iter;
+  const uint32_t first = p.first ? 1u : 0u;
   uint32_t n_active = 0;
-  // PERSIST: queries of this wave that have finished (no parent, no unmerged survivors -- they never change state again), bit =
-  // ordinal of the query within the wave.  Finished queries are skipped altogether: in the last third of a search most
-  // query-iterations are such.  (Waves that own more than 32 queries only track the first 32.)
-  uint32_t fin_mask = 0;
-#ifdef BANG_PHASE_PROBE
-  uint32_t probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long probe_t = 0;
-#endif
-
-  // PERSIST: one launch runs iterations p.iter .. a.iter_end for the queries its waves own (static ownership: a query is
-  // always handled by the same wave, so no grid-wide barrier is needed); the host paces it through `go`.
-  for (uint32_t cur_iter = p.iter; cur_iter <= (PERSIST ? a.iter_end : p.iter); ++cur_iter) {
-  const uint32_t first = PERSIST ? (cur_iter == 1 ? 1u : 0u) : (p.first ? 1u : 0u);
-  if (PERSIST) {
-    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;    // LDS words behind the per-wave scratch: [0] go, [1..2] any-active
-    if (a.go == nullptr) {
-      // self-paced (graph resident in HBM): nothing to wait for; the parents this workgroup stored write-through in its last
-      // iteration must not be read from a stale L1 line
-      if (threadIdx.x == 0) {
-        s_go[1 + (cur_iter & 1u)] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_go = cur_iter;
-      }
-    }
-    // host-paced: wait until the host walker has staged this workgroup's adjacency rows of this iteration
-    const uint32_t* go = a.go + (size_t)blockIdx.x * 16;
-    if (a.go != nullptr && threadIdx.x == 0) {
-      uint32_t v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (v < cur_iter) {                         // BANG_GO_STOP is the largest value: it also ends the wait
-        __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > BANG_KERNEL_GO_TIMEOUT_TICKS) {   // the host is gone (it gives up first, see bang_internal.h)
-          v = BANG_GO_STOP;
-          if (a.abort_flag) *a.abort_flag = 1u;
-          break;
-        }
-      }
-      *s_go = v;
-      // everything other agents (the CPU through the BAR) or this kernel's own atomics wrote since the last iteration
-      // must not be served from this CU's L1
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-#ifdef BANG_PHASE_PROBE
-    if (*s_go == BANG_GO_STOP && a.abort_flag && blockIdx.x == 0 && threadIdx.x == 0)
-      for (int k = 0; k < 8; ++k) a.abort_flag[4 + k] = probe_acc[k];
-#endif
-    if (*s_go == BANG_GO_STOP) break;
-    if (a.ktime_base && threadIdx.x == 0)
-      a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4] = __builtin_amdgcn_s_memrealtime();
-  }
 
   for (uint32_t g0 = q_begin; g0 < q_end; g0 += q_step * NQW) {
     uint32_t q[NQW];
     bool valid[NQW];
-    const uint32_t ord0 = PERSIST ? (g0 - q_begin) / q_step : 0u;      // ordinal of the group's first query within this wave
-    if (PERSIST && ord0 + NQW <= 32u) {
-      const uint32_t grp = ((NQW == 32 ? 0u : (1u << NQW)) - 1u) << ord0;
-      if ((fin_mask & grp) == grp) continue;                            // every query of the group has finished
-    }
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
       const uint32_t slot = g0 + (uint32_t)u * q_step;
       valid[u] = slot < q_end;
-      if (PERSIST && !valid[u] && ord0 + (uint32_t)u < 32u) fin_mask |= 1u << (ord0 + (uint32_t)u);   // nothing there: "finished"
       const uint32_t s_ok = valid[u] ? slot : g0;   // invalid slots shadow slot 0: loads stay legal, every store is guarded
       q[u] = p.d_qmap ? uni(p.d_qmap[s_ok]) : s_ok;  // straggler compaction: slot -> query
     }
 
-#ifdef BANG_PHASE_PROBE
-    if (PERSIST && blockIdx.x == 0 && wave == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); probe_t = __builtin_amdgcn_s_memrealtime(); probe_acc[7] += 1; }
-#endif
     // ---- round trip A: every load that does not depend on another load of the query, issued
     // unconditionally (the launcher guarantees all pointers are valid).  The worklist head needed by K4 is
     // prefetched speculatively: the arrays always hold L valid words.
@@ -479,19 +334,9 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
-      if (PERSIST && !a.rows_uncached) {
-        // Rows in mapped HOST memory, re-read without a kernel boundary in between: L2 copies of remote lines are not probed,
-        // so every load bypasses the caches.  (Such loads are issued per lane, not coalesced: measured 2x the whole front
-        // phase.)  Rows in LOCAL device memory take the plain path below: this CU's L1 was invalidated after `go` was seen,
-        // and L2 copies of local memory are invalidated by the fabric's probes when the CPU's PCIe writes land.
-        cnt_in[u] = __hip_atomic_load(&row[u][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        x0[u] = __hip_atomic_load(&row[u][1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        x1[u] = __hip_atomic_load(&row[u][65u * first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {
       cnt_in[u] = row[u][0];
       x0[u] = row[u][1 + lane];                          // in bounds for every row kind (R <= 64)
       x1[u] = row[u][65u * first];                       // 65th id exists only in the seed list
-      }
       cc[u] = p.d_cand_cnt[q[u]];
       w_n[u] = p.d_wl_cnt[q[u]];
       pw_vis[u] = p.d_wl_vis[(size_t)q[u] * L + lane_l];
@@ -501,7 +346,6 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       if (p.d_qstats && lane == 0) qs[u] = *(const uint2*)(p.d_qstats + (size_t)q[u] * 2);
     }
 
-    PHASE_PROBE(0);   // A: row, worklist head, counters
     uint32_t n[NQW], sid0[NQW], sid1[NQW];   // survivors; lane's survivor id; survivor 64 (lane 0 only)
     uint32_t h0a[NQW], h0b[NQW], h1a[NQW], h1b[NQW];   // filter slots of the lane's id / of element 64
     bool set0[NQW], set1[NQW];                        // slots to set once the query's loads have been issued
@@ -589,7 +433,6 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
     }
 
-    PHASE_PROBE(1);   // B + B': filter probes, compaction, survivor stores issued
     // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
     float d0[NQW], d1[NQW];
 #pragma unroll
@@ -643,7 +486,6 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
       }
     }
 
-    PHASE_PROBE(2);   // C: code rows + LDS reduce + distance stores
     // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ------
     if (do_parent) {
 #pragma unroll
@@ -725,11 +567,9 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
           }
         }
         if (found || nn > 0) ++n_active;
-        else if (PERSIST && ord0 + (uint32_t)u < 32u && !(a.debug & 32u)) fin_mask |= 1u << (ord0 + (uint32_t)u);   // debug bit 32: no skipping
       }
     }
 
-    PHASE_PROBE(3);   // K4: parent selection + its stores
     // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
     // Issued LAST: vmcnt retires in order, so anything issued after an atomic waits for it (2-3 us under load);
     // here the ORs are fire-and-forget and overlap the next queries' first round trip.  A query's filter is touched by
@@ -742,18 +582,14 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
         if (set1[u]) { bloom_set(&bloom[h1a[u] >> 5], 1u << (h1a[u] & 31)); bloom_set(&bloom[h1b[u] >> 5], 1u << (h1b[u] & 31)); }
       }
     }
-    PHASE_PROBE(4);   // the filter's ORs, drained
   }
 
   // same-address atomics from thousands of waves serialise (~90 per microsecond): a plain flag store instead
   if (lane == 0 && p.d_active && n_active) *p.d_active = 1u;
 
-  if (p.d_ktime || (PERSIST && a.ktime_base)) {
+  if (p.d_ktime) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-      if (PERSIST) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-      else p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    }
+    if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
 
   // Completion signal for the host walker, without any L2-wide fence (a release fence writes back every dirty
@@ -762,27 +598,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
   // device counter; the LAST workgroup re-reads the parents with `sc1` loads, copies them to mapped pinned host
   // memory with system-scope stores (coalesced: one 4-byte PCIe write per query from every wave was measured at
   // +75 us per launch), drains, and publishes the iteration number.  The walker thread spins on that word.
-  if (PERSIST && a.go == nullptr) {
-    uint32_t* s_go = scratch_all + (size_t)nwaves * a.scratch_words;
-    if (lane == 0 && n_active) s_go[1 + (cur_iter & 1u)] = 1u;
-    __syncthreads();
-  } else if (PERSIST) {
-    // every workgroup reports on its own: its waves drain their write-through parent stores, the block's parents go to
-    // mapped pinned host memory in one coalesced store, and the iteration number is published behind them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (uint32_t i = wg_q0 + threadIdx.x; i < wg_q1; i += blockDim.x) {
-      const uint32_t v = __hip_atomic_load(&p.d_parents[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&p.h_parents[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flag must not overtake the stores (MI355X guide)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // relaxed: everything the host reads was stored write-through and drained above; a release here would write back the whole L2 of this XCD once per workgroup and iteration
-      __hip_atomic_store(p.h_done_flag + (size_t)blockIdx.x * 16, cur_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (a.ktime_base) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-    }
-  } else if (p.h_done_flag) {
+  if (p.h_done_flag) {
     volatile uint32_t* s_last = scratch_all;        // dynamic LDS: no static allocation next to the 160 KB request
     uint32_t* counter = p.d_done_count;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -808,35 +624,6 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
     __syncthreads();                                 // s_last lives in wave 0's scratch: nobody may reuse it before all have read it
   }
 
-  if (PERSIST) {
-    // K3a + K3b for the queries of this wave, while the host walks (the standalone back kernel in the launch-per-iteration mode)
-    const BackView bv = back_view_at(scratch, L);
-    // self-paced: a block none of whose queries has a parent or unmerged survivors is finished (every wave reads the word
-    // of THIS iteration; the other one is reset at the start of the next iteration, behind a workgroup barrier)
-    const bool block_done = (a.go == nullptr) && (scratch_all[(size_t)nwaves * a.scratch_words + 1 + (cur_iter & 1u)] == 0u);
-    if (cur_iter < a.iter_end || a.go != nullptr)
-    {
-      const uint32_t wlr = (L + WAVE - 1) / WAVE;                        // uniform: pick the compiled BackIn size
-      constexpr bool BIG = (MAXT <= 512);
-      if (wlr <= 2) back_block<2, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
-      else if (wlr <= 4) back_block<4, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
-      else back_block<BACK_WL_REGS, BIG>(p, q_begin, q_end, q_step, fin_mask, cur_iter, bv, lane);
-    }
-    n_active = 0;
-    if (a.ktime_base) {
-      __syncthreads();
-      if (threadIdx.x == 0) a.ktime_base[((size_t)cur_iter * KT_WGS_DEV + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-    if (block_done || cur_iter == a.iter_end) {
-      if (a.abort_flag && threadIdx.x == 0) atomicMax(a.abort_flag + 1, cur_iter);   // statistics: iterations of the slowest block
-#ifdef BANG_PHASE_PROBE
-      if (a.abort_flag && blockIdx.x == 0 && threadIdx.x == 0)
-        for (int k = 0; k < 8; ++k) a.abort_flag[4 + k] = probe_acc[k];
-#endif
-      break;
-    }
-  }
-  }   // iterations
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1113,16 +900,16 @@ extern "C" int bang_k_lut_build(const float* d_pivots_T, const void* d_queries, 
   });
 }
 
-template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, bool PERSIST = false, int NHI = 0>
+template <int PSZ, int NDW, bool ALIGNED, bool ALL, int NQW, int MAXT, int NHI = 0>
 static int launch_front_inst(const FrontArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done[BANG_MAX_DEVICES] = {false};      // per kernel instance AND device
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>,
+    HIP_TRY(hipFuncSetAttribute((const void*)front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, NHI>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, PERSIST, NHI>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((front_kernel<PSZ, NDW, ALIGNED, ALL, NQW, MAXT, NHI>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
@@ -1135,25 +922,11 @@ static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid,
     // 96 dims in 74 chunks: 22 x 2 + 52 x 1), production (ALL) form only, rows of 70 / 74 bytes are never dword aligned
     constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
     if constexpr (NHI != 0) {
-      if ((int)a.p.pq_nhi == NHI && !aligned && a.stages == 7u) {
-        if (a.persist) return launch_front_inst<PSZ, NDW, false, true, 4, 512, true, NHI>(a, grid, block, lds, st);
-        return launch_front_inst<PSZ, NDW, false, true, 4, 512, false, NHI>(a, grid, block, lds, st);
-      }
+      if ((int)a.p.pq_nhi == NHI && !aligned && a.stages == 7u)
+        return launch_front_inst<PSZ, NDW, false, true, 4, 512, NHI>(a, grid, block, lds, st);
     }
     bang_set_error("no kernel instance for the exact-size pivot table psz=%u mp=%u nhi=%u", a.p.psz, a.p.mp, a.p.pq_nhi);
     return BANG_ERR_UNSUPPORTED;
-  }
-  if (a.persist) {
-    // persistent search kernel: 16 waves x 1 query each (128-VGPR build); for the SIFT1M-like layout 8 waves x 4 queries in
-    // flight (the 256-VGPR build) was measured slower (front phase 45 vs 30 us per iteration, sort/merge 18 vs 13.5 us).
-    // Layouts whose straight-line distance code does not fit 128 VGPRs only have the 8-wave build.
-    if constexpr (PSZ * NDW > 32) {
-      return aligned ? launch_front_inst<PSZ, NDW, true, true, 4, 512, true>(a, grid, block, lds, st)
-                     : launch_front_inst<PSZ, NDW, false, true, 4, 512, true>(a, grid, block, lds, st);
-    } else {
-      return aligned ? launch_front_inst<PSZ, NDW, true, true, 1, 1024, true>(a, grid, block, lds, st)
-                     : launch_front_inst<PSZ, NDW, false, true, 1, 1024, true>(a, grid, block, lds, st);
-    }
   }
   const bool all = (a.stages == 7u);
   if (!all) {
@@ -1172,11 +945,7 @@ static int launch_front_al(const FrontArgs& a, bool aligned, int nqw, dim3 grid,
 #undef BANG_FRONT_PICK
 }
 
-struct PersistArgs {
-  const uint32_t* go; uint32_t iter_end; uint32_t wg_queries; unsigned long long* ktime_base; uint32_t* abort_flag; uint32_t rows_uncached;
-};
-
-static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream, const PersistArgs* pa = nullptr) {
+static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream) {
   if (!p) return BANG_ERR_ARG;
   if (p->Q == 0) return BANG_OK;
   if (p->R > BANG_MAX_R || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
@@ -1184,22 +953,12 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_seed) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
   if ((stages & 4u) && (!p->d_wl_ids || !p->d_wl_dist || !p->d_wl_vis || !p->d_wl_cnt || !p->d_mark || !p->d_parents ||
                         !p->d_cand_ids || !p->d_cand_cnt)) { bang_set_error("null worklist/candidate buffer"); return BANG_ERR_ARG; }
-  if (p->h_done_flag && !pa && (!p->d_done_count || !p->h_parents)) { bang_set_error("completion flag needs d_done_count and h_parents"); return BANG_ERR_ARG; }
+  if (p->h_done_flag && (!p->d_done_count || !p->h_parents)) { bang_set_error("completion flag needs d_done_count and h_parents"); return BANG_ERR_ARG; }
   if ((stages & 1u) && (!p->d_bloom || (!p->first && !p->d_stage && !p->d_graph))) { bang_set_error("null filter buffer"); return BANG_ERR_ARG; }
   if ((stages & 2u) && (p->psz ? (!p->d_pivots_packed || !p->d_qc) : !p->d_lut)) { bang_set_error("null PQ buffer"); return BANG_ERR_ARG; }
   FrontArgs a;
   a.p = *p;
   a.stages = stages;
-  a.go = nullptr; a.iter_end = p->iter; a.scratch_words = 0; a.wg_queries = 0; a.ktime_base = nullptr; a.abort_flag = nullptr; a.rows_uncached = 0; a.persist = pa ? 1u : 0u;
-  if (pa) {
-    const bool host_paced = pa->go != nullptr;
-    if (stages != 7u || !pa->wg_queries || p->d_qmap || pa->iter_end < p->iter ||
-        (host_paced ? (!p->h_done_flag || !p->h_parents || !p->d_stage || p->d_graph) : !p->d_graph)) {
-      bang_set_error("bad persistent launch arguments"); return BANG_ERR_ARG;
-    }
-    a.go = pa->go; a.iter_end = pa->iter_end; a.wg_queries = pa->wg_queries; a.ktime_base = pa->ktime_base; a.abort_flag = pa->abort_flag;
-    a.rows_uncached = host_paced ? pa->rows_uncached : 1u;
-  }
   {
     static int dbg = -1;
     if (dbg < 0) { const char* v = getenv("BANG_FRONT_DEBUG"); dbg = v ? atoi(v) : 0; }
@@ -1230,45 +989,27 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   if (env_waves < 0) { const char* v = getenv("BANG_FRONT_WAVES"); env_waves = v ? atoi(v) : 0; }
   int wgs = need_piv ? num_cus() : num_cus() * 8;
   if (p->max_wgs && (int)p->max_wgs < wgs) wgs = (int)p->max_wgs;
-  const int per_wg = pa ? (int)pa->wg_queries : (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
+  const int per_wg = (int)((p->Q + (uint32_t)wgs - 1) / (uint32_t)wgs);   // queries a workgroup must cover
   // interleaving 4 queries per wave did not pay on SIFT1M-like data (the kernel is bound by random-access
   // throughput of the visited filter, not by dependent latency); kept selectable for other shapes
   // Layouts with > 32 chunk-dwords x floats per entry (m = 68..76 at 2 floats per entry: SIFT1B, DEEP100M) need more
   // than 128 VGPRs for the straight-line distance code: run them as <= 8 waves (256-VGPR budget, no spills) with 4
   // queries in flight per wave instead of 16 waves x 1 query.
   const bool heavy = p->psz != 0 && p->psz * (p->mp / 4u) > 32u;
-  int nqw = (stages != 7u) ? 1 : (pa ? (heavy ? 4 : 1) : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1)));
+  int nqw = (stages != 7u) ? 1 : (env_nqw > 0 ? env_nqw : (heavy ? 4 : 1));
   nqw = (nqw >= 2) ? 4 : 1;
-  int max_waves = (env_waves > 0 && !pa) ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
+  int max_waves = env_waves > 0 ? env_waves : ((heavy && stages == 7u) ? 8 : 16);
   if (p->pq_nhi) { nqw = 4; if (max_waves > 8) max_waves = 8; }      // the exact-size instances are 8 waves x 4 queries in flight
   if (max_waves > 16) max_waves = 16;
   int waves = (per_wg + nqw - 1) / nqw;
   if (waves < 1) waves = 1;
   if (waves > max_waves) waves = max_waves;
-  size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
-  size_t lds_extra = 0;
-  if (pa) {   // the wave's scratch doubles as its sort/merge view; one more 16-byte slot holds the broadcast `go` word
-    a.scratch_words = std::max<uint32_t>(FRONT_SCRATCH_WORDS * (uint32_t)nqw, back_view_words(p->L));
-    scratch_per_wave = (size_t)a.scratch_words * 4;
-    lds_extra = 16;
-  }
-  const int waves_wanted = waves;
-  while (waves > 1 && piv_bytes + lds_extra + (size_t)waves * scratch_per_wave > lds_cap) --waves;
-  const size_t lds = piv_bytes + lds_extra + (size_t)waves * scratch_per_wave;
+  const size_t scratch_per_wave = (size_t)FRONT_SCRATCH_WORDS * 4 * (size_t)nqw;
+  while (waves > 1 && piv_bytes + (size_t)waves * scratch_per_wave > lds_cap) --waves;
+  const size_t lds = piv_bytes + (size_t)waves * scratch_per_wave;
   if (lds > lds_cap) { bang_set_error("pivot table does not fit LDS (%zu B)", lds); return BANG_ERR_UNSUPPORTED; }
-  // a persistent launch that had to give up waves to make room for the merge scratch is slower than the per-iteration loop
-  if (pa && waves < waves_wanted && waves < (heavy ? 6 : 12)) {
-    bang_set_error("persistent search kernel: %d of %d waves fit beside the pivot table at L=%u", waves, waves_wanted, p->L);
-    return BANG_ERR_UNSUPPORTED;
-  }
   int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
-  if (pa) {
-    // one workgroup per block of wg_queries queries; every one of them must be resident (each waits for the host, which
-    // waits for all of them): at most one per CU
-    grid_n = (int)((p->Q + pa->wg_queries - 1) / pa->wg_queries);
-    if (grid_n > num_cus() || grid_n > (int)KT_WGS_DEV) { bang_set_error("persistent launch: %d workgroups exceed the CU count", grid_n); return BANG_ERR_ARG; }
-  }
   const dim3 grid(grid_n), block(waves * WAVE);
   const bool al = (p->m % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1292,11 +1033,6 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
 }
 
 extern "C" int bang_k_front(const bang_iter_params* p, void* stream) { return launch_front(p, 7u, stream); }
-extern "C" int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
-                                        unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_uncached, void* stream) {
-  PersistArgs pa{d_go, iter_end, wg_queries, d_ktime_base, d_abort, rows_uncached};
-  return launch_front(p, 7u, stream, &pa);
-}
 extern "C" int bang_num_cus(void) { return num_cus(); }
 
 // Is there a kernel instance for the exact-size pivot table of this layout (see launch_front_al)?
@@ -1304,15 +1040,6 @@ extern "C" int bang_ragged_supported(uint32_t psz, uint32_t mp, uint32_t nhi, ui
   return (psz == 2 && (m & 3u) != 0 && ((mp == 72 && nhi == 58) || (mp == 76 && nhi == 22))) ? 1 : 0;
 }
 
-// Does the persistent search kernel have room for enough waves (pivot table + per-wave front/merge scratch within 160 KB of
-// LDS) for this PQ layout and worklist length?  Mirrors the launcher's arithmetic.
-extern "C" int bang_persistent_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
-  const bool heavy = psz != 0 && psz * (mp / 4u) > 32u;
-  const uint32_t nqw = heavy ? 4u : 1u, waves = heavy ? 6u : 12u;      // at least three quarters of the waves must fit
-  const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
-  const size_t per_wave = (size_t)std::max<uint32_t>(FRONT_SCRATCH_WORDS * nqw, back_view_words(L)) * 4u;
-  return piv_bytes + 16 + waves * per_wave <= (size_t)160 * 1024 ? 1 : 0;
-}
 extern "C" int bang_k_filter(const bang_iter_params* p, void* stream) { return launch_front(p, 1u, stream); }
 extern "C" int bang_k_pqdist(const bang_iter_params* p, void* stream) { return launch_front(p, 2u, stream); }
 extern "C" int bang_k_parent(const bang_iter_params* p, void* stream) { return launch_front(p, 4u, stream); }

@@ -245,21 +245,6 @@ typedef struct {
  * (:1201-1241) -> compute_parent1 / compute_parent2 (:1464-1521 / :1384-1459), one wavefront per query. */
 int bang_k_front(const bang_iter_params* p, void* stream);
 
-/* Persistent search kernel: ONE launch runs the whole loop of a batch (bang_search.cu:650-958) -- front(t) = K5+K2+K4, then
- * back(t) = K3a+K3b, for t = p->iter .. iter_end.  Workgroup w owns queries [w*wg_queries, (w+1)*wg_queries) and advances on its
- * own; ceil(Q / wg_queries) workgroups, all resident (<= CU count).
- *  - host-paced (host-graph mode, d_go != NULL): before front(t) the workgroup waits until d_go[16*w] >= t (0xFFFFFFFF = stop);
- *    after front(t) it copies its parents to p->h_parents and stores t into p->h_done_flag[16*w].  rows_local = 1: p->d_stage is
- *    LOCAL device memory written by the CPU through the PCIe BAR (plain coalesced row loads); 0: mapped host memory
- *    (cache-bypassing loads).
- *  - self-paced (graph resident in HBM: d_go == NULL, p->d_graph set): no host involvement; a workgroup leaves when none of its
- *    queries is active any more.
- * d_ktime_base: [iter_end + 1][256][4] s_memrealtime stamps {go seen, front end, published, merge end} or NULL.  d_abort (2 words,
- * zeroed, or NULL): [0] is set when a workgroup gave up waiting for the host (3 s), [1] receives the highest iteration any
- * workgroup ran.  No d_qmap.  BANG_ERR_UNSUPPORTED if the pivot table plus the waves' merge scratch do not fit the 160 KB of LDS. */
-int bang_k_search_persistent(const bang_iter_params* p, uint32_t iter_end, uint32_t wg_queries, const uint32_t* d_go,
-                             unsigned long long* d_ktime_base, uint32_t* d_abort, uint32_t rows_local, void* stream);
-
 /* ---- the query-resident search kernel (csrc/bang_search.hip) ----
  * ONE launch runs the whole search loop of a batch (bang_search.cu:650-958): K5 neighbor_filtering_new (:1140-1165) ->
  * K2 compute_neighborDist_par (:1201-1241) -> K4 compute_parent1/2 (:1464-1521 / :1384-1459) -> K3a/K3b

@@ -90,17 +90,16 @@ def test_exact_size_pivot_table_host_side(libbang):
     assert binding.pack_pivots_ragged(np.zeros((256, 128), np.float32), chunk_offsets(128, 64), 128, 64, 64) == (0, None)   # all 2-dim: nothing to save
 
 
-def test_persistent_kernel_lds_budget_arithmetic(libbang):
-    """bang_persistent_supported(psz, mp, nhi, L): pivot table + the waves' merge scratch must fit 160 KB of LDS with at least
-    three quarters of the waves (host-side arithmetic, mirrors the launcher)."""
-    f = libbang.bang_persistent_supported
+def test_search_kernel_lds_budget_arithmetic(libbang):
+    """bang_search_supported(psz, mp, nhi, L) = waves per workgroup whose worklists fit the 160 KB of LDS beside the pivot table
+    (host-side arithmetic, mirrors the launcher)."""
+    f = libbang.bang_search_supported
     f.restype = C.c_int
     f.argtypes = [C.c_uint32] * 4
-    assert f(4, 32, 0, 70) == 1 and f(4, 32, 0, 200) == 1          # SIFT1M layout: 128 KB table, 16 waves
-    assert f(4, 32, 0, 512) == 0                                   # maximum L: not even 12 waves fit
-    assert f(2, 72, 0, 152) == 1                                   # 128 dims in 70 chunks, padded table 144 KB, 8 waves
-    assert f(2, 76, 0, 152) == 0 and f(2, 76, 22, 152) == 1        # 96 dims in 74 chunks: only the exact-size table (96 KB) fits
-    assert f(0, 5, 0, 100) == 1                                    # LUT path: no table in LDS
+    assert f(4, 32, 0, 70) == 16 and f(4, 32, 0, 152) == 14 and 4 <= f(4, 32, 0, 512) <= 6   # SIFT1M layout: 128 KB table
+    assert f(2, 72, 0, 152) < f(2, 72, 58, 152)                    # 128 dims in 70 chunks: padded 144 KB vs exact-size 128 KB
+    assert f(2, 76, 0, 152) < 4 and f(2, 76, 22, 152) == 16        # 96 dims in 74 chunks: only the exact-size table (96 KB) leaves room
+    assert f(0, 5, 0, 100) == 0 and f(4, 32, 0, 513) == 0          # LUT path / L beyond MAX_L: no search kernel
     g = libbang.bang_ragged_supported
     g.restype = C.c_int
     g.argtypes = [C.c_uint32] * 4

@@ -181,17 +181,17 @@ def test_exact_size_pivot_table_gives_the_same_distances(request, libbang, fixtu
 
 @pytest.mark.parametrize("fixture,L,ragged", [("small_f32", 40, False), ("small_i8", 24, False), ("small_u8", 32, False),
                                               ("small_deep", 32, True)])
-def test_persistent_search_kernel_alone(request, libbang, fixture, L, ragged):
-    """bang_k_search_persistent called directly (self-paced form: graph in HBM, no host in the loop), then K6 + K7: the ids and
-    exact distances must be the oracle's for the whole search, and the candidate log its expansion order."""
+def test_search_kernel_alone(request, libbang, fixture, L, ragged):
+    """bang_k_search called directly (self-paced form: graph in HBM, no host in the loop), then K6 + K7: the ids and exact
+    distances must be the oracle's for the whole search, the candidate log its expansion order, the iteration counts its own."""
     from bang_amd.binding import IterState
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     q = q[:24]
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
     st = IterState(ix, q, L, device_graph=True, ragged=ragged)
-    iters = st.run_persistent(wg_queries=16)
-    assert 1 <= iters <= L + 49
+    iters = st.run_search()
+    assert np.array_equal(iters.astype(np.int64), st_o[:, 0])
     ccnt, _, _ = st.candidates()
     assert np.array_equal(ccnt, st_o[:, 1].astype(ccnt.dtype))
     ids, dists = st.rerank(10)
