@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = os.path.join(_PKG, "lib", "libbang.so")
+_LIB = os.environ.get("BANG_AMD_LIB") or os.path.join(_PKG, "lib", "libbang.so")    # (override: A/B runs of experimental builds)
 
 U8, I8, F32 = 0, 1, 2
 DIST_L2, DIST_MIPS = 0, 1
@@ -85,7 +85,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
     srcs += [os.path.join(_PKG, "..", "include", f) for f in ("bang.h", "bang_c.h")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
-    if force or stale:
+    if (force or stale) and not os.environ.get("BANG_AMD_LIB"):
         subprocess.check_call(["make", "-C", _PKG, "-s", "-j4"])
     return _LIB
 

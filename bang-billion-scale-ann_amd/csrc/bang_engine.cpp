@@ -220,6 +220,11 @@ struct bang_engine {
   uint8_t* h_fp = nullptr;             // pinned mirror
   std::vector<uint8_t> h_fin;          // [Q] walker-side: query seen finished (its staged row count is already 0)
   uint32_t* h_stage = nullptr;         // pinned [Q][65]
+  // results of a query: ids [Q][k] u64 | dists [k][Q] f32 | iterations [Q] u32 in ONE device allocation (d_results), mirrored by a
+  // pinned host buffer (h_results): small batches come back in one asynchronous copy instead of three staged ones
+  uint8_t* d_results = nullptr;
+  uint8_t* h_results = nullptr;
+  size_t res_off_dists = 0, res_off_iters = 0, res_bytes = 0;
   uint64_t* d_ids_out = nullptr;
   float* d_dists_out = nullptr;
   std::vector<std::unique_ptr<Lane>> lanes;
@@ -538,8 +543,10 @@ void free_batch(bang_engine* e) {
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
-  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_ids_out); dfree(e->d_dists_out);
-  dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_qiters); dfree(e->d_srows); dfree(e->d_sctl);
+  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_results);
+  e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
+  if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
+  dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_pub_q) (void)hipHostFree(e->h_pub_q);
   if (e->h_pub_c) (void)hipHostFree(e->h_pub_c);
@@ -1059,6 +1066,15 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     while (ms_since(ts) * 1000.0 < (double)(e->stagger_us * ln.index)) _mm_pause();
   }
 
+  // diagnostic (BANG_TIMELINE=1): host time of every stage of one bang_query, with a stream sync behind each (stderr)
+  static const bool tl_on = getenv("BANG_TIMELINE") != nullptr;
+  auto tl_t = Clock::now();
+  auto tl = [&](const char* what) {
+    if (!tl_on) return;
+    (void)hipStreamSynchronize(ln.s_main);
+    fprintf(stderr, "[timeline lane %d] %-28s %8.1f us\n", ln.index, what, ms_since(tl_t) * 1000.0);
+    tl_t = Clock::now();
+  };
   // queries H2D (:612) + K1 (:623)
   uint8_t* dq = (uint8_t*)e->d_queries + (size_t)ln.q0 * qbytes;
   LANE_HIP(hipMemcpyAsync(dq, (const uint8_t*)h_queries + (size_t)ln.q0 * qbytes, (size_t)ln.nq * qbytes,
@@ -1070,6 +1086,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     BANG_TRY(bang_k_lut_build(e->d_pivots_T, dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_lut, ln.nq,
                               e->D, e->m, dim_adjust, ln.s_main));
 
+  tl("queries H2D + K1");
   uint32_t iter = 1;                                                         // :596
   // vector-log rows [fp_lo, fp_hi] are staged in pinned memory but not yet copied to the device
   uint32_t fp_lo = 0, fp_hi = 0;
@@ -1266,6 +1283,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   DBG("[lane %d] loop done iter=%u\n", ln.index, iter);
   BANG_TRY(flush_fp());
 
+  tl("search");
   // re-rank K6+K7 (:967-987)
   if (fp_any) {
     LANE_HIP(hipEventRecord(ln.ev_fp, ln.s_fp));
@@ -1289,20 +1307,42 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                                    e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D, (uint32_t)e->k,
                                    dim_adjust, e->d_ids_out, e->d_dists_out, ln.s_main));
   }
+  tl("re-rank");
   // results D2H (:997-999): ids [Q][k]; dists [k][Q] (rank-major)
-  LANE_HIP(hipMemcpyAsync(h_ids + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k,
-                          (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
-  LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
-                            (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
-  if (e->search_host) LANE_HIP(hipMemcpyAsync(pw_stats, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
-  if (e->search_v2 || e->search_host) LANE_HIP(hipMemcpyAsync(e->h_qiters.data() + ln.q0, e->d_qiters + ln.q0, (size_t)ln.nq * 4, hipMemcpyDeviceToHost, ln.s_main));
+  // A copy into the caller's pageable arrays is staged by the runtime and costs ~20 us before the first byte moves.  A batch whose
+  // results are small comes back whole in ONE asynchronous copy into the pinned mirror and is handed out with memcpy; a large one
+  // keeps the direct copies (the runtime pipelines its staging; one more pass over 1.2 MB on one core would cost as much).
+  const bool whole = ln.q0 == 0 && (int)ln.nq == Q && (int)ln.nq == e->Qcur;
+  const bool mailbox = whole && e->res_off_iters <= (size_t)BANG_RESULT_MAILBOX_BYTES;
+  uint32_t* h_abort = (uint32_t*)(e->h_results + e->res_bytes - 64) + ln.index;   // (one word per lane in the last line)
+  *h_abort = 0;
+  if (e->search_host) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
+  const bool iters = e->search_v2 || e->search_host;
+  if (mailbox) {
+    LANE_HIP(hipMemcpyAsync(e->h_results, e->d_results, iters ? e->res_off_iters + (size_t)ln.nq * 4 : e->res_off_iters,
+                            hipMemcpyDeviceToHost, ln.s_main));
+  } else {
+    LANE_HIP(hipMemcpyAsync(h_ids + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k,
+                            (size_t)ln.nq * e->k * sizeof(uint64_t), hipMemcpyDeviceToHost, ln.s_main));
+    LANE_HIP(hipMemcpy2DAsync(h_dists + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4,
+                              (size_t)e->k, hipMemcpyDeviceToHost, ln.s_main));
+    if (iters) LANE_HIP(hipMemcpyAsync(e->h_results + e->res_off_iters + (size_t)ln.q0 * 4, e->d_qiters + ln.q0, (size_t)ln.nq * 4,
+                                       hipMemcpyDeviceToHost, ln.s_main));
+  }
   ln.phase.store(6);
   LANE_HIP(hipStreamSynchronize(ln.s_main));
   ln.phase.store(7);
+  if (mailbox) {
+    memcpy(h_ids, e->h_results, (size_t)ln.nq * e->k * sizeof(uint64_t));
+    memcpy(h_dists, e->h_results + e->res_off_dists, (size_t)ln.nq * e->k * 4);
+  }
+  tl("results D2H");
+  pw_stats[0] = *h_abort;
   if (pw_stats[0]) { bang_set_error("search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
-  if (e->search_v2 || e->search_host) {
+  if (iters) {
+    const uint32_t* hq = (const uint32_t*)(e->h_results + e->res_off_iters) + ln.q0;
     uint32_t mx = 0;
-    for (uint32_t i = 0; i < ln.nq; ++i) mx = std::max(mx, e->h_qiters[ln.q0 + i]);
+    for (uint32_t i = 0; i < ln.nq; ++i) { e->h_qiters[ln.q0 + i] = hq[i]; mx = std::max(mx, hq[i]); }
     ln.iterations = mx;
   }
   DBG("[lane %d] synced\n", ln.index);
@@ -1578,10 +1618,19 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_cand_ids, nq * rows));
   BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
   BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
-  BANG_TRY(dmalloc(&e->d_ids_out, nq * e->k));
-  BANG_TRY(dmalloc(&e->d_dists_out, nq * e->k));
+  {
+    const size_t a64 = 63;
+    e->res_off_dists = ((size_t)nq * e->k * 8 + a64) & ~a64;
+    e->res_off_iters = (e->res_off_dists + (size_t)nq * e->k * 4 + a64) & ~a64;
+    e->res_bytes = (e->res_off_iters + (size_t)nq * 4 + 64 + a64) & ~a64;                   // + one line: the kernel's abort word
+    BANG_TRY(dmalloc(&e->d_results, e->res_bytes));
+    HIP_TRY(hipHostMalloc((void**)&e->h_results, e->res_bytes, hipHostMallocDefault));
+    e->d_ids_out = (uint64_t*)e->d_results;
+    e->d_dists_out = (float*)(e->d_results + e->res_off_dists);
+    e->d_qiters = (uint32_t*)(e->d_results + e->res_off_iters);
+    e->h_qiters.assign(nq, 0);
+  }
   BANG_TRY(dmalloc(&e->d_parents_dev, nq));
-  if (e->search_v2 || e->search_host) { BANG_TRY(dmalloc(&e->d_qiters, nq)); e->h_qiters.assign(nq, 0); }
   if (dev_graph) {
     BANG_TRY(dmalloc(&e->d_active, rows + 2));
   } else {

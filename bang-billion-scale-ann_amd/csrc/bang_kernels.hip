@@ -680,45 +680,57 @@ __global__ void center_queries_kernel(const T* __restrict__ queries, const float
 // ------------------------------------------------------------------------------------------
 #define RERANK_MAX_CAND (BANG_MAX_L + BANG_EXTRA_ITERS)
 
+// One thread per candidate, the canonical chain (ascending dimension, fmaf) -- but the vector arrives 128 bytes at a time: eight
+// 16-byte loads in flight before the first use, so a 128-byte u8 vector costs ONE memory round trip, not 32 dependent ones.
 template <typename T>
-__device__ __forceinline__ float exact_dist(const uint8_t* __restrict__ vec, const T* __restrict__ qv, uint32_t D);
-
+__device__ __forceinline__ float elem_diff(uint32_t w, int b, const T* __restrict__ qv, uint32_t j);
 template <>
-__device__ __forceinline__ float exact_dist<float>(const uint8_t* __restrict__ vec, const float* __restrict__ qv, uint32_t D) {
-  const float* v = (const float*)vec;
-  float acc = 0.0f;
-  for (uint32_t j = 0; j < D; ++j) {
-    const float diff = v[j] - qv[j];
-    acc = __builtin_fmaf(diff, diff, acc);
-  }
-  return acc;
+__device__ __forceinline__ float elem_diff<float>(uint32_t w, int, const float* __restrict__ qv, uint32_t j) {
+  return __uint_as_float(w) - qv[j];
 }
 template <>
-__device__ __forceinline__ float exact_dist<uint8_t>(const uint8_t* __restrict__ vec, const uint8_t* __restrict__ qv, uint32_t D) {
+__device__ __forceinline__ float elem_diff<uint8_t>(uint32_t w, int b, const uint8_t* __restrict__ qv, uint32_t j) {
+  return (float)((int)((w >> (8 * b)) & 0xffu) - (int)qv[j]);                       // int subtract :1294
+}
+template <>
+__device__ __forceinline__ float elem_diff<int8_t>(uint32_t w, int b, const int8_t* __restrict__ qv, uint32_t j) {
+  return (float)((int)(int8_t)((w >> (8 * b)) & 0xffu) - (int)qv[j]);
+}
+
+template <typename T>
+__device__ __forceinline__ float exact_dist(const uint8_t* __restrict__ vec, const T* __restrict__ qv, uint32_t D) {
+  constexpr uint32_t EPW = 4 / sizeof(T);                 // elements per dword
   float acc = 0.0f;
   uint32_t j = 0;
   if ((((uintptr_t)vec) & 3u) == 0) {
-    for (; j + 4 <= D; j += 4) {
-      const uint32_t w = *(const uint32_t*)(vec + j);
+    const uint32_t ndw = (D * (uint32_t)sizeof(T)) >> 2;
+    for (uint32_t w0 = 0; w0 + 4 <= ndw; w0 += 32) {
+      u32x4a w[8];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float diff = (float)((int)((w >> (8 * b)) & 0xffu) - (int)qv[j + b]);   // int subtract :1294
-        acc = __builtin_fmaf(diff, diff, acc);
+      for (int i = 0; i < 8; ++i)
+        if (w0 + 4 * i + 4 <= ndw) w[i] = *(const u32x4a*)(vec + (size_t)(w0 + 4 * i) * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (w0 + 4 * i + 4 <= ndw) {
+          const uint32_t ww[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int b = 0; b < (int)EPW; ++b) {
+              const float diff = elem_diff<T>(ww[d], b, qv, j);
+              acc = __builtin_fmaf(diff, diff, acc);
+              ++j;
+            }
+          }
+        }
       }
     }
   }
-  for (; j < D; ++j) {
-    const float diff = (float)((int)vec[j] - (int)qv[j]);
-    acc = __builtin_fmaf(diff, diff, acc);
-  }
-  return acc;
-}
-template <>
-__device__ __forceinline__ float exact_dist<int8_t>(const uint8_t* __restrict__ vec, const int8_t* __restrict__ qv, uint32_t D) {
-  const int8_t* v = (const int8_t*)vec;
-  float acc = 0.0f;
-  for (uint32_t j = 0; j < D; ++j) {
-    const float diff = (float)((int)v[j] - (int)qv[j]);
+  const T* v = (const T*)vec;
+  for (; j < D; ++j) {                                    // unaligned vectors, and the last < 16 bytes
+    float diff;
+    if constexpr (sizeof(T) == 4) diff = (float)v[j] - (float)qv[j];
+    else diff = (float)((int)v[j] - (int)qv[j]);
     acc = __builtin_fmaf(diff, diff, acc);
   }
   return acc;

@@ -43,7 +43,7 @@ struct SearchArgs {
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
 };
 
-#define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (key[64] + acc[64]) aliases both
+#define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
 __host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx) { return nctx * search_wl_words(L) + SRCH_SCRATCH_WORDS + 32u; }
@@ -77,37 +77,43 @@ __device__ __forceinline__ void wave_min_key(uint32_t& hi, uint32_t& lo) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Every lane brings up to two items (word index, bit mask, the word's value as probed in THIS iteration).  All probes of the
 // iteration were issued before this point and nothing was stored in between, so two lanes that hit the same word hold the same
-// old value.  tbl: 128 LDS words private to the wave.  Returns with every item stored, merged into another lane's store, or
-// (pa / pb still set) left for the atomic fallback.
+// old value.  tbl: 128 LDS words private to the wave, used as a claim table of 128 slots.  A round: every pending item writes its
+// tag {word, lane, a|b} into the slot its word hashes to and reads the slot back -- the last writer OWNS the slot and stores
+// old | bit.  An item that finds another WORD in its slot retries in the next round (another hash); one that finds its own word
+// under another tag (rare: ~0.3 per iteration) has its bit merged into the owner's store through the same slot.  Nothing needs
+// initialising: whoever reads a slot has just written it, so its content is this round's.  Returns with every item stored,
+// merged into another lane's store, or (pa / pb still set; ~0.03 per iteration) left for the atomic fallback.
 __device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint32_t* tbl, int lane, bool& pa, uint32_t ia,
                                               uint32_t ba, uint32_t wa, bool& pb, uint32_t ib, uint32_t bb, uint32_t wb) {
-  uint32_t* key = tbl;
-  uint32_t* acc = tbl + 64;
   const uint32_t tag_a = (ia << 7) | ((uint32_t)lane << 1), tag_b = (ib << 7) | ((uint32_t)lane << 1) | 1u;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     if (__ballot(pa || pb) == 0) break;                          // uniform
     const uint32_t mul = r == 0 ? 0x9E37u : r == 1 ? 0x85EBu : 0xC2B3u;
-    const uint32_t sa = ((ia * mul) >> 9) & 63u, sb = ((ib * mul) >> 9) & 63u;
-    key[lane] = 0xFFFFFFFFu;
+    const uint32_t sa = ((ia * mul) >> 9) & 127u, sb = ((ib * mul) >> 9) & 127u;
+    if (pa) tbl[sa] = tag_a;
+    if (pb) tbl[sb] = tag_b;                                      // a later instruction: wins over this lane's own item a
     wave_sync();
-    if (pa) key[sa] = tag_a;
-    if (pb) key[sb] = tag_b;                                      // a later instruction: wins over this lane's own item a
-    wave_sync();
-    const uint32_t ra = key[sa], rb = key[sb];
+    const uint32_t ra = tbl[sa], rb = tbl[sb];
     const bool own_a = pa && ra == tag_a, own_b = pb && rb == tag_b;
     const bool same_a = pa && !own_a && (ra >> 7) == ia, same_b = pb && !own_b && (rb >> 7) == ib;
-    if (own_a) acc[sa] = ba;
-    if (own_b) acc[sb] = bb;
     wave_sync();
-    if (same_a) (void)__hip_atomic_fetch_or(&acc[sa], ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_or_b32
-    if (same_b) (void)__hip_atomic_fetch_or(&acc[sb], bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    wave_sync();
-    if (own_a) bloom[ia] = wa | acc[sa];
-    if (own_b) bloom[ib] = wb | acc[sb];
+    uint32_t va = ba, vb = bb;
+    if (__ballot(same_a || same_b)) {                             // uniform, rare: the slots now collect the bits of their word
+      if (own_a) tbl[sa] = ba;
+      if (own_b) tbl[sb] = bb;
+      wave_sync();
+      if (same_a) (void)__hip_atomic_fetch_or(&tbl[sa], ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_or_b32
+      if (same_b) (void)__hip_atomic_fetch_or(&tbl[sb], bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      wave_sync();
+      if (own_a) va = tbl[sa];
+      if (own_b) vb = tbl[sb];
+      wave_sync();
+    }
+    if (own_a) bloom[ia] = wa | va;
+    if (own_b) bloom[ib] = wb | vb;
     pa = pa && !(own_a || same_a);
     pb = pb && !(own_b || same_b);
-    wave_sync();
   }
 }
 
@@ -140,8 +146,8 @@ __device__ __forceinline__ uint32_t rank_in(const float* sd, uint32_t n8, float 
 
 // merge of the nb leading sorted survivors into the worklist, in place (every read precedes every write: one wave, LDS in order)
 template <int WLR>
-__device__ __forceinline__ uint32_t merge_in_lds(const WaveLds& s, uint32_t n, uint32_t w_n, uint32_t L, uint32_t mark, int lane) {
-  const float worst = s.wd[w_n - 1];
+__device__ __forceinline__ uint32_t merge_in_lds(const WaveLds& s, uint32_t n, uint32_t w_n, uint32_t L, uint32_t mark, float worst,
+                                                 int lane) {
   const uint32_t lim = L < n ? L : n;
   uint32_t nb = lim;                                            // leading survivors with dist < worst (stop at the first >=) :1653-1657
   {
@@ -187,9 +193,65 @@ __device__ __forceinline__ uint32_t merge_in_lds(const WaveLds& s, uint32_t n, u
   return new_n;
 }
 
-// sort the n survivors (lane i < 64 holds survivor i, lane 0 also survivor 64) and merge them into the worklist; returns the new length
+// The common case of K3a + K3b -- worklist full (w_n == L), survivors in lanes (n <= 64) -- without sorting and without binary
+// searches.  Only survivors closer than the worklist's last entry can enter (:1653-1657; with no room left that IS the reference's
+// nb), and the merged position of every element is a count:
+//   new e : #{old : d_old < d_e}  (lower_bound :1675)  +  #{new f : d_f < d_e, or d_f == d_e and f before e}  (its stable rank :1559-1567)
+//   old k : k  +  #{new e : d_e <= d_k}               (upper_bound :1678)
+// One pass over the (few) entering survivors, broadcast from their lanes with v_readlane, updates all three counts in registers.
+template <int WLR>
+__device__ __forceinline__ void merge_few(const WaveLds& s, uint64_t m_in, float d0, uint32_t id0, uint32_t L, uint32_t mark, int lane) {
+  float od[WLR];
+  uint32_t oi[WLR], cnt[WLR], ov = 0;
+#pragma unroll
+  for (int j = 0; j < WLR; ++j) {
+    const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
+    od[j] = __builtin_inff(); oi[j] = 0; cnt[j] = 0;              // +inf: counted by no survivor's lower_bound, written nowhere
+    if (k < L) { od[j] = s.wd[k]; oi[j] = s.wi[k]; ov |= (uint32_t)s.wv[k] << j; }
+  }
+  uint32_t rank = 0, below = 0;
+  for (uint64_t mm = m_in; mm; mm &= mm - 1) {                     // uniform loop, input order
+    const int e = __builtin_ctzll(mm);
+    const float de = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d0), e));
+    rank += (de < d0 || (de == d0 && e < lane)) ? 1u : 0u;
+    uint32_t pp = 0;
+#pragma unroll
+    for (int j = 0; j < WLR; ++j) {
+      cnt[j] += (de <= od[j]) ? 1u : 0u;
+      pp += (uint32_t)__popcll(__ballot(od[j] < de));
+    }
+    if (lane == e) below = pp;
+  }
+  wave_sync();                                                     // every read of the old worklist precedes every write
+  if ((m_in >> lane) & 1ull) {
+    const uint32_t pn = below + rank;
+    if (pn < L) { s.wi[pn] = id0; s.wd[pn] = d0; s.wv[pn] = (id0 == mark) ? 1 : 0; }
+  }
+#pragma unroll
+  for (int j = 0; j < WLR; ++j) {
+    const uint32_t k = (uint32_t)lane + (uint32_t)j * WAVE;
+    const uint32_t po = k + cnt[j];
+    if (k < L && po < L) { s.wi[po] = oi[j]; s.wd[po] = od[j]; s.wv[po] = (((ov >> j) & 1u) || oi[j] == mark) ? 1 : 0; }   // + mark step :1711-1714
+  }
+  wave_sync();
+}
+
+// sort the n survivors (lane i < 64 holds survivor i, lane 0 also survivor 64) and merge them into the worklist; returns the new length.
+// worst = distance of the worklist's last entry (iter > 1)
 __device__ __forceinline__ uint32_t sort_and_merge(const WaveLds& s, uint32_t n, float d0, uint32_t id0, float d1, uint32_t id1,
-                                                   uint32_t iter, uint32_t w_n, uint32_t L, uint32_t medoid, uint32_t mark, int lane) {
+                                                   uint32_t iter, uint32_t w_n, uint32_t L, uint32_t medoid, uint32_t mark, float worst,
+                                                   int lane) {
+  if (iter > 1 && w_n == L && n <= 64) {
+    const uint64_t m_in = __ballot((uint32_t)lane < n && d0 < worst);
+    if ((uint32_t)__popcll(m_in) <= L) {                           // (more than L entering survivors: only with L < 64; general path)
+      const uint32_t wlr = (L + WAVE - 1) / WAVE;
+      if (wlr <= 1) merge_few<1>(s, m_in, d0, id0, L, mark, lane);
+      else if (wlr <= 2) merge_few<2>(s, m_in, d0, id0, L, mark, lane);
+      else if (wlr <= 4) merge_few<4>(s, m_in, d0, id0, L, mark, lane);
+      else merge_few<8>(s, m_in, d0, id0, L, mark, lane);
+      return L;
+    }
+  }
   const float inf = __builtin_inff();
   s.sd[lane] = ((uint32_t)lane < n) ? d0 : inf;
   if (lane < 8) s.sd[64 + lane] = (lane == 0 && n > 64) ? d1 : inf;
@@ -214,10 +276,32 @@ __device__ __forceinline__ uint32_t sort_and_merge(const WaveLds& s, uint32_t n,
     return new_n;
   }
   const uint32_t wlr = (w_n + WAVE - 1) / WAVE;                 // uniform: registers for the old entries a lane owns
-  if (wlr <= 1) return merge_in_lds<1>(s, n, w_n, L, mark, lane);
-  if (wlr <= 2) return merge_in_lds<2>(s, n, w_n, L, mark, lane);
-  if (wlr <= 4) return merge_in_lds<4>(s, n, w_n, L, mark, lane);
-  return merge_in_lds<8>(s, n, w_n, L, mark, lane);
+  if (wlr <= 1) return merge_in_lds<1>(s, n, w_n, L, mark, worst, lane);
+  if (wlr <= 2) return merge_in_lds<2>(s, n, w_n, L, mark, worst, lane);
+  if (wlr <= 4) return merge_in_lds<4>(s, n, w_n, L, mark, worst, lane);
+  return merge_in_lds<8>(s, n, w_n, L, mark, worst, lane);
+}
+
+// What K4 of the NEXT iteration needs from the worklist (compute_parent2 :1425-1446) -- its first unvisited entry and its last
+// distance -- is known as soon as this iteration's merge is done: fetched here, held in scalar registers, so that the parent
+// decision behind the distance stage is one compare instead of three dependent LDS round trips.
+struct WlHead { bool found; uint32_t idx, id; float d, tail; };
+__device__ __forceinline__ WlHead worklist_head(const WaveLds& s, uint32_t w_n, int lane) {
+  WlHead h;
+  h.found = false; h.idx = 0; h.id = 0; h.d = 0.0f; h.tail = 0.0f;
+  if (w_n == 0) return h;
+  for (uint32_t base = 0; base < w_n && !h.found; base += WAVE) {          // first unvisited entry :1425-1439
+    const uint32_t i = base + (uint32_t)lane;
+    const uint64_t mk = __ballot(i < w_n && s.wv[i < w_n ? i : 0] == 0);
+    if (mk) { h.idx = base + (uint32_t)__builtin_ctzll(mk); h.found = true; }
+  }
+  const float t = s.wd[w_n - 1];
+  const float d = s.wd[h.idx];
+  const uint32_t id = s.wi[h.idx];
+  h.tail = __uint_as_float(uni(__float_as_uint(t)));
+  h.d = __uint_as_float(uni(__float_as_uint(d)));
+  h.id = uni(id);
+  return h;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -319,12 +403,18 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   const uint32_t gw = blockIdx.x * nwaves + wave;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   constexpr int SB = (NDW >= 18) ? 6 : 0;          // long rows (70 .. 128 chunks): consumed 6 code dwords (24 chunks) at a time
+#ifndef BANG_HOST_EARLY_ROWS
+#define BANG_HOST_EARLY_ROWS 0     // host-paced instances: 60-100 B of scratch per lane with it, SIFT1B-shape 13.5 -> 16.3 ms
+#endif
+  constexpr bool EARLY_ROWS = !HOST || BANG_HOST_EARLY_ROWS;   // code rows requested before the filter update (else: behind it)
 
   // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
   bool active = false, exhausted = false;
   uint32_t q = 0, iter = 0, w_n = 0, cc = 0, mark = 0, evals = 0, fetched = 0;
   uint32_t cnt_in = 0, x0 = 0, x1 = 0;
   bool have_row = false;
+  WlHead head;                                     // first unvisited worklist entry + last distance, as of the last merge (uniform)
+  head.found = false; head.idx = 0; head.id = 0; head.d = 0.0f; head.tail = 0.0f;
   // the centred query of the current context, in registers (lane l of qc.v[r] = element 64 r + l; read with v_readlane): loaded
   // once per query instead of streamed through scalar loads in every iteration's distance stage
   constexpr int QW = NDW * 4 * PSZ;
@@ -347,7 +437,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 
   // diagnostic (p.d_prof != NULL, host-paced form): thread 0 of every workgroup accumulates where its half-rounds spend their time
   unsigned long long pf_poll = 0, pf_front = 0, pf_pub = 0, pf_back = 0, pf_n = 0, pf_t = 0;
-  const bool prof = HOST && p.d_prof != nullptr && threadIdx.x == 0;       // (first wave of the workgroup's first group)
+  const bool prof = HOST && p.d_prof != nullptr && wave == 0;             // uniform (the accumulators stay in scalar registers): first wave of the workgroup's first group
 #define PF_STAMP(acc) do { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); acc += t_ - pf_t; pf_t = t_; } } while (0)
   if (prof) pf_t = __builtin_amdgcn_s_memrealtime();
 
@@ -374,8 +464,11 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
     if (HOST) {
       if (nctx == 2) {                                                  // un-park context c
         const uint32_t* pk = park + c * SRCH_CTX_WORDS;
-        active = pk[0] != 0u; q = pk[1]; iter = pk[2]; w_n = pk[3]; cc = pk[4]; mark = pk[5]; evals = pk[6]; fetched = pk[7];
-        have_row = pk[8] != 0u;
+        active = uni(pk[0]) != 0u; q = uni(pk[1]); iter = uni(pk[2]); w_n = uni(pk[3]); cc = uni(pk[4]); mark = uni(pk[5]);
+        evals = uni(pk[6]); fetched = uni(pk[7]);
+        have_row = uni(pk[8]) != 0u;
+        head.found = uni(pk[9]) != 0u; head.idx = uni(pk[10]); head.id = uni(pk[11]);
+        head.d = __uint_as_float(uni(pk[12])); head.tail = __uint_as_float(uni(pk[13]));
         if (active) load_qc(q);
       }
       // ---------------- wait for the rows of this context's previous round
@@ -475,8 +568,12 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       evals += n;
       PH(2);   // compaction
 
+      // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
+      PqRow<NDW, ALIGNED> row;
+      if (EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, p.m, sid0);
+
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
-      // (before the distance stage: the hashes and the probed words die here instead of living through the register-hungry K2)
+      // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
       {
         bool pa = pass0, pb = pass0;
         filter_commit(bloom, tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b);
@@ -495,9 +592,8 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
-        PqRow<NDW, ALIGNED> row;
         if ((uint32_t)lane < n) {
-          pq_row_load(row, p.d_codes, p.m, sid0);
+          if (!EARLY_ROWS) pq_row_load(row, p.d_codes, p.m, sid0);
           d0 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
         if (n > 64) {                                          // survivor 64 (seed list only), lane 0
@@ -531,18 +627,12 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       if (first) {
         if (have_best) { found = true; parent = bid; from_best = true; }
       } else {
-        uint32_t w_hit = 0;
-        for (uint32_t base = 0; base < w_n && !found; base += WAVE) {      // first unvisited entry :1425-1439
-          const uint32_t i = base + (uint32_t)lane;
-          const uint64_t mk = __ballot(i < w_n && s.wv[i < w_n ? i : 0] == 0);
-          if (mk) { w_hit = base + (uint32_t)__builtin_ctzll(mk); found = true; }
-        }
-        if (found) {
-          const float wdist = s.wd[w_hit];
-          if (bd < wdist) { parent = bid; from_best = true; }
-          else { parent = s.wi[w_hit]; if (lane == 0) s.wv[w_hit] = 1; }
+        if (head.found) {                                      // first unvisited entry :1425-1439 (worklist_head() after the last merge)
+          found = true;
+          if (bd < head.d) { parent = bid; from_best = true; }
+          else { parent = head.id; if (lane == 0) s.wv[head.idx] = 1; }
         } else if (w_n > 0) {                                  // corner case :1442-1446
-          if (bd < s.wd[w_n - 1]) { found = true; parent = bid; from_best = true; }
+          if (bd < head.tail) { found = true; parent = bid; from_best = true; }
         }
       }
       parent = uni(parent);
@@ -606,7 +696,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
-      if (n > 0 && iter < cap_iter) w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, lane);
+      if (n > 0 && iter < cap_iter) w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
       PH(6);   // (publish +) sort/merge
 #ifdef BANG_SEARCH_PHASE_PROF
       if (wave == 0) ++ph_n;
@@ -625,6 +715,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         ++iter;
         have_row = found;
         cnt_in = n_cnt; x0 = n_x0;
+        head = worklist_head(s, w_n, lane);
       }
     }
     if (HOST && nctx == 2) {                                             // park context c
@@ -632,12 +723,13 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       if (lane == 0) {
         pk[0] = active ? 1u : 0u; pk[1] = q; pk[2] = iter; pk[3] = w_n; pk[4] = cc; pk[5] = mark; pk[6] = evals; pk[7] = fetched;
         pk[8] = have_row ? 1u : 0u;
+        pk[9] = head.found ? 1u : 0u; pk[10] = head.idx; pk[11] = head.id; pk[12] = __float_as_uint(head.d); pk[13] = __float_as_uint(head.tail);
       }
       wave_sync();
     }
     PF_STAMP(pf_back);
   }
-  if (prof) {
+  if (prof && lane == 0) {
     unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
     o[0] = pf_poll; o[1] = pf_front; o[2] = pf_pub; o[3] = pf_back; o[4] = pf_n;
   }

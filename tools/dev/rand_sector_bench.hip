@@ -42,6 +42,48 @@ __global__ __launch_bounds__(1024) void k(uint32_t* __restrict__ table, uint64_t
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// fetch-OR with return: ONE request per probe that both reads the old word and sets the bit (vs read + plain store above)
+template <int INFLIGHT, bool RETURN>
+__global__ __launch_bounds__(1024) void ka(uint32_t* __restrict__ table, uint64_t rows, uint32_t iters, uint32_t* out) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  for (uint32_t it = 0; it < iters; ++it) {
+    uint32_t v[INFLIGHT];
+#pragma unroll
+    for (int j = 0; j < INFLIGHT; ++j) {
+      const uint64_t r = mix(tid * 0x9E3779B97F4A7C15ull + (uint64_t)it * INFLIGHT + j) % rows;
+      if (RETURN) v[j] = __hip_atomic_fetch_or(&table[r], 1u << (it & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else { __hip_atomic_fetch_or(&table[r], 1u << (it & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v[j] = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < INFLIGHT; ++j) acc ^= v[j];
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int INFLIGHT, bool RETURN>
+static void run_atomic(const char* name, uint32_t* d_table, uint64_t table_bytes, int waves, uint32_t* d_out) {
+  const uint64_t rows = (table_bytes - 512) / 4;
+  const uint32_t iters = 64;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  dim3 grid(cus), block(waves * 64);
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((ka<INFLIGHT, RETURN>), grid, block, 0, 0, d_table, rows, 4u, d_out);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL((ka<INFLIGHT, RETURN>), grid, block, 0, 0, d_table, rows, iters, d_out);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double n = (double)cus * waves * 64 * iters * INFLIGHT;
+  printf("{\"case\": \"%s\", \"table_MB\": %.0f, \"row_bytes\": 4, \"inflight\": %d, \"waves_per_cu\": %d, \"atomic_return\": %d, "
+         "\"ms\": %.3f, \"G_rows_per_s\": %.2f}\n", name, table_bytes / 1e6, INFLIGHT, waves, (int)RETURN, ms, n / ms / 1e6);
+}
+
 template <int DW, int INFLIGHT, bool WRITE, bool BYPASS>
 static void run(const char* name, uint32_t* d_table, uint64_t table_bytes, uint32_t row_bytes, int waves, uint32_t* d_out) {
   const uint64_t rows = (table_bytes - 512) / row_bytes;
@@ -78,6 +120,9 @@ int main(int argc, char** argv) {
       run<1, 4, false, true>("probe 4 B, read only", d_table, tb, 4, waves, d_out);
       run<1, 4, true, true>("probe 4 B + plain store", d_table, tb, 4, waves, d_out);
       run<1, 8, false, true>("probe 4 B, read only", d_table, tb, 4, waves, d_out);
+      run_atomic<4, true>("probe 4 B, fetch-OR with return", d_table, tb, waves, d_out);
+      run_atomic<8, true>("probe 4 B, fetch-OR with return", d_table, tb, waves, d_out);
+      run_atomic<4, false>("probe 4 B, OR without return", d_table, tb, waves, d_out);
     }
     run<8, 2, false, false>("code row 32 B", d_table, tb, 32, 16, d_out);
     run<18, 1, false, false>("code row 70 B", d_table, tb, 70, 16, d_out);
