@@ -50,7 +50,7 @@ class SearchParams(C.Structure):
         ("Q", C.c_uint32), ("R", C.c_uint32), ("m", C.c_uint32), ("L", C.c_uint32), ("medoid", C.c_uint32), ("cap_iter", C.c_uint32),
         ("psz", C.c_uint32), ("mp", C.c_uint32), ("pq_nhi", C.c_uint32), ("max_wgs", C.c_uint32), ("max_waves", C.c_uint32),
         ("d_seed", C.c_void_p), ("d_codes", C.c_void_p), ("d_pivots_packed", C.c_void_p), ("d_qc", C.c_void_p),
-        ("d_graph", C.c_void_p), ("entry_len", C.c_uint64), ("vec_bytes", C.c_uint32),
+        ("d_graph", C.c_void_p), ("entry_len", C.c_uint64), ("vec_bytes", C.c_uint32), ("row_layout", C.c_uint32),
         ("d_bloom", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_cnt", C.c_void_p), ("d_qstats", C.c_void_p),
         ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
@@ -73,7 +73,7 @@ class Stats(C.Structure):
                 ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64),
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
-                ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64)]
+                ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64)]
 
 
 def lib_path() -> str:

@@ -36,7 +36,10 @@
 #include <string>
 #include <immintrin.h>
 #include <sched.h>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -273,6 +276,15 @@ struct bang_engine {
                                        // every expanded node's vector, as the reference does), 1 = a packed copy [N][vec_bytes] in HBM (the
                                        // walker ships adjacency rows only), -1 = auto (1 if the copy takes at most 40 % of the free HBM)
   bool vec_on_device = false;          // resolved at load
+  // PULL mode of the host-graph placement: the adjacency lists alone, as [N][64] u32 rows of 256 B (unused slots 0xFFFFFFFF), in
+  // pinned host memory mapped into the GPU's address space.  The self-paced search kernel fetches a parent's row over PCIe by
+  // itself (one 256-B read, ~2 us; 57 GB/s of such rows measured) -- no walker thread, no publish / poll round trip.
+  int pull_opt = -1;                   // -1 auto, 0 = walker (host-paced kernel), 1 = pull
+  bool pull = false;                   // resolved at load
+  uint32_t* h_adj = nullptr;           // [N][64]
+  size_t adj_bytes = 0;
+  std::string rows_key;                // names the shared rows file (BANG_PULL_ROWS_DIR): basename of the index prefix
+  const uint32_t* d_adj = nullptr;     // device address of h_adj
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
@@ -302,6 +314,155 @@ template <typename T>
 void dfree(T*& p) {
   if (p) (void)hipFree((void*)p);
   p = nullptr;
+}
+
+// CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the MI355X boxes expose 256 hardware
+// threads but grant 16 CPUs; spinning walker threads beyond the quota only starve each other)
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long quota = atol(q);
+      if (quota > 0) n = std::min<int>(n, (int)std::max<long>(1, quota / period));
+    }
+    fclose(f);
+  }
+  return std::max(1, n);
+}
+
+// host memory this process may still take: MemAvailable capped by what the cgroup has left
+static size_t host_bytes_available() {
+  size_t avail = ~(size_t)0;
+  if (FILE* f = fopen("/proc/meminfo", "r")) {
+    char line[128];
+    while (fgets(line, sizeof(line), f)) {
+      unsigned long long kb = 0;
+      if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (size_t)kb * 1024; break; }
+    }
+    fclose(f);
+  }
+  unsigned long long mx = 0, cur = 0;
+  bool have_mx = false, have_cur = false;
+  if (FILE* f = fopen("/sys/fs/cgroup/memory.max", "r")) { have_mx = fscanf(f, "%llu", &mx) == 1; fclose(f); }   // "max": no limit
+  if (FILE* f = fopen("/sys/fs/cgroup/memory.current", "r")) { have_cur = fscanf(f, "%llu", &cur) == 1; fclose(f); }
+  if (have_mx && have_cur) avail = std::min<size_t>(avail, mx > cur ? (size_t)(mx - cur) : 0);
+  return avail;
+}
+
+// Pull mode: the adjacency lists of the host graph, re-laid as 256-byte rows the GPU can fetch with one PCIe read each.
+// One copy per NODE when BANG_PULL_ROWS_DIR names a directory every rank can see (tmpfs): the rows live in the file
+// <dir>/<index name>_pull_rows.bin, built by whichever rank loads first (write to a temporary name, rename) and mapped shared by
+// the others; every rank registers the mapping with its own device.  Without the variable: private anonymous memory.
+struct PullRowsSig { char magic[8]; uint64_t N, medoid, R, sample_hash; };
+// what a rows file must match: sizes, medoid and the adjacency lists of 64 nodes spread over the index
+static PullRowsSig pull_rows_signature(const bang_engine* e) {
+  PullRowsSig g;
+  memcpy(g.magic, "BANGROWS", 8);
+  g.N = e->N; g.medoid = e->medoid; g.R = e->R;
+  uint64_t h = 0xcbf29ce484222325ull;
+  const size_t vb = vec_bytes(e);
+  for (uint32_t t = 0; t < 64; ++t) {
+    const size_t i = (size_t)((unsigned __int128)e->N * t / 64);
+    const uint8_t* ent = e->graph + i * e->entry_len + vb;
+    uint32_t deg;
+    memcpy(&deg, ent, 4);
+    if (deg > e->R) deg = e->R;
+    for (size_t b = 0; b < 4 + (size_t)deg * 4; ++b) h = (h ^ ent[b]) * 0x100000001b3ull;
+  }
+  g.sample_hash = h;
+  return g;
+}
+
+static int build_pull_rows(bang_engine* e) {
+  const size_t bytes = (size_t)e->N * 256 + 4096;
+  const size_t sig_off = (size_t)e->N * 256 + 2048;
+  const PullRowsSig sig = pull_rows_signature(e);
+  std::string path;
+  if (const char* dir = getenv("BANG_PULL_ROWS_DIR"))
+    if (*dir) path = std::string(dir) + "/" + (e->rows_key.empty() ? std::string("index") : e->rows_key) + "_pull_rows.bin";
+  void* m = MAP_FAILED;
+  bool fill = true;
+  if (!path.empty()) {
+    int fd = open(path.c_str(), O_RDWR);
+    if (fd >= 0) {                                 // built by another rank of this node (or an earlier run on the same index)
+      struct stat st;
+      if (fstat(fd, &st) == 0 && (size_t)st.st_size == bytes) {
+        m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED && memcmp((const uint8_t*)m + sig_off, &sig, sizeof(sig)) != 0) {   // another index: rebuild
+          (void)munmap(m, bytes);
+          m = MAP_FAILED;
+        }
+        fill = (m == MAP_FAILED);
+      }
+      close(fd);
+    }
+  }
+  if (m == MAP_FAILED) {
+    const size_t avail = host_bytes_available();
+    if (bytes + ((size_t)8 << 30) > avail) {       // never push the host into the OOM killer for an optimisation
+      bang_set_error("pull rows: %.1f GB do not fit the %.1f GB of host memory left", bytes / 1e9, avail / 1e9);
+      return BANG_ERR_NOMEM;
+    }
+    fill = true;
+    std::string tmp;
+    if (!path.empty()) {
+      tmp = path + ".tmp." + std::to_string((long)getpid());
+      const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+      if (fd >= 0) {
+        if (ftruncate(fd, (off_t)bytes) == 0) m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { (void)unlink(tmp.c_str()); tmp.clear(); }
+      } else tmp.clear();
+    }
+    if (m == MAP_FAILED) {
+      m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m == MAP_FAILED) { bang_set_error("pull rows: cannot map %.1f GB of host memory", bytes / 1e9); return BANG_ERR_NOMEM; }
+      (void)madvise(m, bytes, MADV_HUGEPAGE);
+      tmp.clear();
+    }
+    uint32_t* rows = (uint32_t*)m;
+    const size_t vb = vec_bytes(e);
+    const int T = std::max(1, std::min(16, usable_cpus()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([=]() {
+        const size_t a = (size_t)e->N * t / T, b = (size_t)e->N * (t + 1) / T;
+        for (size_t i = a; i < b; ++i) {
+          const uint8_t* ent = e->graph + i * e->entry_len + vb;
+          uint32_t deg;
+          memcpy(&deg, ent, 4);
+          if (deg > e->R) deg = e->R;
+          uint32_t* r = rows + i * 64;
+          memcpy(r, ent + 4, (size_t)deg * 4);
+          for (uint32_t k = deg; k < 64; ++k) r[k] = 0xFFFFFFFFu;
+        }
+      });
+    for (auto& x : th) x.join();
+    memset((uint8_t*)m + (size_t)e->N * 256, 0xFF, 4096);
+    memcpy((uint8_t*)m + sig_off, &sig, sizeof(sig));
+    if (!tmp.empty() && rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());   // (the mapping stays valid either way)
+  }
+  (void)fill;
+  if (hipHostRegister(m, bytes, hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)munmap(m, bytes);
+    bang_set_error("pull rows: hipHostRegister of %.1f GB failed", bytes / 1e9);
+    return BANG_ERR_HIP;
+  }
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, m, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(m);
+    (void)munmap(m, bytes);
+    bang_set_error("pull rows: no device address for the registered rows");
+    return BANG_ERR_HIP;
+  }
+  e->h_adj = (uint32_t*)m; e->adj_bytes = bytes; e->d_adj = (const uint32_t*)dp; e->pull = true;
+  return BANG_OK;
 }
 
 int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext, const float* pivots,
@@ -422,6 +583,17 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       e->vec_on_device = true;
     }
   }
+  e->pull = false;
+  if (e->graph_mode != BANG_GRAPH_DEVICE && e->pull_opt != 0) {
+    // pull needs the re-rank's vectors in HBM (nothing walks the graph entries any more) and rows of <= 64 ids
+    if (e->vec_on_device && e->R <= 64) {
+      const int rc = build_pull_rows(e);
+      if (rc != BANG_OK && e->pull_opt == 1) return rc;            // asked for explicitly: report; auto: the walker serves the graph
+    } else if (e->pull_opt == 1) {
+      bang_set_error("option pull = 1 needs the full-precision vectors resident in HBM (option vectors) and R <= 64");
+      return BANG_ERR_ARG;
+    }
+  }
   if (e->graph_mode == BANG_GRAPH_DEVICE) {
     const size_t gbytes = (size_t)e->N * e->entry_len;
     HIP_TRY(hipMalloc((void**)&e->d_graph, gbytes + 256));
@@ -447,6 +619,8 @@ void unload_index(bang_engine* e) {
   dfree(e->d_graph);
   dfree(e->d_vecs);
   e->vec_on_device = false;
+  if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
+  e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
   free(e->graph_owned);
   e->graph_owned = nullptr;
   if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
@@ -565,6 +739,10 @@ bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n;
 
 int load_files(bang_engine* e, const char* prefix) {
   const std::string p(prefix);
+  {
+    const size_t sl = p.find_last_of('/');
+    e->rows_key = (sl == std::string::npos) ? p : p.substr(sl + 1);
+  }
   const std::string f_piv = p + "_pq_pivots.bin", f_cmp = p + "_pq_compressed.bin", f_graph = p + "_disk.bin",
                     f_meta = p + "_disk_metadata.bin";                       // suffixes :39-45
   FILE* fp = fopen(f_piv.c_str(), "rb");
@@ -1111,6 +1289,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
     sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
     sp.d_graph = e->d_graph; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
+    if (!dev_graph) { sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1; }   // pull mode
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
     sp.d_ktime = ktime_slot(e, ln);
@@ -1440,6 +1619,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
   if (const char* v = getenv("BANG_USE_FLAG")) e->use_flag = atoi(v) ? 1 : 0;
   if (const char* v = getenv("BANG_PERSISTENT")) e->persistent = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_NUMA")) e->numa_opt = std::min(1, std::max(-1, atoi(v)));
+  if (const char* v = getenv("BANG_PULL")) e->pull_opt = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_SEARCH")) e->search_opt = std::min(1, std::max(-1, atoi(v)));
   if (const char* v = getenv("BANG_STAGE_ZC")) e->stage_zero_copy = std::min(2, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_STAGGER_US")) e->stagger_us = std::max(0, atoi(v));
@@ -1466,7 +1646,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   const std::string k(key);
   // placement and layout options are consumed by bang_load, loop-shape options by bang_alloc (bang_c.h): changing them
   // afterwards would leave buffers that do not match the option
-  if (e->loaded && (k == "graph" || k == "device" || k == "pq" || k == "pq_ragged" || k == "vectors")) {
+  if (e->loaded && (k == "graph" || k == "device" || k == "pq" || k == "pq_ragged" || k == "vectors" || k == "pull")) {
     bang_set_error("option %s must be set before bang_load", key); return BANG_ERR_ARG;
   }
   if (e->allocated && (k == "lanes" || k == "threads" || k == "stage_zero_copy" || k == "persistent" || k == "search" || k == "numa" || k == "timing" || k == "front_wgs")) {
@@ -1485,6 +1665,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
   else if (k == "compact") { e->compact = value ? 1 : 0; }
   else if (k == "persistent") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->persistent = (int)value; }
   else if (k == "numa") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->numa_opt = (int)value; }
+  else if (k == "pull") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->pull_opt = (int)value; }
   else if (k == "search") { if (value < -1 || value > 1) return BANG_ERR_ARG; e->search_opt = (int)value; }
   else if (k == "fp_batch") { if (value < 1) return BANG_ERR_ARG; e->fp_batch = (int)value; }
   else if (k == "front_wgs") { if (value < 0) return BANG_ERR_ARG; e->front_wgs_opt = (int)value; }
@@ -1531,23 +1712,6 @@ extern "C" int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklis
   return BANG_OK;
 }
 
-// CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the MI355X boxes expose 256 hardware
-// threads but grant 16 CPUs; spinning walker threads beyond the quota only starve each other)
-static int usable_cpus() {
-  int n = (int)std::thread::hardware_concurrency();
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char q[64];
-    long period = 0;
-    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-      const long quota = atol(q);
-      if (quota > 0) n = std::min<int>(n, (int)std::max<long>(1, quota / period));
-    }
-    fclose(f);
-  }
-  return std::max(1, n);
-}
 
 static int alloc_buffers(bang_engine* e, int Q) {
   const size_t L = (size_t)e->L, nq = (size_t)Q;
@@ -1584,7 +1748,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   e->pq_nhi = 0;
   // graph in HBM: the query-resident search kernel, with whichever pivot table (padded / exact-size) leaves LDS for more waves
   e->search_v2 = false;
-  if (dev_graph && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
+  if ((dev_graph || e->pull) && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
     const int w_pad = bang_search_supported(e->psz, e->mp, 0, (uint32_t)e->L);
     const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
     if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
@@ -1594,7 +1758,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   }
   // graph in host RAM: the host-paced form of the same kernel, where the walker can write device memory (BAR mode)
   e->search_host = false;
-  if (!dev_graph && persist_want && e->use_flag && e->stage_mode_eff == 2 && e->search_opt != 0 && e->psz != 0) {
+  if (!dev_graph && !e->search_v2 && persist_want && e->use_flag && e->stage_mode_eff == 2 && e->search_opt != 0 && e->psz != 0) {
     const int w_pad = bang_search_supported(e->psz, e->mp, 0, (uint32_t)e->L);
     const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
     if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
@@ -1849,6 +2013,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
   s.wg_queries = e->search_host ? e->sv_W * e->sv_C : 0;
   s.pacing_groups = e->search_host ? e->sv_NG : 0;
+  s.graph_pull = (e->pull && e->search_v2 && e->graph_mode != BANG_GRAPH_DEVICE) ? 1 : 0;
   s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
   s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
   return rc;
@@ -1909,6 +2074,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     s.hops_p50 = cc[cc.size() / 2];
     s.hops_p99 = cc[std::min(cc.size() - 1, (cc.size() * 99) / 100)];
     s.hops_max = cc.back();
+    if (s.graph_pull) s.pulled_bytes = (s.candidates - (uint64_t)e->Qcur) * 256;      // one row per expansion (the seed list is on the device)
   }
   *out = s;
   return BANG_OK;

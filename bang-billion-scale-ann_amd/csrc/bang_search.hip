@@ -535,6 +535,8 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
     if (active) {
       // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
       uint32_t ci = have_row ? uni(cnt_in) : 0u;
+      if (!HOST && p.row_layout && !first && have_row)       // ids ascending, padding behind them
+        ci = (uint32_t)__popcll(__ballot(x0 != 0xFFFFFFFFu));
       PH(0);   // the adjacency row has arrived (and: query hand-out, loop overhead)
       {
         const uint32_t cap = p.R + (first ? 1u : 0u);
@@ -650,9 +652,14 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
     if (!HOST) {
       // graph resident in HBM: the next adjacency row is requested NOW; it travels while the survivors are merged
       if (want_row) {
-        const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
-        n_cnt = nrow[0];
-        n_x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
+        if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
+          n_x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
+          n_cnt = 64u;                                       // counted when the row is consumed
+        } else {
+          const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
+          n_cnt = nrow[0];
+          n_x0 = nrow[1 + lane];                             // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
+        }
       }
     } else {
       uint32_t* cnt_act = wg_lds + 1 + (tick % 3u);

@@ -85,7 +85,7 @@ def shared_dir(ctx):
     return os.path.join("/tmp", tag)
 
 
-def build_workload(name, ctx, Q=0, shape_n=0):
+def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True):
     """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), prefix (index files, N > 1), release().
 
     N > 1 (one process per GPU): ONE host graph for the node (the reference keeps one pIndex in host RAM,
@@ -105,22 +105,20 @@ def build_workload(name, ctx, Q=0, shape_n=0):
         from tools import shape_workload
         shared = None
         if world > 1:
-            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
+            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
             dist.broadcast(n_plan, 0)
             shape_n = int(n_plan.item())
             shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
         ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
-            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared)
+            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows)
 
         def rel():
             shape_workload.release(ix)
             if world > 1:
                 dist.barrier()
                 if rank == 0:
-                    try:
-                        os.unlink(shared[0])
-                    except OSError:
-                        pass
+                    import shutil
+                    shutil.rmtree(sdir, ignore_errors=True)      # the graph image and the engine's pull rows file
     else:
         N, D, dtype, R, m, Qd, ncl = WORKLOADS[name]
         wl_name = (f"{name}: SIFT1M-like structured synthetic, {dtype} N={N} D={D} R={R} m={m} "
@@ -158,18 +156,33 @@ def build_workload(name, ctx, Q=0, shape_n=0):
     torch.cuda.synchronize()
     log(f"[bench] workload built in {time.time() - t0:.1f}s: {wl_name}")
     return dict(ix=ix, queries=queries, gt_i=gt_i, gt_d=gt_d, d_codes=d_codes, name=wl_name, graph=shape_graph, release=rel,
-                key=name, prefix=prefix)
+                key=name, prefix=prefix, shared_dir=sdir)
 
 
 # ---------------------------------------------------------------------------------------------------------- one measurement
-def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1):
+def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
+    """pull: host-graph placement only -- -1 = engine default (the kernel pulls adjacency rows over PCIe when the rows fit the host
+    memory next to the graph, else the C++ walker serves them), 0 = walker, 1 = pull."""
     import bang_amd
+    import torch.distributed as dist
     gm = {"host": bang_amd.GRAPH_HOST, "device": bang_amd.GRAPH_DEVICE, "auto": bang_amd.GRAPH_AUTO}[graph]
-    eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing)
-    if wl.get("prefix"):
-        eng.load(wl["prefix"])                   # bang_load on the shared index files: `_disk.bin` is mapped, not copied
+    eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing, pull=pull)
+
+    def load():
+        if wl.get("prefix"):
+            eng.load(wl["prefix"])               # bang_load on the shared index files: `_disk.bin` is mapped, not copied
+        else:
+            eng.load_index(wl["ix"], d_codes=wl["d_codes"])
+    if ctx.world > 1 and wl.get("shared_dir"):
+        # one copy of the pull rows per node: rank 0 builds the rows file in the shared directory, the others map it
+        os.environ["BANG_PULL_ROWS_DIR"] = wl["shared_dir"]
+        if ctx.rank == 0:
+            load()
+        dist.barrier()
+        if ctx.rank != 0:
+            load()
     else:
-        eng.load_index(wl["ix"], d_codes=wl["d_codes"])
+        load()
     return eng
 
 
@@ -222,9 +235,9 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         run_once(eng, my_q, ctx, timed=True)
     step_s, init_s = [], []
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
-                "workgroups", "hops_p50", "hops_p99", "hops_max")
+                "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
-               fetched=0, candidates=0, h2d_bytes=0)
+               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0)
     agg.update({kk: 0 for kk in keys_max})
     ids = dists = None
     for _ in range(steps):
@@ -279,7 +292,12 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
                          "rocprofv3 --kernel-trace in profiles/"}
         if traffic_note:
             roof["traffic_note"] = traffic_note
-        if persistent and graph == "host":
+        if persistent and graph == "host" and agg.get("graph_pull"):
+            pb = agg["pulled_bytes"] / launches
+            roof["pcie_pull"] = {"bytes_per_launch": int(pb), "achieved_GBps": round(pb / (avg_ms * 1e-3) / 1e9, 2),
+                                 "note": "256-byte adjacency rows the kernel reads from pinned host memory; 57 GB/s of such rows measured "
+                                         "(tools/dev/gpu_pull_bench.hip)"}
+        elif persistent and graph == "host":
             h2d = agg["h2d_bytes"] / launches
             roof["pcie_h2d"] = {"bytes_per_launch": int(h2d), "achieved_GBps": round(h2d / (avg_ms * 1e-3) / 1e9, 2),
                                 "note": "adjacency rows (+ vectors if shipped) the walker threads store through the PCIe BAR while the "
@@ -288,15 +306,27 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
     return res
 
 
+def host_loop_name(a, graph):
+    if not a["persistent"]:
+        return "launch per iteration"
+    if graph == "device":
+        return "search kernel, self-paced (graph in HBM)"
+    if a.get("graph_pull"):
+        return "search kernel, self-paced: adjacency rows pulled from pinned host memory over PCIe by the kernel (no walker thread)"
+    return "search kernel, host-paced: C++ walker threads write adjacency rows through the PCIe BAR"
+
+
 def leg_summary(res, wl, graph, recall=None, props=None, extra=None):
     a = res["agg"]
     out = {"workload": wl["name"], "graph": graph, "L": res["L"], "queries_per_s": res["queries_per_s"],
            "ms_per_batch": res["ms_per_step"], "iterations": a["iterations"],
            "hops_p50_p99_max": [a["hops_p50"], a["hops_p99"], a["hops_max"]],
-           "host_loop": "persistent search kernel" if a["persistent"] else "launch per iteration",
+           "host_loop": host_loop_name(a, graph),
            "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                               "packed copy in HBM" if a["vectors_on_device"] else "shipped by the walker (PCIe)"),
            "steps": len(res["step_ms"]), "step_ms_min_max": [min(res["step_ms"]), max(res["step_ms"])]}
+    if a.get("graph_pull"):
+        out["pcie_pulled_bytes_per_batch"] = int(a["pulled_bytes"] // max(1, len(res["step_ms"])))
     if recall is not None:
         out["recall_at_10"] = round(recall, 3)
     if props is not None:
@@ -393,6 +423,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="walker threads per lane; 0 = engine default")
     ap.add_argument("--batches", type=int, default=1, help="N > 1 throughput mode: every rank streams this many WHOLE batches per step")
+    ap.add_argument("--pull", type=int, default=-1, choices=[-1, 0, 1],
+                    help="host-graph placement: 1 = the kernel pulls adjacency rows over PCIe, 0 = C++ walker threads, -1 = engine default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -431,7 +463,7 @@ def main():
     if world > 1:
         dist.barrier()
 
-    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n)
+    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n, reserve_rows=(args.pull != 0))
     ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
     # placement: the engine's own default ("auto": the whole graph in HBM when it fits next to the PQ codes with 16 GB to spare,
     # else host RAM + C++ walker) for the structured workloads; the shape-only workloads use the placement BASELINE.json names
@@ -453,7 +485,7 @@ def main():
         share = max(1, usable_cpus() // world)
         if not threads:
             threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // max(1, lanes or 1)))
-    eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1)
+    eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=args.pull)
 
     def recall_of(ids, a=q0, b=q1):
         if gt_i is None:
@@ -533,11 +565,12 @@ def main():
                "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
                "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
                "iterations": agg["iterations"], "hops_p50_p99_max": [agg["hops_p50"], agg["hops_p99"], agg["hops_max"]],
-               "host_loop": "persistent search kernel" if agg["persistent"] else "launch per iteration",
+               "host_loop": host_loop_name(agg, graph),
                "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                                   "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
                "vector_dtype": ix.dtype, "batches_per_step": args.batches if weak else 1,
                "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
+               "pcie_pulled_bytes_per_step": int(agg["pulled_bytes"] // args.steps),
                "qps_incl_init": res["qps_incl_init"],
                "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
                "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
@@ -573,6 +606,14 @@ def main():
         r3 = measure(e2, wl, my_q, L, leg_steps, leg_warm, ctx, other, traffic_key=f"{args.workload}_{other}")
         cfg[f"at_{other}_graph"] = leg_summary(r3, wl, other, recall=recall_of(r3["ids"]),
                                                extra={"ids_equal_primary_run": bool(np.array_equal(r3["ids"], ids))})
+        e2.free(); e2.unload(); e2.close()
+        # the north-star data flow (C++ walker threads serve the adjacency lists) beside the pull mode
+        e2 = make_engine(wl, "host", ctx, timing=0 if args.no_events else 1, pull=0)
+        e2.set_searchparams(k, L)
+        e2.alloc(Qr)
+        r3 = measure(e2, wl, my_q, L, leg_steps, leg_warm, ctx, "host")
+        cfg["at_host_graph_walker"] = leg_summary(r3, wl, "host", recall=recall_of(r3["ids"]),
+                                                  extra={"ids_equal_primary_run": bool(np.array_equal(r3["ids"], ids))})
         e2.free(); e2.unload(); e2.close()
     k2 = {}
     if legs:

@@ -133,6 +133,9 @@ typedef struct {
   uint64_t hops_p50, hops_p99, hops_max;
   uint64_t search_kernel;     /* 1: the batch ran on the query-resident search kernel (bang_k_search) */
   uint64_t pacing_groups;     /* host-paced search kernel: groups of waves the walker threads serve (0 otherwise) */
+  uint64_t graph_pull;        /* host-graph placement: 1 = PULL mode -- the adjacency lists live as 256-byte rows in pinned host memory
+                                 and the self-paced search kernel fetches them over PCIe by itself (no walker thread in the loop) */
+  uint64_t pulled_bytes;      /* pull mode: bytes of adjacency rows the kernel fetched over PCIe (256 per expansion) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -264,6 +267,9 @@ typedef struct {
   const uint8_t* d_graph;              /* [N][entry_len] */
   uint64_t entry_len;
   uint32_t vec_bytes;
+  uint32_t row_layout;                 /* 0: d_graph = graph entries [vec][u32 degree][u32 id x R] at entry_len.  1: d_graph = ADJACENCY ROWS only,
+                                          [N][64] u32 at a stride of 256 B, unused slots = 0xFFFFFFFF (BANG_ADJ_PAD) -- the layout the engine
+                                          keeps in pinned HOST memory for the pull mode: the kernel fetches rows over PCIe by itself */
   uint32_t* d_bloom;                   /* [Q][BANG_BF_WORDS] visited filters, zeroed (bang_init) */
   uint32_t* d_cand_ids;                /* [Q][L + 50] out: expanded nodes in expansion order, [0] = MEDOID */
   uint32_t* d_cand_cnt;                /* [Q] out */

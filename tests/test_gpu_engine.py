@@ -96,7 +96,7 @@ def test_engine_host_loop_options_do_not_change_results(request, libbang, fixtur
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     ids_o, dists_o = O.Oracle(ix).search(q, 10, 33)
-    with bang_amd.Engine(ix.dtype, graph=0) as e:
+    with bang_amd.Engine(ix.dtype, graph=0, pull=0) as e:          # (pull = 0: the walker serves the graph; these are its knobs)
         for k, v in opts.items():
             if k == "use_flag":
                 continue
@@ -105,7 +105,7 @@ def test_engine_host_loop_options_do_not_change_results(request, libbang, fixtur
             import os
             os.environ["BANG_USE_FLAG"] = "0"
         try:
-            e2 = bang_amd.Engine(ix.dtype, graph=0) if "use_flag" in opts else e
+            e2 = bang_amd.Engine(ix.dtype, graph=0, pull=0) if "use_flag" in opts else e
             e2.load_index(ix)
             e2.set_searchparams(10, 33)
             e2.alloc(q.shape[0])
@@ -140,7 +140,8 @@ def test_engine_host_loop_variants_match_oracle(request, libbang, fixture, L, pe
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
-    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=persistent, vectors=vectors)
+    ids, dists, st = _run_engine(ix, q, 10, L, graph=0, persistent=persistent, vectors=vectors, pull=0)
+    assert st["graph_pull"] == 0
     assert np.array_equal(ids, ids_o)
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
     assert st["dist_evals"] == int(st_o[:, 2].sum())
@@ -262,7 +263,7 @@ def test_search_kernel_host_paced_matches_oracle_per_query(request, libbang, fix
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
-    with bang_amd.Engine(ix.dtype, graph=0, search=1, vectors=vectors, timing=1) as e:
+    with bang_amd.Engine(ix.dtype, graph=0, search=1, vectors=vectors, timing=1, pull=0) as e:
         e.load_index(ix)
         e.set_searchparams(10, L)
         e.alloc(q.shape[0])
@@ -270,6 +271,7 @@ def test_search_kernel_host_paced_matches_oracle_per_query(request, libbang, fix
             e.init(q.shape[0])
             ids, dists = e.query(q)
             st = e.stats()
+            assert st["graph_pull"] == 0
             if not st["search_kernel"]:
                 pytest.skip("device memory is not CPU-writable here (no large BAR): the host-paced search kernel is not used")
             assert st["persistent"] == 1 and st["front_launches"] == 1 and st["vectors_on_device"] == vectors
@@ -292,7 +294,7 @@ def test_search_kernel_host_paced_batch_sizes(request, libbang, small_u8, Q, thr
     for max_wgs in ("0", "2"):
         os.environ["BANG_SEARCH_MAX_WGS"] = max_wgs
         try:
-            with bang_amd.Engine(ix.dtype, graph=0, search=1, threads=threads) as e:
+            with bang_amd.Engine(ix.dtype, graph=0, search=1, threads=threads, pull=0) as e:
                 e.load_index(ix)
                 e.set_searchparams(10, 48)
                 e.alloc(Q)
@@ -304,3 +306,113 @@ def test_search_kernel_host_paced_batch_sizes(request, libbang, small_u8, Q, thr
                 assert np.array_equal(e.query_counters(Q), st_o)
         finally:
             os.environ.pop("BANG_SEARCH_MAX_WGS", None)
+
+
+# ------------------------------------------------------------------------------------------------------------------ pull mode
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("L", [10, 64, 152, 400])
+def test_search_kernel_pull_mode_matches_oracle_per_query(request, libbang, fixture, L):
+    """Graph in host RAM, PULL mode: the adjacency lists live as 256-byte rows in pinned host memory and the self-paced search
+    kernel fetches a parent's row over PCIe by itself -- no walker thread, no bytes pushed by the host.  Per-query counters, ids
+    and distances equal the oracle's; one row is pulled per expansion."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q = q.shape[0]
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=0, pull=1, timing=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, L)
+        e.alloc(Q)
+        for _ in range(2):
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+            assert st["graph_mode"] == 0 and st["graph_pull"] == 1 and st["search_kernel"] == 1 and st["front_launches"] == 1
+            assert st["vectors_on_device"] == 1 and st["h2d_bytes"] == 0 and st["pacing_groups"] == 0
+            assert np.array_equal(ids, ids_o)
+            assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(Q), st_o)
+            assert st["pulled_bytes"] == 256 * (int(st_o[:, 1].sum()) - Q)
+        e.free()
+        e.unload()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Q", [1, 5, 63, 700])
+def test_search_kernel_pull_mode_batch_sizes(libbang, small_u8, Q):
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    qq = np.ascontiguousarray(np.tile(q, ((Q + q.shape[0] - 1) // q.shape[0], 1))[:Q])
+    ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 48, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=0, pull=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 48)
+        e.alloc(Q)
+        e.init(Q)
+        ids, dists = e.query(qq)
+        assert e.stats()["graph_pull"] == 1
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        assert np.array_equal(e.query_counters(Q), st_o)
+
+
+@pytest.mark.gpu
+def test_pull_mode_is_the_default_and_needs_resident_vectors(libbang, small_u8):
+    """"auto" takes the pull mode whenever the vectors are resident in HBM and the rows fit the host memory; asked for explicitly
+    without resident vectors it is an error, not a silent change of mode."""
+    import bang_amd
+    ix, q, _, _ = small_u8
+    ids0, _, st0 = _run_engine(ix, q, 10, 40, graph=0)
+    assert st0["graph_pull"] == 1 and st0["vectors_on_device"] == 1
+    ids1, _, st1 = _run_engine(ix, q, 10, 40, graph=0, vectors=0)            # vectors shipped by the walker: no pull
+    assert st1["graph_pull"] == 0 and np.array_equal(ids0, ids1)
+    with bang_amd.Engine(ix.dtype, graph=0, pull=1, vectors=0) as e:
+        with pytest.raises(bang_amd.BangError, match="pull"):
+            e.load_index(ix)
+    with bang_amd.Engine(ix.dtype, graph=0) as e:
+        e.load_index(ix)
+        with pytest.raises(bang_amd.BangError, match="before bang_load"):
+            e.set_option("pull", 0)
+
+
+@pytest.mark.gpu
+def test_pull_rows_file_is_shared_and_validated(libbang, small_u8, small_i8, tmp_path, monkeypatch):
+    """BANG_PULL_ROWS_DIR: the rows live in ONE file per node -- built by the first engine that loads the index, mapped by the
+    next ones (here: two engines of one process); a file that belongs to another index is rebuilt, not trusted."""
+    import os
+    import bang_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BANG_PULL_ROWS_DIR", str(tmp_path))
+    ix, q, _, _ = small_u8
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 40)
+    path = tmp_path / "index_pull_rows.bin"
+
+    def run(index, queries):
+        with bang_amd.Engine(index.dtype, graph=0, pull=1) as e:
+            e.load_index(index)
+            e.set_searchparams(10, 40)
+            e.alloc(queries.shape[0])
+            e.init(queries.shape[0])
+            out = e.query(queries)
+            assert e.stats()["graph_pull"] == 1
+            return out
+    ids, dists = run(ix, q)
+    assert path.exists() and path.stat().st_size == ix.N * 256 + 4096
+    rows = np.fromfile(path, np.uint32, ix.N * 64).reshape(ix.N, 64)
+    deg, adj = ix.degrees(), ix.adjacency()
+    for i in (0, ix.N // 2, ix.N - 1):
+        assert np.array_equal(rows[i, :deg[i]], adj[i][:deg[i]]) and (rows[i, deg[i]:] == 0xFFFFFFFF).all()
+    assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    ino = path.stat().st_ino
+    ids2, _ = run(ix, q)                                                       # second engine: maps the existing file
+    assert path.stat().st_ino == ino and np.array_equal(ids2, ids_o)
+    # same name and size, other content: must be rebuilt
+    blob = bytearray(path.read_bytes())
+    blob[: ix.N * 256] = b"\x00" * (ix.N * 256)
+    blob[ix.N * 256 + 2048 + 33] ^= 0xFF                                       # break the sample hash of the signature
+    path.write_bytes(bytes(blob))
+    ids3, _ = run(ix, q)
+    assert np.array_equal(ids3, ids_o) and path.stat().st_ino != ino
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]

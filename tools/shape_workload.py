@@ -67,7 +67,10 @@ def usable_host_bytes() -> int:
     return avail
 
 
-def plan_n(name, dev, n_override=0):
+PULL_ROW_BYTES = 256       # host-graph placement, pull mode: the engine keeps the adjacency lists a second time as 256-byte rows
+
+
+def plan_n(name, dev, n_override=0, reserve_rows=True):
     """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything."""
     import torch
     sh = SHAPES[name]
@@ -75,7 +78,7 @@ def plan_n(name, dev, n_override=0):
     entry = sh["D"] * isz + 4 + 4 * sh["R"]
     N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
     if sh["graph"] == "host":
-        N = min(N, int(usable_host_bytes() * 0.75) // entry)
+        N = min(N, int(usable_host_bytes() * 0.75) // (entry + (PULL_ROW_BYTES if reserve_rows else 0)))
     else:
         free, _ = torch.cuda.mem_get_info(dev)
         N = min(N, (int(free * 0.85) - (8 << 30)) // (entry + sh["m"]), int(usable_host_bytes() * 0.75) // entry)
@@ -93,7 +96,7 @@ class ShapeIndex:
         return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
 
 
-def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None):
+def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None, reserve_rows=True):
     """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
     can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent.
     shared=(path, is_creator, barrier): the graph image lives in ONE mapping of the file `path` shared by every rank of the node
@@ -112,9 +115,11 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         pass                                   # N was planned once for the node (plan_n on the creator) and handed to every rank
     elif sh["graph"] == "host":
         budget = int(usable_host_bytes() * 0.75)
-        if N * entry > budget:
-            N2 = budget // entry
-            note = f" (N scaled {N} -> {N2}: host memory budget {budget / 2**30:.0f} GiB)"
+        per_node = entry + (PULL_ROW_BYTES if reserve_rows else 0)
+        if N * per_node > budget:
+            N2 = budget // per_node
+            note = (f" (N scaled {N} -> {N2}: host memory budget {budget / 2**30:.0f} GiB for {entry}-byte graph entries"
+                    + (f" + {PULL_ROW_BYTES}-byte pull rows" if reserve_rows else "") + ")")
             N = N2
     else:
         free, _total = torch.cuda.mem_get_info(dev)
