@@ -1838,7 +1838,7 @@ static int alloc_buffers(bang_engine* e, int Q) {
   nl = std::min(nl, Q);
   if (e->search_v2 || e->search_host) nl = 1;            // the search kernel's waves are the unit of overlap, not lanes
   if (e->search_host && e->threads_opt <= 0) e->threads_eff = std::max(1, std::min(12, usable_cpus() - 2));
-  else if (e->threads_opt <= 0) e->threads_eff = dev_graph ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
+  else if (e->threads_opt <= 0) e->threads_eff = (dev_graph || e->search_v2) ? 1 : std::max(1, std::min(4, (usable_cpus() - 2) / std::max(1, nl)));   // leave 2 CPUs for the caller + HIP runtime threads: a cgroup that exceeds its quota gets throttled for the rest of the period
   else e->threads_eff = e->threads_opt;
   if (!dev_graph) {
     const size_t n_flags = std::max<size_t>((size_t)nl, e->search_host ? 8 * KT_WGS : 0);
@@ -2010,7 +2010,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   s.vectors_on_device = e->vec_on_device ? 1 : 0;
   s.graph_mode = (uint64_t)e->graph_mode;
   s.lanes = (uint64_t)nl;
-  s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE) ? 0 : (uint64_t)e->threads_eff;
+  s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE || e->search_v2) ? 0 : (uint64_t)e->threads_eff;   // (pull mode: nothing walks)
   s.wg_queries = e->search_host ? e->sv_W * e->sv_C : 0;
   s.pacing_groups = e->search_host ? e->sv_NG : 0;
   s.graph_pull = (e->pull && e->search_v2 && e->graph_mode != BANG_GRAPH_DEVICE) ? 1 : 0;

@@ -633,6 +633,15 @@ def main():
                 props = check_properties(w2["ix"], q2, r4["ids"], r4["dists"], k)
                 cfg[f"at_{name}"] = leg_summary(r4, w2, w2["graph"], props=props)
                 e3.free(); e3.unload(); e3.close()
+                if w2["graph"] == "host" and r4["agg"].get("graph_pull"):
+                    # the north-star data flow on its own configuration: the same index served by the C++ walker threads
+                    e3 = make_engine(w2, "host", ctx, timing=0 if args.no_events else 1, pull=0)
+                    e3.set_searchparams(k, 152)
+                    e3.alloc(q2.shape[0])
+                    r4w = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, "host")
+                    cfg[f"at_{name}_walker"] = leg_summary(r4w, w2, "host", props=check_properties(w2["ix"], q2, r4w["ids"], r4w["dists"], k),
+                                                           extra={"ids_equal_pull_run": bool(np.array_equal(r4w["ids"], r4["ids"]))})
+                    e3.free(); e3.unload(); e3.close()
                 k2[f"m{w2['ix'].m}"] = k2_alone(w2["ix"].D, w2["ix"].m, w2["ix"].dtype, ctx)
                 w2["release"]()
                 del w2, q2, e3

@@ -33,7 +33,11 @@ def _search(ix, q, graph, L=70, **opts):
 def test_full_size_properties_and_sample_parity(libbang, sift1m_like):
     from oracle import oracle as O
     ix, q, gt_i, gt_d = sift1m_like
-    ids_h, dists_h, st_h = _search(ix, q, 0)
+    ids_h, dists_h, st_h = _search(ix, q, 0, pull=0)                      # host graph served by the C++ walker threads
+    ids_p, dists_p, st_p = _search(ix, q, 0)                              # host graph, default: the kernel pulls the rows over PCIe
+    assert st_h["graph_pull"] == 0 and st_p["graph_pull"] == 1 and st_p["pulled_bytes"] == 256 * (st_p["candidates"] - 10_000)
+    assert np.array_equal(ids_h, ids_p) and np.array_equal(dists_h.view(np.uint32), dists_p.view(np.uint32))
+    assert st_h["dist_evals"] == st_p["dist_evals"] and st_h["fetched"] == st_p["fetched"]
     ids_d, dists_d, st_d = _search(ix, q, 1)
     ids_l, dists_l, st_l = _search(ix, q, 0, persistent=0, vectors=0)   # host graph, a launch per iteration and lane, vectors shipped by the walker
     ids_v, dists_v, st_v = _search(ix, q, 0, vectors=0)                 # persistent kernel, vectors shipped by the walker

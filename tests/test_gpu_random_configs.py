@@ -19,7 +19,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}-D{c[1]}-{c[2]}-R{c[3]}-m{c[4]}-Q{c[5]}-k{c[6]}-L{c[7]}" for c in CASES])
-@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("graph", [0, 1, "walker"])      # 0: host placement (pull mode where the layout allows), "walker": host, pull = 0
 def test_random_config_matches_oracle(libbang, case, graph):
     import bang_amd
     from bang_amd import synth
@@ -27,7 +27,8 @@ def test_random_config_matches_oracle(libbang, case, graph):
     N, D, dtype, R, m, Q, k, L = case
     ix, q, _, _ = synth.make_index(N, D, dtype, R, m, Q, K=min(10, k), n_clusters=8, seed=1000 + N + D, pq_iters=2)
     ids_o, dists_o, st_o = O.Oracle(ix).search(q, k, L, with_stats=True)
-    with bang_amd.Engine(dtype, graph=graph) as e:
+    opts = dict(graph=0, pull=0) if graph == "walker" else dict(graph=graph)
+    with bang_amd.Engine(dtype, **opts) as e:
         e.load_index(ix)
         e.set_searchparams(k, L)
         e.alloc(Q)

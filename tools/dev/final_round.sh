@@ -10,19 +10,23 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 echo "bench rc=$?"; tail -2 gpurun_out/bench_default.err
 timeout 700 bash tools/profile2.sh r02_sift1m_device sift1m_device --graph device
 timeout 700 bash tools/profile2.sh r02_sift1m_host sift1m_host --graph host
+PROFILE_PASSES="trace fetch write ea" timeout 500 bash tools/profile2.sh r02_sift1m_host_walker sift1m_host_walker --graph host --pull 0
 PROFILE_PASSES="trace fetch write" timeout 600 bash tools/profile2.sh r02_deep100m_shape_device deep100m_shape_device --workload deep100m_shape
 PROFILE_PASSES="trace fetch write" timeout 900 bash tools/profile2.sh r02_sift1b_shape_host sift1b_shape_host --workload sift1b_shape
+PROFILE_PASSES="trace" timeout 600 bash tools/profile2.sh r02_sift1b_shape_host_walker sift1b_shape_host_walker --workload sift1b_shape --pull 0
 timeout 400 bash tools/profile_k2.sh r02 > /dev/null
 {
 echo "# What one rank's shard of the 10 K-query batch costs on a GPU of its own"
 echo
 echo "Single-process \`bench.py --queries Q --L 70 --no-legs\` runs (SIFT1M-like index, 6 timed steps each): Q = 10 000 / W queries = the shard of"
-echo "rank r of W.  No multi-GPU box was available; this is the projection DESIGN.md section 7 quotes."
+echo "rank r of W (host = host graph, rows pulled by the kernel; walker = host graph served by the C++ walker threads)."
+echo "No multi-GPU box was available; this is the projection DESIGN.md section 7 quotes."
 echo
 echo "| graph | queries | QPS | ms per batch | search launch us |"
 echo "|---|---|---|---|---|"
-for g in device host; do for q in 10000 5000 2500 1250; do
-  timeout 300 python bench.py --graph $g --queries $q --L 70 --no-legs --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/shard_${g}_$q.json 2> gpurun_out/shard_${g}_$q.err
+for g in device host walker; do for q in 10000 5000 2500 1250; do
+  ga="--graph $g"; [ $g = walker ] && ga="--graph host --pull 0"
+  timeout 300 python bench.py $ga --queries $q --L 70 --no-legs --no-cpu-baseline --steps 6 --warmup 2 > gpurun_out/shard_${g}_$q.json 2> gpurun_out/shard_${g}_$q.err
   python - <<PY
 import json
 try:
