@@ -38,10 +38,19 @@ def _bench(nproc, extra, timeout=380):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("graph", ["host", "device"])
+@pytest.mark.parametrize("graph", ["host", "host-walker", "device"])
 def test_two_ranks_one_gpu_one_host_graph(libbang, graph):
-    one = _bench(1, ["--graph", graph])
-    two = _bench(2, ["--graph", graph])
+    """host: the default of the host placement -- both ranks pull adjacency rows from ONE rows file in the shared directory (rank 0
+    builds it, rank 1 maps it: BANG_PULL_ROWS_DIR); host-walker: both ranks' walker threads read ONE mapped graph file."""
+    walker = graph == "host-walker"
+    graph = "host" if walker else graph
+    extra = ["--graph", graph] + (["--pull", "0"] if walker else [])
+    one = _bench(1, extra)
+    two = _bench(2, extra)
+    if graph == "host":
+        for r in (one, two):
+            assert ("pulled" in r["config"]["host_loop"]) == (not walker), r["config"]["host_loop"]
+            assert (r["config"]["pcie_pulled_bytes_per_step"] > 0) == (not walker)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["config"]["parity_vs_oracle_first_64"] is True and two["config"]["parity_vs_oracle_first_64"] is True
     assert two["config"]["graph"] == graph and two["config"]["L"] == 46
