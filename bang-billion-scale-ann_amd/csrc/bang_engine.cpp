@@ -594,6 +594,10 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       return BANG_ERR_ARG;
     }
   }
+  if (e->pull && e->graph_map)
+    // nothing reads the mapped graph file while the kernel pulls its rows: let the page cache have the pages back (a later
+    // change of the loop form -- "persistent" = 0 -- simply faults them in again)
+    (void)madvise(e->graph_map, e->graph_map_len, MADV_DONTNEED);
   if (e->graph_mode == BANG_GRAPH_DEVICE) {
     const size_t gbytes = (size_t)e->N * e->entry_len;
     HIP_TRY(hipMalloc((void**)&e->d_graph, gbytes + 256));
