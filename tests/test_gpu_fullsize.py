@@ -1,6 +1,7 @@
-"""BASELINE.json configs[1] at FULL size on the GPU (N = 1 M, uint8, D = 128, R = 64, m = 32, Q = 10 000): too big for
-the oracle to cross-check every query in seconds, so the whole batch is checked through size-independent properties
-and a 128-query sample against the oracle.  The index is built on the GPU with torch (plumbing only)."""
+"""BASELINE.json configs[1] at FULL size on the GPU (N = 1 M, uint8, D = 128, R = 64, m = 32, Q = 10 000): the whole batch
+through size-independent properties, across every graph form, and -- the oracle's OpenMP loop answers 10 000 queries in about a
+second on the GPU box's cores -- every query bit for bit against the oracle.  The index is built on the GPU with torch
+(plumbing only)."""
 import numpy as np
 import pytest
 
@@ -64,3 +65,27 @@ def test_full_size_properties_and_sample_parity(libbang, sift1m_like):
     assert np.array_equal(dists_h[:, sel].view(np.uint32), dists_o.view(np.uint32))
     # 4. iteration accounting: nobody exceeds the cap (bang_search.cu:950), and the worklist length bounds the candidates
     assert st_h["iterations"] <= 70 + 49 and st_h["candidates"] <= 10_000 * (70 + 50)
+
+
+@pytest.mark.parametrize("L", [37, 152])
+def test_full_size_every_query_matches_oracle(libbang, sift1m_like, L):
+    """All 10 000 queries of the full-size batch, bit for bit against the oracle (ids, distances, per-query counters), with the
+    graph in HBM and in host RAM (rows pulled by the kernel): 4 096 waves handing out queries dynamically, worklists that fill
+    early (L = 37: more entering survivors than slots in the first iterations) and late (L = 152)."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = sift1m_like
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    for opts in (dict(graph=1), dict(graph=0, pull=1)):
+        with bang_amd.Engine(ix.dtype, **opts) as e:
+            e.load_index(ix)
+            e.set_searchparams(10, L)
+            e.alloc(q.shape[0])
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            cnt = e.query_counters(q.shape[0])
+            e.free()
+            e.unload()
+        assert np.array_equal(ids, ids_o), opts
+        assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), opts
+        assert np.array_equal(cnt, st_o), opts
