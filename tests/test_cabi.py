@@ -129,3 +129,39 @@ def test_bad_arguments_are_rejected(libbang):
         e.alloc(100)                         # nothing loaded
     with pytest.raises(bang_amd.BangError):
         e.set_option("nonsense", 1)
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """The ctypes structures of bang_amd.binding are hand-written mirrors of include/bang_c.h: a C program compiled against the
+    header prints sizeof and the offset of every field; size, field order and every offset must agree."""
+    import re
+    import shutil
+    import subprocess
+    from bang_amd import binding as B
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler")
+    pairs = {"bang_iter_params": B.IterParams, "bang_search_params": B.SearchParams, "bang_index_desc": B.IndexDesc,
+             "bang_stats": B.Stats}
+    hdr = open(os.path.join(ROOT, "include", "bang_c.h")).read()
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "bang_c.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct \{(.*?)\}\s*" + cname + r"\s*;", hdr, re.S)
+        assert body, cname
+        src.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            assert re.search(r"\b" + re.escape(f) + r"\b", body.group(1)), f"{cname}.{f} is not in the header"
+            src.append(f'  printf("{cname} {f} %zu\\n", offsetof({cname}, {f}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    got = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        s, f, v = line.split()
+        got[(s, f)] = int(v)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert got[(cname, f)] == getattr(cls, f).offset, f"{cname}.{f}"
