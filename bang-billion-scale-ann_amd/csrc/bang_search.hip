@@ -37,7 +37,7 @@
 struct SearchArgs {
   bang_search_params p;
   uint32_t lds_piv_floats;
-  uint32_t wave_words;       // LDS words per wave: nctx worklists + 144 scratch + 32 parked context state
+  uint32_t wave_words;       // LDS words per wave: nctx worklists + 144 scratch (+ 32 parked context state when nctx == 2)
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
@@ -46,7 +46,9 @@ struct SearchArgs {
 #define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
-__host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx) { return nctx * search_wl_words(L) + SRCH_SCRATCH_WORDS + 32u; }
+__host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx) {
+  return nctx * search_wl_words(L) + SRCH_SCRATCH_WORDS + (nctx == 2 ? 32u : 0u);
+}
 
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   const uint32_t nwaves = blockDim.x >> 6;
   const uint32_t nctx = HOST ? a.nctx : 1u;
   const uint32_t L = p.L, medoid = p.medoid, cap_iter = p.cap_iter;
-  // a wave's LDS region: [worklist of context 0][worklist of context 1][scratch 144][parked context state 2 x 16]
+  // a wave's LDS region: [worklist of context 0]([worklist of context 1])[scratch 144]([parked context state 2 x 16]: nctx == 2 only)
   uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
   uint32_t* scratch = wbase + (size_t)nctx * a.wl_words;
   uint32_t* park = scratch + SRCH_SCRATCH_WORDS;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   // [120..121] the group's barrier
   uint32_t* wg_lds = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words + (size_t)grp_in_wg * 128;
   if (HOST && gslot == 0) { wg_lds[lane] = 0u; wg_lds[64 + lane] = 0u; }
-  if (HOST && lane < (int)(2 * SRCH_CTX_WORDS)) park[lane] = 0u;        // both contexts: inactive
+  if (HOST && nctx == 2 && lane < (int)(2 * SRCH_CTX_WORDS)) park[lane] = 0u;        // both contexts: inactive
   __syncthreads();
   if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
@@ -929,11 +931,12 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
 #define SRCH_WG_SHARED_BYTES 2048u     // group-shared LDS behind the waves' regions (host-paced form): 128 words per pacing group, up to 4 groups
 #define SRCH_DEFAULT_GROUP_WAVES 8u
 
-// waves per workgroup that fit beside the pivot table with nctx query contexts each (0: not even one)
-static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx) {
+// waves per workgroup that fit beside the pivot table with nctx query contexts each (0: not even one); the host-paced form also
+// keeps its pacing groups' shared words there
+static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx, bool host_paced) {
   const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
   const size_t per_wave = (size_t)search_wave_words(L, nctx) * 4u;
-  const size_t cap = (size_t)160 * 1024 - SRCH_WG_SHARED_BYTES;
+  const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u);
   if (piv_bytes + per_wave > cap) return 0;
   const size_t w = (cap - piv_bytes) / per_wave;
   return (uint32_t)(w > 16 ? 16 : w);
@@ -941,7 +944,7 @@ static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t
 
 extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
   if (psz == 0 || L == 0 || L > BANG_MAX_L) return 0;
-  return (int)waves_that_fit(psz, mp, nhi, L, 1);
+  return (int)waves_that_fit(psz, mp, nhi, L, 1, false);            // (the self-paced form; the host-paced one may hold one wave less)
 }
 
 // One workgroup per CU at most (the pivot table takes most of the LDS).  A batch smaller than CUs x waves is spread over all
@@ -956,7 +959,7 @@ extern "C" int bang_search_geometry(uint32_t psz, uint32_t mp, uint32_t nhi, uin
   if (!host_paced) nctx = 1;
   else if (nctx == 0) nctx = 1;     // two contexts per wave measured slower (more, emptier half-rounds): kept as an experiment knob
   else if (nctx > 2) nctx = 2;
-  uint32_t waves = waves_that_fit(psz, mp, nhi, L, nctx);
+  uint32_t waves = waves_that_fit(psz, mp, nhi, L, nctx, host_paced != 0);
   if (waves == 0) { bang_set_error("pivot table + one wave's worklist do not fit LDS at L=%u", L); return BANG_ERR_UNSUPPORTED; }
   if (max_waves && max_waves < waves) waves = max_waves;
   const uint32_t cus = (uint32_t)num_cus();
@@ -998,7 +1001,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   a.gs = gs;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx);
-  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + SRCH_WG_SHARED_BYTES;
+  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + p->mp / 4u;
