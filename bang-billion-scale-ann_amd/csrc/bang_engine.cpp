@@ -447,7 +447,7 @@ static int build_pull_rows(bang_engine* e) {
     if (!tmp.empty() && rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());   // (the mapping stays valid either way)
   }
   (void)fill;
-  if (hipHostRegister(m, bytes, hipHostRegisterMapped) != hipSuccess) {
+  if (hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
     (void)munmap(m, bytes);
     bang_set_error("pull rows: hipHostRegister of %.1f GB failed", bytes / 1e9);
