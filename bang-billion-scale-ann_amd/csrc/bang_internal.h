@@ -34,7 +34,7 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
 // word, which ends the kernel at once); a workgroup only gives up on its own -- the host process is gone -- well after that.
 #define BANG_HOST_WALK_TIMEOUT_MS 20000.0
 #define BANG_KERNEL_GO_TIMEOUT_TICKS 3000000000ull   /* 30 s of the 100 MHz s_memrealtime clock */
-#define BANG_RESULT_MAILBOX_BYTES (512 * 1024)   // results (ids + distances) up to this size return through the pinned mirror in one copy
+#define BANG_RESULT_MAILBOX_BYTES (8 * 1024 * 1024)   // results (ids + distances) up to this size return through the pinned mirror in one copy (BANG_MAILBOX_BYTES)
 
 int bang_num_cus(void);
 // 1 if the fused kernel has an instance for the exact-size ("ragged") pivot table of this layout
