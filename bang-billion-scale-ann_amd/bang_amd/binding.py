@@ -76,6 +76,9 @@ class Stats(C.Structure):
                 ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64)]
 
 
+ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source
+
+
 def lib_path() -> str:
     return _LIB
 
@@ -197,6 +200,24 @@ class Engine:
         d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, _vp(graph).value, _vp(codes).value,
                       d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value)
         _check(lib().bang_load_mem_e(self._h, C.byref(d)), "bang_load_mem")
+
+    def load_stream(self, ix, source, ctx=None, d_codes: int | None = None):
+        """Streamed load (bang_load_stream_e): `source` is a C function pointer -- or a Python callable
+        (first, count, dst_address) -> 0 -- that writes `count` graph entries in the reference layout for the nodes from `first`;
+        ix supplies everything but the graph (medoid, entry_len, D, R, N, m, codes, pivots, centroid, chunk_off)."""
+        codes = None if ix.codes is None else np.ascontiguousarray(ix.codes, dtype=np.uint8)
+        pivots = np.ascontiguousarray(ix.pivots, dtype=np.float32)
+        centroid = np.ascontiguousarray(ix.centroid, dtype=np.float32)
+        chunk_off = np.ascontiguousarray(ix.chunk_off, dtype=np.uint32)
+        if not isinstance(source, (ENTRY_SOURCE, C._CFuncPtr)):
+            py = source
+            source = ENTRY_SOURCE(lambda _ctx, first, count, dst: int(py(first, count, dst)))
+        self._keep = [codes, pivots, centroid, chunk_off, source]
+        d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, None, None if codes is None else _vp(codes).value,
+                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value)
+        fn = lib().bang_load_stream_e
+        fn.argtypes = [C.c_void_p, C.POINTER(IndexDesc), C.c_void_p, C.c_void_p]
+        _check(fn(self._h, C.byref(d), C.cast(source, C.c_void_p), ctx), "bang_load_stream")
 
     def set_searchparams(self, recall: int, worklist_length: int, distfn: int = DIST_L2):
         _check(lib().bang_set_searchparams_e(self._h, recall, worklist_length, distfn), "bang_set_searchparams")

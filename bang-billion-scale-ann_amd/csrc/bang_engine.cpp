@@ -284,6 +284,11 @@ struct bang_engine {
   uint32_t* h_adj = nullptr;           // [N][64]
   size_t adj_bytes = 0;
   std::string rows_key;                // names the shared rows file (BANG_PULL_ROWS_DIR): basename of the index prefix
+  // STREAMED load: the graph entries pass through in chunks (vectors -> HBM, adjacency -> pull rows) and are not kept
+  bang_entry_source entry_fn = nullptr;   // set for the duration of a streamed load
+  void* entry_ctx = nullptr;
+  std::string graph_path;              // file loads: `<p>_disk.bin`, mapped only if a walker form ever needs the entries
+  bool graph_streamed = false;         // loaded without a resident graph (graph == nullptr): only the pull mode can run as is
   const uint32_t* d_adj = nullptr;     // device address of h_adj
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
@@ -358,111 +363,288 @@ static size_t host_bytes_available() {
 // <dir>/<index name>_pull_rows.bin, built by whichever rank loads first (write to a temporary name, rename) and mapped shared by
 // the others; every rank registers the mapping with its own device.  Without the variable: private anonymous memory.
 struct PullRowsSig { char magic[8]; uint64_t N, medoid, R, sample_hash; };
-// what a rows file must match: sizes, medoid and the adjacency lists of 64 nodes spread over the index
-static PullRowsSig pull_rows_signature(const bang_engine* e) {
+// what a rows file must match: sizes, medoid and the adjacency lists of 64 nodes spread over the index (folded in node order)
+static inline size_t sig_sample_node(const bang_engine* e, uint32_t t) { return (size_t)((unsigned __int128)e->N * t / 64); }
+static inline void sig_fold(const bang_engine* e, uint64_t& h, const uint8_t* adj /* [u32 degree][u32 id x R] */) {
+  uint32_t deg;
+  memcpy(&deg, adj, 4);
+  if (deg > e->R) deg = e->R;
+  for (size_t b = 0; b < 4 + (size_t)deg * 4; ++b) h = (h ^ adj[b]) * 0x100000001b3ull;
+}
+static PullRowsSig sig_make(const bang_engine* e, uint64_t h) {
   PullRowsSig g;
   memcpy(g.magic, "BANGROWS", 8);
-  g.N = e->N; g.medoid = e->medoid; g.R = e->R;
-  uint64_t h = 0xcbf29ce484222325ull;
-  const size_t vb = vec_bytes(e);
-  for (uint32_t t = 0; t < 64; ++t) {
-    const size_t i = (size_t)((unsigned __int128)e->N * t / 64);
-    const uint8_t* ent = e->graph + i * e->entry_len + vb;
-    uint32_t deg;
-    memcpy(&deg, ent, 4);
-    if (deg > e->R) deg = e->R;
-    for (size_t b = 0; b < 4 + (size_t)deg * 4; ++b) h = (h ^ ent[b]) * 0x100000001b3ull;
-  }
-  g.sample_hash = h;
+  g.N = e->N; g.medoid = e->medoid; g.R = e->R; g.sample_hash = h;
   return g;
 }
+static const uint64_t kSigSeed = 0xcbf29ce484222325ull;
 
-static int build_pull_rows(bang_engine* e) {
-  const size_t bytes = (size_t)e->N * 256 + 4096;
-  const size_t sig_off = (size_t)e->N * 256 + 2048;
-  const PullRowsSig sig = pull_rows_signature(e);
-  std::string path;
-  if (const char* dir = getenv("BANG_PULL_ROWS_DIR"))
-    if (*dir) path = std::string(dir) + "/" + (e->rows_key.empty() ? std::string("index") : e->rows_key) + "_pull_rows.bin";
+// one node's adjacency list as a pull row: 64 slots, ids first (ascending), the rest padded
+static inline void pull_row_from_entry(const bang_engine* e, uint32_t* row, const uint8_t* adj) {
+  uint32_t deg;
+  memcpy(&deg, adj, 4);
+  if (deg > e->R) deg = e->R;
+  memcpy(row, adj + 4, (size_t)deg * 4);
+  for (uint32_t k = deg; k < 64; ++k) row[k] = 0xFFFFFFFFu;
+}
+
+// Pull mode: the adjacency lists of the host graph, re-laid as 256-byte rows the GPU can fetch with one PCIe read each.
+// One copy per NODE when BANG_PULL_ROWS_DIR names a directory every rank can see (tmpfs): the rows live in the file
+// <dir>/<index name>_pull_rows.bin, built by whichever rank loads first (write to a temporary name, rename) and mapped shared by
+// the others; every rank registers the mapping with its own device.  Without the variable: private anonymous memory.
+struct PullRows {
   void* m = MAP_FAILED;
-  bool fill = true;
-  if (!path.empty()) {
-    int fd = open(path.c_str(), O_RDWR);
+  size_t bytes = 0, sig_off = 0;
+  bool fill = true;                    // false: an existing rows file was mapped (its signature is checked in pull_rows_finish)
+  std::string path, tmp;
+};
+static void pull_rows_abandon(PullRows& pr) {
+  if (pr.m != MAP_FAILED) (void)munmap(pr.m, pr.bytes);
+  pr.m = MAP_FAILED;
+  if (!pr.tmp.empty()) (void)unlink(pr.tmp.c_str());
+  pr.tmp.clear();
+}
+// expect: the signature the file must carry if it exists already (NULL: unknown yet -- a streamed load checks at the end)
+static int pull_rows_open(bang_engine* e, PullRows& pr, const PullRowsSig* expect) {
+  pr.bytes = (size_t)e->N * 256 + 4096;
+  pr.sig_off = (size_t)e->N * 256 + 2048;
+  if (const char* dir = getenv("BANG_PULL_ROWS_DIR"))
+    if (*dir) pr.path = std::string(dir) + "/" + (e->rows_key.empty() ? std::string("index") : e->rows_key) + "_pull_rows.bin";
+  if (!pr.path.empty()) {
+    const int fd = open(pr.path.c_str(), O_RDWR);
     if (fd >= 0) {                                 // built by another rank of this node (or an earlier run on the same index)
       struct stat st;
-      if (fstat(fd, &st) == 0 && (size_t)st.st_size == bytes) {
-        m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m != MAP_FAILED && memcmp((const uint8_t*)m + sig_off, &sig, sizeof(sig)) != 0) {   // another index: rebuild
-          (void)munmap(m, bytes);
-          m = MAP_FAILED;
+      if (fstat(fd, &st) == 0 && (size_t)st.st_size == pr.bytes) {
+        pr.m = mmap(nullptr, pr.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (pr.m != MAP_FAILED && expect && memcmp((const uint8_t*)pr.m + pr.sig_off, expect, sizeof(*expect)) != 0) {
+          (void)munmap(pr.m, pr.bytes);           // another index: rebuild
+          pr.m = MAP_FAILED;
         }
-        fill = (m == MAP_FAILED);
       }
       close(fd);
     }
   }
-  if (m == MAP_FAILED) {
-    const size_t avail = host_bytes_available();
-    if (bytes + ((size_t)8 << 30) > avail) {       // never push the host into the OOM killer for an optimisation
-      bang_set_error("pull rows: %.1f GB do not fit the %.1f GB of host memory left", bytes / 1e9, avail / 1e9);
-      return BANG_ERR_NOMEM;
-    }
-    fill = true;
-    std::string tmp;
-    if (!path.empty()) {
-      tmp = path + ".tmp." + std::to_string((long)getpid());
-      const int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
-      if (fd >= 0) {
-        if (ftruncate(fd, (off_t)bytes) == 0) m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (m == MAP_FAILED) { (void)unlink(tmp.c_str()); tmp.clear(); }
-      } else tmp.clear();
-    }
-    if (m == MAP_FAILED) {
-      m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-      if (m == MAP_FAILED) { bang_set_error("pull rows: cannot map %.1f GB of host memory", bytes / 1e9); return BANG_ERR_NOMEM; }
-      (void)madvise(m, bytes, MADV_HUGEPAGE);
-      tmp.clear();
-    }
-    uint32_t* rows = (uint32_t*)m;
-    const size_t vb = vec_bytes(e);
+  pr.fill = (pr.m == MAP_FAILED);
+  if (!pr.fill) return BANG_OK;
+  const size_t avail = host_bytes_available();
+  if (pr.bytes + ((size_t)8 << 30) > avail) {      // never push the host into the OOM killer for an optimisation
+    bang_set_error("pull rows: %.1f GB do not fit the %.1f GB of host memory left", pr.bytes / 1e9, avail / 1e9);
+    return BANG_ERR_NOMEM;
+  }
+  if (!pr.path.empty()) {
+    pr.tmp = pr.path + ".tmp." + std::to_string((long)getpid());
+    const int fd = open(pr.tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd >= 0) {
+      if (ftruncate(fd, (off_t)pr.bytes) == 0) pr.m = mmap(nullptr, pr.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (pr.m == MAP_FAILED) { (void)unlink(pr.tmp.c_str()); pr.tmp.clear(); }
+    } else pr.tmp.clear();
+  }
+  if (pr.m == MAP_FAILED) {
+    pr.m = mmap(nullptr, pr.bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (pr.m == MAP_FAILED) { bang_set_error("pull rows: cannot map %.1f GB of host memory", pr.bytes / 1e9); return BANG_ERR_NOMEM; }
+    (void)madvise(pr.m, pr.bytes, MADV_HUGEPAGE);
+    pr.tmp.clear();
+  }
+  return BANG_OK;
+}
+// the rows are complete: signature written (built here) or checked (mapped), file published, mapping registered with the device
+static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig) {
+  if (pr.fill) {
+    memset((uint8_t*)pr.m + (size_t)e->N * 256, 0xFF, 4096);
+    memcpy((uint8_t*)pr.m + pr.sig_off, &sig, sizeof(sig));
+    if (!pr.tmp.empty() && rename(pr.tmp.c_str(), pr.path.c_str()) != 0) (void)unlink(pr.tmp.c_str());   // (the mapping stays valid either way)
+    pr.tmp.clear();
+  } else if (memcmp((const uint8_t*)pr.m + pr.sig_off, &sig, sizeof(sig)) != 0) {
+    pull_rows_abandon(pr);
+    bang_set_error("pull rows: %s belongs to another index (delete it)", pr.path.c_str());
+    return BANG_ERR_IO;
+  }
+  if (hipHostRegister(pr.m, pr.bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    pull_rows_abandon(pr);
+    bang_set_error("pull rows: hipHostRegister of %.1f GB failed", pr.bytes / 1e9);
+    return BANG_ERR_HIP;
+  }
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, pr.m, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(pr.m);
+    pull_rows_abandon(pr);
+    bang_set_error("pull rows: no device address for the registered rows");
+    return BANG_ERR_HIP;
+  }
+  e->h_adj = (uint32_t*)pr.m; e->adj_bytes = pr.bytes; e->d_adj = (const uint32_t*)dp; e->pull = true;
+  pr.m = MAP_FAILED;
+  return BANG_OK;
+}
+
+// rows from a graph that is resident in host memory
+static int build_pull_rows(bang_engine* e) {
+  const size_t vb = vec_bytes(e);
+  uint64_t h = kSigSeed;
+  for (uint32_t t = 0; t < 64; ++t) sig_fold(e, h, e->graph + sig_sample_node(e, t) * e->entry_len + vb);
+  const PullRowsSig sig = sig_make(e, h);
+  PullRows pr;
+  BANG_TRY(pull_rows_open(e, pr, &sig));
+  if (pr.fill) {
+    uint32_t* rows = (uint32_t*)pr.m;
     const int T = std::max(1, std::min(16, usable_cpus()));
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
       th.emplace_back([=]() {
         const size_t a = (size_t)e->N * t / T, b = (size_t)e->N * (t + 1) / T;
-        for (size_t i = a; i < b; ++i) {
-          const uint8_t* ent = e->graph + i * e->entry_len + vb;
-          uint32_t deg;
-          memcpy(&deg, ent, 4);
-          if (deg > e->R) deg = e->R;
-          uint32_t* r = rows + i * 64;
-          memcpy(r, ent + 4, (size_t)deg * 4);
-          for (uint32_t k = deg; k < 64; ++k) r[k] = 0xFFFFFFFFu;
-        }
+        for (size_t i = a; i < b; ++i) pull_row_from_entry(e, rows + i * 64, e->graph + i * e->entry_len + vb);
       });
     for (auto& x : th) x.join();
-    memset((uint8_t*)m + (size_t)e->N * 256, 0xFF, 4096);
-    memcpy((uint8_t*)m + sig_off, &sig, sizeof(sig));
-    if (!tmp.empty() && rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());   // (the mapping stays valid either way)
   }
-  (void)fill;
-  if (hipHostRegister(m, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)munmap(m, bytes);
-    bang_set_error("pull rows: hipHostRegister of %.1f GB failed", bytes / 1e9);
-    return BANG_ERR_HIP;
+  return pull_rows_finish(e, pr, sig);
+}
+
+// seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501), from the medoid's graph entry
+static int stage_medoid(bang_engine* e, const uint8_t* me) {
+  uint32_t deg;
+  memcpy(&deg, me + vec_bytes(e), 4);
+  if (deg > e->R) deg = e->R;
+  for (uint32_t i = 0; i < deg; ++i) {                 // cheap spot check of the adjacency layout: the medoid's neighbours
+    uint32_t nb;
+    memcpy(&nb, me + vec_bytes(e) + 4 + 4 * (size_t)i, 4);
+    if (nb >= e->N) { bang_set_error("medoid neighbour %u = %u is out of range (N = %u): wrong data type or corrupt index", i, nb, e->N); return BANG_ERR_IO; }
   }
-  void* dp = nullptr;
-  if (hipHostGetDevicePointer(&dp, m, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipHostUnregister(m);
-    (void)munmap(m, bytes);
-    bang_set_error("pull rows: no device address for the registered rows");
-    return BANG_ERR_HIP;
-  }
-  e->h_adj = (uint32_t*)m; e->adj_bytes = bytes; e->d_adj = (const uint32_t*)dp; e->pull = true;
+  std::vector<uint32_t> seed(2 + BANG_MAX_R + 1, 0);
+  seed[0] = deg + 1;
+  seed[1] = (uint32_t)e->medoid;
+  memcpy(&seed[2], me + vec_bytes(e) + 4, (size_t)deg * 4);
+  BANG_TRY(dmalloc(&e->d_seed, seed.size()));
+  HIP_TRY(hipMemcpy(e->d_seed, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&e->d_medoid_vec, (vec_bytes(e) + 15) & ~(size_t)15));
+  HIP_TRY(hipMemcpy(e->d_medoid_vec, me, vec_bytes(e), hipMemcpyHostToDevice));
   return BANG_OK;
+}
+
+// Can this index run in pull mode without a resident graph?  (vectors in HBM, rows in host memory, no walker option forced)
+static bool stream_feasible(bang_engine* e, size_t hbm_reserve, std::string* why) {
+  const size_t need = (size_t)e->N * vec_bytes(e);
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  if (e->pull_opt == 0) { if (why) *why = "option pull = 0"; return false; }
+  if (e->vectors_opt == 0) { if (why) *why = "option vectors = 0"; return false; }
+  if (e->R > 64) { if (why) *why = "R > 64"; return false; }
+  if (e->persistent == 0 || e->search_opt == 0) { if (why) *why = "the search kernel is switched off"; return false; }
+  if (e->vectors_opt != 1 && need + hbm_reserve > free_b) { if (why) *why = "the full-precision vectors do not fit HBM"; return false; }
+  return true;
+}
+
+// STREAMED load: every chunk of graph entries the source hands over is split on the spot -- vectors into HBM (through a pinned
+// staging buffer), adjacency lists into the pull rows -- and dropped.  Host memory: the rows (N x 256 B) and one chunk.
+static int stage_entries_streamed(bang_engine* e) {
+  const size_t vb = vec_bytes(e), N = e->N, el = e->entry_len;
+  HIP_TRY(hipMalloc((void**)&e->d_vecs, N * vb + 256));
+  PullRows pr;
+  BANG_TRY(pull_rows_open(e, pr, nullptr));
+  const size_t chunk = std::max<size_t>(1024, std::min<size_t>((size_t)1 << 20, ((size_t)512 << 20) / el));
+  void* bufp = nullptr;
+  if (posix_memalign(&bufp, 4096, chunk * el) != 0) { pull_rows_abandon(pr); bang_set_error("streamed load: no memory for a chunk"); return BANG_ERR_NOMEM; }
+  uint8_t* buf = (uint8_t*)bufp;
+  uint8_t* stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  std::vector<uint8_t> medoid_entry(el);
+  int rc = BANG_OK;
+  auto cleanup = [&]() {
+    free(buf);
+    for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipHostFree(stage[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+  };
+  for (int b = 0; b < 2 && rc == BANG_OK; ++b)
+    if (hipHostMalloc((void**)&stage[b], chunk * vb, hipHostMallocDefault) != hipSuccess || hipEventCreate(&ev[b]) != hipSuccess) {
+      (void)hipGetLastError(); bang_set_error("streamed load: no pinned staging buffer"); rc = BANG_ERR_HIP;
+    }
+  uint64_t h = kSigSeed;
+  uint32_t next_t = 0;
+  uint32_t* rows = (uint32_t*)pr.m;
+  const int T = std::max(1, std::min(16, usable_cpus()));
+  int b = 0;
+  for (size_t first = 0; first < N && rc == BANG_OK; first += chunk, b ^= 1) {
+    const size_t n = std::min(chunk, N - first);
+    if (e->entry_fn(e->entry_ctx, first, n, buf) != 0) { bang_set_error("streamed load: the entry source failed at node %zu", first); rc = BANG_ERR_IO; break; }
+    while (next_t < 64 && sig_sample_node(e, next_t) < first + n) {
+      sig_fold(e, h, buf + (sig_sample_node(e, next_t) - first) * el + vb);
+      ++next_t;
+    }
+    if (e->medoid >= first && e->medoid < first + n) memcpy(medoid_entry.data(), buf + (e->medoid - first) * el, el);
+    if (hipEventSynchronize(ev[b]) != hipSuccess) { bang_set_error("streamed load: event"); rc = BANG_ERR_HIP; break; }   // the previous copy out of this buffer is done
+    {
+      uint8_t* st = stage[b];
+      const bool fill = pr.fill;
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t)
+        th.emplace_back([=]() {
+          const size_t a = n * t / T, z = n * (t + 1) / T;
+          for (size_t i = a; i < z; ++i) {
+            const uint8_t* ent = buf + i * el;
+            memcpy(st + i * vb, ent, vb);
+            if (fill) pull_row_from_entry(e, rows + (first + i) * 64, ent + vb);
+          }
+        });
+      for (auto& x : th) x.join();
+    }
+    if (hipMemcpyAsync(e->d_vecs + first * vb, stage[b], n * vb, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+        hipEventRecord(ev[b], nullptr) != hipSuccess) { bang_set_error("streamed load: vector upload failed"); rc = BANG_ERR_HIP; break; }
+  }
+  if (rc == BANG_OK && hipDeviceSynchronize() != hipSuccess) { bang_set_error("streamed load: sync"); rc = BANG_ERR_HIP; }
+  cleanup();
+  if (rc != BANG_OK) { (void)hipGetLastError(); pull_rows_abandon(pr); return rc; }
+  e->vec_on_device = true;
+  BANG_TRY(pull_rows_finish(e, pr, sig_make(e, h)));
+  BANG_TRY(stage_medoid(e, medoid_entry.data()));
+  e->graph_streamed = true;
+  return BANG_OK;
+}
+
+struct FileEntrySource { int fd; uint64_t entry_len; };
+static int file_entry_source(void* ctx, uint64_t first, uint64_t count, uint8_t* dst) {
+  const FileEntrySource* f = (const FileEntrySource*)ctx;
+  size_t left = (size_t)(count * f->entry_len);
+  off_t off = (off_t)(first * f->entry_len);
+  while (left) {
+    const ssize_t r = pread(f->fd, dst, left, off);
+    if (r <= 0) return -1;
+    dst += r; off += r; left -= (size_t)r;
+  }
+  return 0;
+}
+
+// The graph file in host memory, MAPPED shared and read-only, not copied: the ranks of a multi-GPU job (one process per GPU) walk
+// ONE copy in the page cache instead of one 388 GB copy each (:312-328).  MAP_POPULATE reads the file in now, as the reference's
+// fread does.  BANG_GRAPH_MMAP=0 (or a failing mmap) falls back to a private copy, which can ask for transparent huge pages.
+static int map_graph_file(bang_engine* e) {
+  if (e->graph) return BANG_OK;
+  if (e->graph_path.empty()) { bang_set_error("the graph entries were streamed at load time and are not resident: only the pull mode can run"); return BANG_ERR_UNSUPPORTED; }
+  const int fd = open(e->graph_path.c_str(), O_RDONLY);
+  if (fd < 0) { printf("Error.. Could not open the Graph Index File: %s\n", e->graph_path.c_str()); bang_set_error("cannot open %s", e->graph_path.c_str()); return BANG_ERR_IO; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < (size_t)e->N * e->entry_len) { close(fd); bang_set_error("graph file too small"); return BANG_ERR_IO; }
+  const size_t gsize = (size_t)st.st_size;
+  static const bool want_map = !(getenv("BANG_GRAPH_MMAP") && atoi(getenv("BANG_GRAPH_MMAP")) == 0);
+  void* mp = want_map ? mmap(nullptr, gsize, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0) : MAP_FAILED;
+  int rc = BANG_OK;
+  if (mp != MAP_FAILED) {
+    e->graph_map = mp; e->graph_map_len = gsize;
+    (void)madvise(mp, gsize, MADV_RANDOM);
+    e->graph = (const uint8_t*)mp;
+  } else {
+    void* gp = nullptr;
+    if (posix_memalign(&gp, (size_t)2 << 20, gsize) != 0) gp = nullptr;
+    e->graph_owned = (uint8_t*)gp;
+    if (gp) (void)madvise(gp, gsize, MADV_HUGEPAGE);
+    if (!e->graph_owned) { printf("Error.. Malloc failed for Graph Index.\n"); bang_set_error("malloc(%zu) failed", gsize); rc = BANG_ERR_NOMEM; }
+    else {
+      FileEntrySource src{fd, e->entry_len};
+      if (file_entry_source(&src, 0, e->N, e->graph_owned) != 0) { bang_set_error("short graph file"); rc = BANG_ERR_IO; free(e->graph_owned); e->graph_owned = nullptr; }
+      else e->graph = e->graph_owned;
+    }
+  }
+  close(fd);
+  return rc;
 }
 
 int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext, const float* pivots,
@@ -538,24 +720,39 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
     BANG_TRY(dmalloc(&e->d_pivots_packed, packed.size()));
     HIP_TRY(hipMemcpy(e->d_pivots_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
   }
-  // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501)
-  const uint8_t* me = e->graph + e->medoid * e->entry_len;
-  uint32_t deg;
-  memcpy(&deg, me + vec_bytes(e), 4);
-  if (deg > e->R) deg = e->R;
-  for (uint32_t i = 0; i < deg; ++i) {                 // cheap spot check of the adjacency layout: the medoid's neighbours
-    uint32_t nb;
-    memcpy(&nb, me + vec_bytes(e) + 4 + 4 * (size_t)i, 4);
-    if (nb >= e->N) { bang_set_error("medoid neighbour %u = %u is out of range (N = %u): wrong data type or corrupt index", i, nb, e->N); return BANG_ERR_IO; }
+  // ---- everything that depends on the graph entries
+  e->vec_on_device = false;
+  e->pull = false;
+  e->graph_streamed = false;
+  if (!e->graph) {
+    // no resident graph: a streamed load (the caller's entry source), or a graph FILE that has not been touched yet.  If the pull
+    // mode applies the entries only pass through (vectors -> HBM, adjacency -> pull rows); else a file is mapped as before.
+    std::string why;
+    const bool feasible = e->graph_mode != BANG_GRAPH_DEVICE && stream_feasible(e, hbm_reserve, &why);
+    const bool from_file = (e->entry_fn == nullptr);
+    static const bool want_stream = !(getenv("BANG_STREAM_LOAD") && atoi(getenv("BANG_STREAM_LOAD")) == 0);
+    if (!from_file && !feasible) {
+      bang_set_error("a streamed load runs in pull mode on the host placement only: %s", why.empty() ? "option graph = device" : why.c_str());
+      return BANG_ERR_UNSUPPORTED;
+    }
+    if (feasible && (!from_file || want_stream)) {
+      FileEntrySource fsrc{-1, e->entry_len};
+      if (from_file) {
+        fsrc.fd = open(e->graph_path.c_str(), O_RDONLY);
+        if (fsrc.fd < 0) { printf("Error.. Could not open the Graph Index File: %s\n", e->graph_path.c_str()); bang_set_error("cannot open %s", e->graph_path.c_str()); return BANG_ERR_IO; }
+        (void)posix_fadvise(fsrc.fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+        e->entry_fn = file_entry_source; e->entry_ctx = &fsrc;
+      }
+      const int rc = stage_entries_streamed(e);
+      if (from_file) { close(fsrc.fd); e->entry_fn = nullptr; e->entry_ctx = nullptr; }
+      if (rc == BANG_OK) { e->loaded = true; return BANG_OK; }
+      if (!(from_file && rc == BANG_ERR_NOMEM && e->pull_opt != 1)) return rc;
+      dfree(e->d_vecs);                               // the rows do not fit this host: keep the graph resident, the walker serves it
+      e->vec_on_device = false;
+    }
+    BANG_TRY(map_graph_file(e));
   }
-  std::vector<uint32_t> seed(2 + BANG_MAX_R + 1, 0);
-  seed[0] = deg + 1;
-  seed[1] = (uint32_t)e->medoid;
-  memcpy(&seed[2], me + vec_bytes(e) + 4, (size_t)deg * 4);
-  BANG_TRY(dmalloc(&e->d_seed, seed.size()));
-  HIP_TRY(hipMemcpy(e->d_seed, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&e->d_medoid_vec, (vec_bytes(e) + 15) & ~(size_t)15));
-  HIP_TRY(hipMemcpy(e->d_medoid_vec, me, vec_bytes(e), hipMemcpyHostToDevice));
+  BANG_TRY(stage_medoid(e, e->graph + e->medoid * e->entry_len));
   e->vec_on_device = false;
   if (e->graph_mode != BANG_GRAPH_DEVICE && e->vectors_opt != 0) {
     // 288 GB of HBM hold the full-precision vectors of a billion uint8 points (128 GB) next to their PQ codes (70 GB): keep a
@@ -583,7 +780,6 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       e->vec_on_device = true;
     }
   }
-  e->pull = false;
   if (e->graph_mode != BANG_GRAPH_DEVICE && e->pull_opt != 0) {
     // pull needs the re-rank's vectors in HBM (nothing walks the graph entries any more) and rows of <= 64 ids
     if (e->vec_on_device && e->R <= 64) {
@@ -625,6 +821,7 @@ void unload_index(bang_engine* e) {
   e->vec_on_device = false;
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
+  e->graph_path.clear(); e->graph_streamed = false; e->entry_fn = nullptr; e->entry_ctx = nullptr;
   free(e->graph_owned);
   e->graph_owned = nullptr;
   if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
@@ -815,32 +1012,13 @@ int load_files(bang_engine* e, const char* prefix) {
     fseek(fp, (long)offs[2] + 8, SEEK_SET);
     ok = ok && read_exact(fp, chunk_off.data(), chunk_off.size() * 4);
     if (!ok) { bang_set_error("pivots file: short section"); rc = BANG_ERR_IO; break; }
-    // graph + full-precision vectors into host RAM (:312-328)
+    // graph + full-precision vectors (:312-328): only checked here; upload_index streams the file (pull mode) or maps it
     fseek(fg, 0, SEEK_END);
     const size_t gsize = (size_t)ftell(fg);
     fseek(fg, 0, SEEK_SET);
     if (gsize < (size_t)e->N * e->entry_len) { bang_set_error("graph file too small"); rc = BANG_ERR_IO; break; }
-    // The graph (+ vectors) stays in host RAM (:312-328).  It is MAPPED, shared and read-only, not copied: the ranks of a
-    // multi-GPU job (one process per GPU) then walk ONE copy in the page cache instead of one 388 GB copy each.  MAP_POPULATE
-    // reads the file in at load time, as the reference's fread does.  BANG_GRAPH_MMAP=0 (or a failing mmap) falls back to a
-    // private copy, which can ask for transparent huge pages (the walker reads one random entry per expanded node).
-    {
-      static const bool want_map = !(getenv("BANG_GRAPH_MMAP") && atoi(getenv("BANG_GRAPH_MMAP")) == 0);
-      void* mp = want_map ? mmap(nullptr, gsize, PROT_READ, MAP_SHARED | MAP_POPULATE, fileno(fg), 0) : MAP_FAILED;
-      if (mp != MAP_FAILED) {
-        e->graph_map = mp; e->graph_map_len = gsize;
-        (void)madvise(mp, gsize, MADV_RANDOM);
-        e->graph = (const uint8_t*)mp;
-      } else {
-        void* gp = nullptr;
-        if (posix_memalign(&gp, (size_t)2 << 20, gsize) != 0) gp = nullptr;
-        e->graph_owned = (uint8_t*)gp;
-        if (gp) (void)madvise(gp, gsize, MADV_HUGEPAGE);
-        if (!e->graph_owned) { printf("Error.. Malloc failed for Graph Index.\n"); bang_set_error("malloc(%zu) failed", gsize); rc = BANG_ERR_NOMEM; break; }
-        if (!read_exact(fg, e->graph_owned, gsize)) { bang_set_error("short graph file"); rc = BANG_ERR_IO; break; }
-        e->graph = e->graph_owned;
-      }
-    }
+    e->graph_path = f_graph;
+    e->graph = nullptr;
   } while (0);
   fclose(fp); fclose(fc); fclose(fg); fclose(fm);
   if (rc != BANG_OK) {
@@ -1696,7 +1874,32 @@ extern "C" int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* d) {
   e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
   e->graph = d->graph;
   e->graph_owned = nullptr;
+  e->graph_path.clear();
   const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+extern "C" int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* d, bang_entry_source src, void* ctx) {
+  if (!e || !d || !src || d->graph || !d->pivots || !d->centroid || !d->chunk_off || (!d->codes && !d->d_codes)) {
+    bang_set_error("bad index descriptor (a streamed load takes an entry source and no graph pointer)");
+    return BANG_ERR_ARG;
+  }
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
+  e->graph = nullptr;
+  e->graph_owned = nullptr;
+  e->graph_path.clear();
+  if (e->graph_mode == BANG_GRAPH_DEVICE) { bang_set_error("a streamed load keeps the adjacency lists on the host (pull mode): option graph = device does not apply"); return BANG_ERR_UNSUPPORTED; }
+  e->graph_mode = BANG_GRAPH_HOST;                       // (auto included: there is no graph image to put into HBM)
+  if (e->entry_len != (uint64_t)e->D * e->tsize + 4 + 4ull * e->R) {
+    bang_set_error("index entry length %llu does not match D=%u x %zu B + 4 + 4 x R=%u", (unsigned long long)e->entry_len, e->D, e->tsize, e->R);
+    return BANG_ERR_ARG;
+  }
+  e->entry_fn = src; e->entry_ctx = ctx;
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  e->entry_fn = nullptr; e->entry_ctx = nullptr;
   if (rc != BANG_OK) unload_index(e);
   return rc;
 }
@@ -1771,6 +1974,9 @@ static int alloc_buffers(bang_engine* e, int Q) {
       e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
     }
   }
+  // a walker form on an index whose graph entries only passed through at load time: map the graph file now (a streamed load
+  // from an entry source has nothing to map: error)
+  if (!dev_graph && !e->search_v2 && !e->graph) BANG_TRY(map_graph_file(e));
   e->fp_direct = false;
   HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));

@@ -92,6 +92,17 @@ typedef struct {
 } bang_index_desc;
 int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* desc);
 
+/* STREAMED load (host placement, pull mode only): the graph entries are handed over chunk by chunk and are never held in host
+ * memory as a whole.  The engine calls src(ctx, first, count, dst) for consecutive node ranges; the source writes `count`
+ * entries in the reference layout ([T vec[D]][u32 degree][u32 id x R], entry_len bytes each) to dst and returns 0.  Of each entry
+ * the vector goes to HBM and the adjacency list into the 256-byte pull rows in pinned host memory: a 10^9-node SIFT index then
+ * needs 256 GB of host RAM instead of 388 GB + 256 GB.  desc->graph must be NULL.  Fails (BANG_ERR_UNSUPPORTED / BANG_ERR_NOMEM)
+ * where the pull mode is not possible -- vectors that do not fit HBM, rows that do not fit the host, R > 64, option pull = 0 --
+ * because nothing else can run without the graph.  bang_load_e streams `<p>_disk.bin` through the same path when the pull mode
+ * applies (BANG_STREAM_LOAD=0: map the file as before); should a walker form be asked for later, the file is mapped then. */
+typedef int (*bang_entry_source)(void* ctx, uint64_t first, uint64_t count, uint8_t* dst);
+int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* desc, bang_entry_source src, void* ctx);
+
 int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn); /* bang.h:60 */
 int bang_alloc_e(bang_engine_t* e, int num_queries);                                        /* bang.h:53 */
 int bang_init_e(bang_engine_t* e, int num_queries);                                         /* bang.h:56 */

@@ -416,3 +416,118 @@ def test_pull_rows_file_is_shared_and_validated(libbang, small_u8, small_i8, tmp
     ids3, _ = run(ix, q)
     assert np.array_equal(ids3, ids_o) and path.stat().st_ino != ino
     assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+
+
+# -------------------------------------------------------------------------------------------------------------- streamed load
+def _entry_source(ix):
+    """A Python entry source over an in-memory index: copies the requested node range in the reference entry layout."""
+    import ctypes as C
+    graph = np.ascontiguousarray(ix.graph, dtype=np.uint8)
+
+    def src(first, count, dst):
+        C.memmove(dst, graph[first:first + count].ctypes.data, count * ix.entry_len)
+        return 0
+    return src
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["small_f32", "small_u8", "small_i8"])
+def test_streamed_load_matches_oracle(request, libbang, fixture):
+    """bang_load_stream_e: the graph entries pass through in chunks (vectors -> HBM, adjacency lists -> pull rows) and are never
+    resident as a whole; the search runs in pull mode and returns the oracle's bits."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q = q.shape[0]
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 48, with_stats=True)
+    for graph in (bang_amd.GRAPH_HOST, bang_amd.GRAPH_AUTO):
+        with bang_amd.Engine(ix.dtype, graph=graph) as e:
+            e.load_stream(ix, _entry_source(ix))
+            e.set_searchparams(10, 48)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+            assert st["graph_mode"] == 0 and st["graph_pull"] == 1 and st["vectors_on_device"] == 1
+            assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(Q), st_o)
+
+
+@pytest.mark.gpu
+def test_streamed_load_needs_the_pull_mode(libbang, small_u8):
+    """Without a resident graph nothing but the pull mode can run: a streamed load refuses configurations that exclude it, and a
+    walker form asked for afterwards is an error (there is no file to map)."""
+    import bang_amd
+    ix, q, _, _ = small_u8
+    for opts in (dict(graph=1), dict(graph=0, pull=0), dict(graph=0, vectors=0), dict(graph=0, persistent=0), dict(graph=0, search=0)):
+        with bang_amd.Engine(ix.dtype, **opts) as e:
+            with pytest.raises(bang_amd.BangError, match="pull mode"):
+                e.load_stream(ix, _entry_source(ix))
+    with bang_amd.Engine(ix.dtype, graph=0) as e:
+        e.load_stream(ix, _entry_source(ix))
+        e.set_option("persistent", 0)
+        e.set_searchparams(10, 40)
+        with pytest.raises(bang_amd.BangError, match="streamed"):
+            e.alloc(q.shape[0])
+    with bang_amd.Engine(ix.dtype, graph=0) as e:                   # a failing source fails the load
+        with pytest.raises(bang_amd.BangError, match="entry source"):
+            e.load_stream(ix, lambda first, count, dst: 1)
+
+
+@pytest.mark.gpu
+def test_file_load_streams_the_graph_and_maps_it_on_demand(libbang, small_u8, tmp_path, monkeypatch):
+    """bang_load on the host placement: `_disk.bin` is streamed (never resident) when the pull mode applies; a walker form chosen
+    after the load maps the file then; BANG_STREAM_LOAD=0 maps it up front as before.  Same bits every way."""
+    import bang_amd
+    from bang_amd import formats
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    Q = q.shape[0]
+    prefix = str(tmp_path / "idx")
+    formats.write_index(prefix, ix)
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 40)
+
+    def run(late_opts=None, **opts):
+        with bang_amd.Engine(ix.dtype, graph=0, **opts) as e:
+            e.load(prefix)
+            for k, v in (late_opts or {}).items():
+                e.set_option(k, v)
+            e.set_searchparams(10, 40)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        return st
+    assert run()["graph_pull"] == 1                                   # streamed, pulled
+    st = run(late_opts=dict(persistent=0))                            # streamed at load; the walker loop maps the file at bang_alloc
+    assert st["graph_pull"] == 0 and st["persistent"] == 0 and st["h2d_bytes"] > 0
+    assert run(pull=0)["graph_pull"] == 0                             # walker asked for up front: mapped at load
+    monkeypatch.setenv("BANG_STREAM_LOAD", "0")
+    assert run()["graph_pull"] == 1                                   # mapped at load, rows built from the mapping
+
+
+@pytest.mark.gpu
+def test_streamed_load_shares_and_checks_the_rows_file(libbang, small_u8, small_i8, tmp_path, monkeypatch):
+    import bang_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BANG_PULL_ROWS_DIR", str(tmp_path))
+    ix, q, _, _ = small_u8
+    ids_o, _ = O.Oracle(ix).search(q, 10, 40)
+    path = tmp_path / "index_pull_rows.bin"
+
+    def run(index):
+        with bang_amd.Engine(index.dtype, graph=0) as e:
+            e.load_stream(index, _entry_source(index))
+            e.set_searchparams(10, 40)
+            e.alloc(q.shape[0])
+            e.init(q.shape[0])
+            return e.query(q)[0]
+    assert np.array_equal(run(ix), ids_o) and path.exists()
+    ino = path.stat().st_ino
+    assert np.array_equal(run(ix), ids_o) and path.stat().st_ino == ino       # second load: rows mapped, signature checked at the end
+    blob = bytearray(path.read_bytes())
+    blob[ix.N * 256 + 2048 + 33] ^= 0xFF
+    path.write_bytes(bytes(blob))
+    with pytest.raises(bang_amd.BangError, match="another index"):            # a streamed load cannot rebuild behind itself: loud
+        run(ix)
