@@ -85,7 +85,7 @@ def shared_dir(ctx):
     return os.path.join("/tmp", tag)
 
 
-def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True):
+def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False):
     """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), prefix (index files, N > 1), release().
 
     N > 1 (one process per GPU): ONE host graph for the node (the reference keeps one pIndex in host RAM,
@@ -104,13 +104,15 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True):
     if name.endswith("_shape"):
         from tools import shape_workload
         shared = None
+        stream = bool(stream and shape_workload.SHAPES[name]["graph"] == "host")
         if world > 1:
-            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
+            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows, stream) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
             dist.broadcast(n_plan, 0)
             shape_n = int(n_plan.item())
-            shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
+            if not stream:                       # (a streamed index has no graph image to share: every rank runs the generator)
+                shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
         ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
-            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows)
+            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows, stream=stream)
 
         def rel():
             shape_workload.release(ix)
@@ -169,8 +171,12 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
     eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing, pull=pull)
 
     def load():
-        if wl.get("prefix"):
-            eng.load(wl["prefix"])               # bang_load on the shared index files: `_disk.bin` is mapped, not copied
+        src = getattr(wl["ix"], "entry_source", None)
+        if src is not None:                      # streamed shape index: the engine pulls the generator's entries through in chunks
+            import ctypes as C
+            eng.load_stream(wl["ix"], src[0], C.byref(src[1]), d_codes=wl["d_codes"])
+        elif wl.get("prefix"):
+            eng.load(wl["prefix"])               # bang_load on the shared index files (`_disk.bin` streamed or mapped, never copied)
         else:
             eng.load_index(wl["ix"], d_codes=wl["d_codes"])
     if ctx.world > 1 and wl.get("shared_dir"):
@@ -425,6 +431,9 @@ def main():
     ap.add_argument("--batches", type=int, default=1, help="N > 1 throughput mode: every rank streams this many WHOLE batches per step")
     ap.add_argument("--pull", type=int, default=-1, choices=[-1, 0, 1],
                     help="host-graph placement: 1 = the kernel pulls adjacency rows over PCIe, 0 = C++ walker threads, -1 = engine default")
+    ap.add_argument("--resident-graph", action="store_true",
+                    help="sift1b_shape: build the whole 388-byte-per-node graph image in host memory (N then fits graph + pull rows) "
+                         "instead of streaming the generator through the engine (default: streamed, N fits the pull rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -463,7 +472,8 @@ def main():
     if world > 1:
         dist.barrier()
 
-    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n, reserve_rows=(args.pull != 0))
+    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n, reserve_rows=(args.pull != 0),
+                        stream=(args.pull != 0 and not args.resident_graph))
     ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
     # placement: the engine's own default ("auto": the whole graph in HBM when it fits next to the PQ codes with 16 GB to spare,
     # else host RAM + C++ walker) for the structured workloads; the shape-only workloads use the placement BASELINE.json names
@@ -624,7 +634,7 @@ def main():
     if legs:
         for name in ("deep100m_shape", "sift1b_shape"):
             try:
-                w2 = build_workload(name, ctx)
+                w2 = build_workload(name, ctx, stream=True)      # sift1b_shape: streamed load, N as large as the pull rows allow
                 q2 = np.ascontiguousarray(w2["queries"])
                 e3 = make_engine(w2, w2["graph"], ctx, timing=0 if args.no_events else 1)
                 e3.set_searchparams(k, 152)                  # the reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
@@ -633,21 +643,27 @@ def main():
                 props = check_properties(w2["ix"], q2, r4["ids"], r4["dists"], k)
                 cfg[f"at_{name}"] = leg_summary(r4, w2, w2["graph"], props=props)
                 e3.free(); e3.unload(); e3.close()
-                if w2["graph"] == "host" and r4["agg"].get("graph_pull"):
-                    # the north-star data flow on its own configuration: the same index served by the C++ walker threads
-                    e3 = make_engine(w2, "host", ctx, timing=0 if args.no_events else 1, pull=0)
-                    e3.set_searchparams(k, 152)
-                    e3.alloc(q2.shape[0])
-                    r4w = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, "host")
-                    cfg[f"at_{name}_walker"] = leg_summary(r4w, w2, "host", props=check_properties(w2["ix"], q2, r4w["ids"], r4w["dists"], k),
-                                                           extra={"ids_equal_pull_run": bool(np.array_equal(r4w["ids"], r4["ids"]))})
-                    e3.free(); e3.unload(); e3.close()
                 k2[f"m{w2['ix'].m}"] = k2_alone(w2["ix"].D, w2["ix"].m, w2["ix"].dtype, ctx)
                 w2["release"]()
                 del w2, q2, e3
                 torch.cuda.empty_cache()
             except Exception as ex:                          # a leg must never take the primary line down
                 cfg[f"at_{name}"] = {"error": repr(ex)[:300]}
+        try:
+            # the north-star data flow on its own configuration: a resident graph image served by the C++ walker threads
+            w2 = build_workload("sift1b_shape", ctx, reserve_rows=False, stream=False)
+            q2 = np.ascontiguousarray(w2["queries"])
+            e3 = make_engine(w2, "host", ctx, timing=0 if args.no_events else 1, pull=0)
+            e3.set_searchparams(k, 152)
+            e3.alloc(q2.shape[0])
+            r4w = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, "host")
+            cfg["at_sift1b_shape_walker"] = leg_summary(r4w, w2, "host", props=check_properties(w2["ix"], q2, r4w["ids"], r4w["dists"], k))
+            e3.free(); e3.unload(); e3.close()
+            w2["release"]()
+            del w2, q2, e3
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            cfg["at_sift1b_shape_walker"] = {"error": repr(ex)[:300]}
         # a structured index beyond the Infinity Cache (N = 10 M: 320 MB of codes, 3.9 GB graph), recall-verified, both placements
         try:
             w3 = build_workload("sift10m", ctx)

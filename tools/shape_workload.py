@@ -38,7 +38,32 @@ def _lib():
     lib.shape_map_shared.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
     lib.shape_fill_graph.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
     lib.shape_fill_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    lib.shape_fill_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
     return lib
+
+
+class ShapeSource(C.Structure):
+    """shape_source of shape_fill.c: the context of shape_entry_source (the generator as an entry source of a streamed load)."""
+    _fields_ = [("N", C.c_uint64), ("seed", C.c_uint64), ("vec_bytes", C.c_uint32), ("R", C.c_uint32),
+                ("nthreads", C.c_int32), ("vec_float", C.c_int32)]
+
+
+class LazyGraph:
+    """Stands in for the [N][entry] graph image of a STREAMED shape index: rows are regenerated on demand (every node has its own
+    generator state), which is all the result checks need (`graph[ids, :vec_bytes]`)."""
+
+    def __init__(self, lib, src: ShapeSource, entry: int):
+        self._lib, self._src, self._entry = lib, src, entry
+        self.shape = (int(src.N), entry)
+
+    def __getitem__(self, key):
+        rows, cols = key if isinstance(key, tuple) else (key, slice(None))
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        out = np.empty((rows.size, self._entry), np.uint8)
+        s = self._src
+        for k, r in enumerate(rows):
+            self._lib.shape_fill_range(out[k].ctypes.data, s.N, int(r), 1, s.vec_bytes, s.R, s.seed, 1, s.vec_float)
+        return out[:, cols]
 
 
 def usable_cpus() -> int:
@@ -70,14 +95,17 @@ def usable_host_bytes() -> int:
 PULL_ROW_BYTES = 256       # host-graph placement, pull mode: the engine keeps the adjacency lists a second time as 256-byte rows
 
 
-def plan_n(name, dev, n_override=0, reserve_rows=True):
+def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False):
     """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything."""
     import torch
     sh = SHAPES[name]
     isz = 4 if sh["dtype"] == "float" else 1
     entry = sh["D"] * isz + 4 + 4 * sh["R"]
     N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
-    if sh["graph"] == "host":
+    if sh["graph"] == "host" and stream:
+        free, _ = torch.cuda.mem_get_info(dev)
+        N = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (sh["D"] * isz + sh["m"]))
+    elif sh["graph"] == "host":
         N = min(N, int(usable_host_bytes() * 0.75) // (entry + (PULL_ROW_BYTES if reserve_rows else 0)))
     else:
         free, _ = torch.cuda.mem_get_info(dev)
@@ -96,7 +124,8 @@ class ShapeIndex:
         return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
 
 
-def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None, reserve_rows=True):
+def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None, reserve_rows=True,
+         stream=False):
     """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
     can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent.
     shared=(path, is_creator, barrier): the graph image lives in ONE mapping of the file `path` shared by every rank of the node
@@ -111,8 +140,18 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     lib = _lib()
     ncpu = usable_cpus()
     note = ""
+    stream = bool(stream and sh["graph"] == "host" and not host_codes)
     if shared is not None and n_override:
         pass                                   # N was planned once for the node (plan_n on the creator) and handed to every rank
+    elif stream:
+        # STREAMED: the graph image never exists -- the engine pulls the generator's entries through in chunks (vectors -> HBM,
+        # adjacency lists -> 256-byte pull rows in host memory).  Host budget: the rows; HBM budget: codes + vectors + 28 GB.
+        free, _total = torch.cuda.mem_get_info(dev)
+        N2 = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (D * isz + m))
+        if N2 < N:
+            note = (f" (N scaled {N} -> {N2}: {PULL_ROW_BYTES}-byte pull rows in 75 % of the host memory of the box, "
+                    f"vectors + codes in HBM)")
+            N = N2
     elif sh["graph"] == "host":
         budget = int(usable_host_bytes() * 0.75)
         per_node = entry + (PULL_ROW_BYTES if reserve_rows else 0)
@@ -135,7 +174,12 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
             N = N2
     t0 = time.time()
     gbytes = N * entry
-    if shared is not None:
+    ptr, graph, source = None, None, None
+    if stream:
+        source = ShapeSource(N, seed, D * isz, R, ncpu, 1 if sh["dtype"] == "float" else 0)
+        graph = LazyGraph(lib, source, entry)
+        gbytes = 0
+    elif shared is not None:
         path, creator, barrier = shared
         if creator:
             ptr = lib.shape_map_shared(path.encode(), gbytes, 1)
@@ -153,8 +197,9 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         if not ptr:
             raise MemoryError(f"cannot map {gbytes} bytes")
         lib.shape_fill_graph(ptr, N, D * isz, R, seed, ncpu, 1 if sh["dtype"] == "float" else 0)   # floats: uniform in [-1, 1)
-    graph = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(gbytes,)).reshape(N, entry)
-    log(f"[shape] graph image {gbytes / 2**30:.1f} GiB filled in {time.time() - t0:.1f}s with {ncpu} threads{note}")
+    if not stream:
+        graph = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(gbytes,)).reshape(N, entry)
+        log(f"[shape] graph image {gbytes / 2**30:.1f} GiB filled in {time.time() - t0:.1f}s with {ncpu} threads{note}")
     t0 = time.time()
     codes_host, cptr = None, None
     if host_codes:
@@ -186,9 +231,15 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         queries = (rng.random((Q, D), dtype=np.float32) * 2 - 1).astype(np.float32)
     ix = ShapeIndex(dtype=sh["dtype"], N=N, D=D, R=R, m=m, medoid=int(N // 2), graph=graph,
                     codes=codes_host if host_codes else np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
-                    chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib, _cptr=cptr, _cbytes=N * m)
-    name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
-              f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * m / 1e9:.0f} GB in HBM{note}")
+                    chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib, _cptr=cptr, _cbytes=N * m,
+                    entry_source=((lib.shape_entry_source, source) if stream else None))
+    if stream:
+        name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, STREAMED load: adjacency lists "
+                  f"{N * PULL_ROW_BYTES / 1e9:.0f} GB as pull rows in host RAM, vectors {N * D * isz / 1e9:.0f} GB + codes "
+                  f"{N * m / 1e9:.0f} GB in HBM{note}")
+    else:
+        name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
+                  f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * m / 1e9:.0f} GB in HBM{note}")
     return ix, queries, None, None, (codes.data_ptr() if codes is not None else None), name_s, sh["graph"]
 
 
