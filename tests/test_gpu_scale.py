@@ -115,3 +115,41 @@ def test_offsets_beyond_4gib_match_oracle(libbang, shape, N):
             assert st["dist_evals"] == int(st_o[:, 2].sum()) and st["candidates"] == int(st_o[:, 1].sum())
     finally:
         SW.release(ix)
+
+
+def test_streamed_shape_index_equals_the_resident_one(libbang):
+    """The streamed load at a size whose pull rows exceed 4 GiB: the shape generator as the engine's entry source (no graph image in
+    host memory) against the same index built as a resident image -- pulled, walked and in HBM.  Same ids, same distances."""
+    import ctypes as C
+    import torch
+    import bang_amd
+    from tools import shape_workload as SW
+    N, Q, k, L = 20_000_000, 64, 10, 40
+    dev = torch.device("cuda", 0)
+    ix_s, q, _, _, d_codes_s, name_s, _ = SW.make("sift1b_shape", dev, n_override=N, Q=Q, log=lambda *a: None, stream=True)
+    ix_r, q_r, _, _, d_codes_r, _, _ = SW.make("sift1b_shape", dev, n_override=N, Q=Q, log=lambda *a: None, stream=False)
+    try:
+        assert ix_s.N == N and ix_r.N == N and "STREAMED" in name_s and N * 256 > 2**32
+        assert np.array_equal(q, q_r)
+        assert np.array_equal(ix_s.graph[np.array([0, N // 2, N - 1])], ix_r.graph[[0, N // 2, N - 1]])   # one generator, two routes
+
+        def run(load, **opts):
+            with bang_amd.Engine(ix_s.dtype, **opts) as e:
+                load(e)
+                e.set_searchparams(k, L)
+                e.alloc(Q)
+                e.init(Q)
+                ids, dists = e.query(q)
+                st = e.stats()
+            return ids, dists, st
+        src = ix_s.entry_source
+        ids, dists, st = run(lambda e: e.load_stream(ix_s, src[0], C.byref(src[1]), d_codes=d_codes_s), graph=0)
+        assert st["graph_pull"] == 1 and st["pulled_bytes"] == 256 * (st["candidates"] - Q)
+        assert (ids < N).all() and ids.max() > 2**32 // 256                 # results do live behind the 4 GiB mark of the rows
+        for opts in (dict(graph=0, pull=1), dict(graph=0, pull=0), dict(graph=1)):
+            ids2, dists2, st2 = run(lambda e: e.load_index(ix_r, d_codes=d_codes_r), **opts)
+            assert np.array_equal(ids, ids2) and np.array_equal(dists.view(np.uint32), dists2.view(np.uint32)), opts
+            assert st2["dist_evals"] == st["dist_evals"] and st2["candidates"] == st["candidates"]
+    finally:
+        SW.release(ix_s)
+        SW.release(ix_r)
