@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the PQ-distance stage ALONE (K2, compute_neighborDist_par, bang_search.cu:1201-1241):
 #   tools/k2_alone.py --big = bang_k_pqdist_stream over 40 M (query, neighbour) pairs per launch on a 4 GB code table, m = 32 / 70 / 74.
-# Pass 1: kernel trace + stats; pass 2: FETCH_SIZE; pass 3: L2 hit / miss / requests.  Output: gpurun_out/profiles_out/<tag>_k2_alone.md
+# Pass 1: kernel trace + stats; pass 2: FETCH_SIZE; pass 3: L2 hit / miss / requests; passes 4-5: SQ wait/busy split, instruction mix, LDS conflicts.  Output: gpurun_out/profiles_out/<tag>_k2_alone.md
 set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
@@ -10,6 +10,8 @@ rm -rf "$OUT"; mkdir -p "$OUT" gpurun_out/profiles_out
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/k2_alone.py --big > "$OUT/k2_trace.jsonl" 2> "$OUT/k2_trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/k2_alone.py --big > "$OUT/k2_fetch.jsonl" 2> "$OUT/k2_fetch.err"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d "$OUT/pmc_l2" -- python3 tools/k2_alone.py --big > "$OUT/k2_l2.jsonl" 2> "$OUT/k2_l2.err"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d "$OUT/pmc_sq1" -- python3 tools/k2_alone.py --big > "$OUT/k2_sq1.jsonl" 2> "$OUT/k2_sq1.err"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 tools/k2_alone.py --big > "$OUT/k2_sq2.jsonl" 2> "$OUT/k2_sq2.err"
 python3 - "$OUT" > gpurun_out/profiles_out/${TAG}_k2_alone.md <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]
@@ -38,7 +40,9 @@ if f:
         print(f"| m = {m} | {len(grp)} | {sum(du)/len(du):.1f} | {min(du):.1f} | {max(du):.1f} | {grp[0]['Kernel_Name'].split('(')[0][:60]} |")
     print()
 for name, label in (("pmc_fetch", "FETCH_SIZE (KB; raw -- random 32-74-byte rows are 64-byte requests, the gfx950 x2 correction for wide coalesced reads does not apply)"),
-                    ("pmc_l2", "L2 / fabric counters")):
+                    ("pmc_l2", "L2 / fabric counters"),
+                    ("pmc_sq1", "where the wave cycles go (SQ, quad-cycles summed over waves)"),
+                    ("pmc_sq2", "instructions and LDS bank conflicts (SQ)")):
     f = glob.glob(os.path.join(out, name + "/**/*counter_collection.csv"), recursive=True)
     if not f:
         continue
@@ -58,4 +62,4 @@ for name, label in (("pmc_fetch", "FETCH_SIZE (KB; raw -- random 32-74-byte rows
     print()
 PY
 cat gpurun_out/profiles_out/${TAG}_k2_alone.md | head -60
-rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_l2"
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_l2" "$OUT/pmc_sq1" "$OUT/pmc_sq2"
