@@ -73,43 +73,71 @@ struct QcRegs {
   }
 };
 
+// QcRow16: the centred query replicated per 16-lane row -- lane l of v[r] holds qc[16 r + (l & 15)] -- so that "pivot - query" is ONE
+// instruction, v_subrev_f32 with a DPP row broadcast of the query operand, instead of v_readlane + v_sub (K2 alone spends 128 of its
+// 597 VALU instructions per 64 rows on those v_readlanes).  ceil(QW / 16) registers per query: for kernels with registers to spare.
+template <int NR>
+struct QcRow16 {
+  float v[NR];
+};
+template <int N>
+__device__ __forceinline__ float sub_row_bcast(float p, float qreg) {     // p - (lane N of qreg's 16-lane row)
+  float d;
+  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(qreg), "v"(p), "n"(N));
+  return d;
+}
+template <class QC>
+__device__ __forceinline__ float qc_sub(const QC& qc, float p, uint32_t i) { return p - qc[i]; }
+template <int NR>
+__device__ __forceinline__ float qc_sub(const QcRow16<NR>& qc, float p, uint32_t i) {
+  const float r = qc.v[i >> 4];
+  switch (i & 15u) {                                   // i is a constant after unrolling: one case survives
+    case 0: return sub_row_bcast<0>(p, r);   case 1: return sub_row_bcast<1>(p, r);   case 2: return sub_row_bcast<2>(p, r);
+    case 3: return sub_row_bcast<3>(p, r);   case 4: return sub_row_bcast<4>(p, r);   case 5: return sub_row_bcast<5>(p, r);
+    case 6: return sub_row_bcast<6>(p, r);   case 7: return sub_row_bcast<7>(p, r);   case 8: return sub_row_bcast<8>(p, r);
+    case 9: return sub_row_bcast<9>(p, r);   case 10: return sub_row_bcast<10>(p, r); case 11: return sub_row_bcast<11>(p, r);
+    case 12: return sub_row_bcast<12>(p, r); case 13: return sub_row_bcast<13>(p, r); case 14: return sub_row_bcast<14>(p, r);
+    default: return sub_row_bcast<15>(p, r);
+  }
+}
+
 template <int PSZ, int NHI, class QC>
 __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, const QC& qc, uint32_t c, uint32_t code) {
   float t = 0.0f;
   if (PSZ == 2 && NHI > 0) {
     if (c < (uint32_t)NHI) {
       const float2 p = *(const float2*)(piv_lds + c * 512u + code * 2u);
-      const float d0 = p.x - qc[c * 2 + 0];
+      const float d0 = qc_sub(qc, p.x, c * 2 + 0);
       t = __builtin_fmaf(d0, d0, t);
-      const float d1 = p.y - qc[c * 2 + 1];
+      const float d1 = qc_sub(qc, p.y, c * 2 + 1);
       t = __builtin_fmaf(d1, d1, t);
     } else {
-      const float d0 = piv_lds[(uint32_t)NHI * 256u + c * 256u + code] - qc[c * 2 + 0];
+      const float d0 = qc_sub(qc, piv_lds[(uint32_t)NHI * 256u + c * 256u + code], c * 2 + 0);
       t = __builtin_fmaf(d0, d0, t);
     }
     return t;
   }
   const float* e = piv_lds + ((size_t)c * 256 + code) * PSZ;
   if (PSZ == 1) {
-    const float d = e[0] - qc[c];
+    const float d = qc_sub(qc, e[0], c);
     t = __builtin_fmaf(d, d, t);
   } else if (PSZ == 2) {
     const float2 p = *(const float2*)e;
-    const float d0 = p.x - qc[c * 2 + 0];
+    const float d0 = qc_sub(qc, p.x, c * 2 + 0);
     t = __builtin_fmaf(d0, d0, t);
-    const float d1 = p.y - qc[c * 2 + 1];
+    const float d1 = qc_sub(qc, p.y, c * 2 + 1);
     t = __builtin_fmaf(d1, d1, t);
   } else {
 #pragma unroll
     for (int i = 0; i < PSZ; i += 4) {
       const float4 p = *(const float4*)(e + i);
-      const float d0 = p.x - qc[c * PSZ + i + 0];
+      const float d0 = qc_sub(qc, p.x, c * PSZ + i + 0);
       t = __builtin_fmaf(d0, d0, t);
-      const float d1 = p.y - qc[c * PSZ + i + 1];
+      const float d1 = qc_sub(qc, p.y, c * PSZ + i + 1);
       t = __builtin_fmaf(d1, d1, t);
-      const float d2 = p.z - qc[c * PSZ + i + 2];
+      const float d2 = qc_sub(qc, p.z, c * PSZ + i + 2);
       t = __builtin_fmaf(d2, d2, t);
-      const float d3 = p.w - qc[c * PSZ + i + 3];
+      const float d3 = qc_sub(qc, p.w, c * PSZ + i + 3);
       t = __builtin_fmaf(d3, d3, t);
     }
   }

@@ -763,6 +763,12 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 // The stage the BASELINE metric quotes an HBM figure for.  One wave per query row at a time, the NEXT row's ids and code rows in
 // flight while the current one is reduced (two register sets, ping-pong), pivot table in LDS, centred query through scalar loads:
 // the launch is bound by how fast the memory system returns random 32-74-byte rows, not by dependent round trips.
+// Experiment (-DBANG_K2_QC_ROW16=1): the query replicated per 16-lane row and subtracted with a DPP row broadcast (QcRow16,
+// bang_device.h) -- 380 instead of 597 VALU instructions per 64 rows, yet only +1.5 % rows/s (the stage is not VALU-bound), and the
+// DPP instruction is inline asm, outside the compiler's hazard recogniser: not the default.
+#ifndef BANG_K2_QC_ROW16
+#define BANG_K2_QC_ROW16 0
+#endif
 template <int PSZ, int NDW, bool ALIGNED, int NHI, int MAXT>
 __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_params p, uint32_t lds_piv_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -774,7 +780,9 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
   }
-  constexpr int SB = (NDW >= 18) ? 6 : 0;
+  // segments of the row reduce (dependency fence in pq_row_reduce): at most ~32-48 pivot floats in flight per lane
+  constexpr int SB = (NDW >= 18) ? 6 : (BANG_K2_QC_ROW16 && PSZ == 4 && NDW >= 8) ? 2 : (BANG_K2_QC_ROW16 && PSZ == 8 && NDW >= 4) ? 1
+                   : (BANG_K2_QC_ROW16 && PSZ <= 2 && NDW >= 16) ? 4 : 0;
   const int lane = lane_id();
   const uint32_t nwaves = blockDim.x >> 6;
   const uint32_t step = gridDim.x * nwaves;
@@ -782,9 +790,22 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
   if (q >= p.Q) return;
   PqRow<NDW, ALIGNED> rowA, rowB;
   constexpr int QW = NDW * 4 * PSZ;                 // floats of a centred query (padded layout)
+#if BANG_K2_QC_ROW16
+  // the centred query replicated per 16-lane row: "pivot - query" is one v_subrev_f32 with a DPP row broadcast (bang_device.h)
+  constexpr int NV = (QW + 15) / 16;
+  typedef QcRow16<NV> Qc;
+  auto load_qc = [&](Qc& dst, uint32_t qq) {
+    const float* src = p.d_qc + (size_t)qq * QW;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const uint32_t i = (uint32_t)r * 16u + ((uint32_t)lane & 15u);
+      dst.v[r] = src[i < (uint32_t)QW ? i : 0u];
+    }
+  };
+#else
   constexpr int NV = (QW + 63) / 64;
-  QcRegs<NV> qcA, qcB;                              // the centred query in registers: no scalar-load waits inside the reduce
-  auto load_qc = [&](QcRegs<NV>& dst, uint32_t qq) {
+  typedef QcRegs<NV> Qc;                            // the centred query in registers (v_readlane): no scalar-load waits inside the reduce
+  auto load_qc = [&](Qc& dst, uint32_t qq) {
     const float* src = p.d_qc + (size_t)qq * QW;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
@@ -792,6 +813,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
       dst.v[r] = src[i < (uint32_t)QW ? i : 0u];
     }
   };
+#endif
+  Qc qcA, qcB;
   uint32_t nA = uni(p.d_cnt[q]), nB = 0;
   if (nA > 64) nA = 64;
   uint32_t idA = p.d_nbrs[(size_t)q * BANG_NBR_STRIDE + lane], idB = 0;
@@ -809,7 +832,9 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
       if ((uint32_t)lane < nB) pq_row_load(rowB, p.d_codes, p.m, idB);
     }
     {
-      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowA, piv_lds, qcA);     // all lanes: v_readlane needs no exec mask games
+      // all lanes, full EXEC (DPP / v_readlane read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
+      asm volatile("s_nop 4");
+      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowA, piv_lds, qcA);
       if ((uint32_t)lane < nA) p.d_dist[(size_t)q * BANG_NBR_STRIDE + lane] = d;
     }
     if (!hasB) break;
@@ -824,6 +849,7 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
       if ((uint32_t)lane < nA) pq_row_load(rowA, p.d_codes, p.m, idA);
     }
     {
+      asm volatile("s_nop 4");
       const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowB, piv_lds, qcB);
       if ((uint32_t)lane < nB) p.d_dist[(size_t)qB * BANG_NBR_STRIDE + lane] = d;
     }
