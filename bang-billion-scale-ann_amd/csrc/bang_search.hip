@@ -26,6 +26,8 @@
 // Reference line numbers: /root/reference/BANG_Base/bang_search.cu.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -763,6 +765,12 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 // The stage the BASELINE metric quotes an HBM figure for.  One wave per query row at a time, the NEXT row's ids and code rows in
 // flight while the current one is reduced (two register sets, ping-pong), pivot table in LDS, centred query through scalar loads:
 // the launch is bound by how fast the memory system returns random 32-74-byte rows, not by dependent round trips.
+// runs f(integral_constant<0>), f(integral_constant<1>), ... until one returns false
+template <class F, int... I>
+__device__ __forceinline__ bool pipe_trip(F& f, std::integer_sequence<int, I...>) {
+  return (f(std::integral_constant<int, I>{}) && ...);
+}
+
 // Experiment (-DBANG_K2_QC_ROW16=1): the query replicated per 16-lane row and subtracted with a DPP row broadcast (QcRow16,
 // bang_device.h) -- 380 instead of 597 VALU instructions per 64 rows, yet only +1.5 % rows/s (the stage is not VALU-bound), and the
 // DPP instruction is inline asm, outside the compiler's hazard recogniser: not the default.
@@ -786,9 +794,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
   const int lane = lane_id();
   const uint32_t nwaves = blockDim.x >> 6;
   const uint32_t step = gridDim.x * nwaves;
-  uint32_t q = blockIdx.x * nwaves + uni(threadIdx.x >> 6);
+  const uint32_t q = blockIdx.x * nwaves + uni(threadIdx.x >> 6);
   if (q >= p.Q) return;
-  PqRow<NDW, ALIGNED> rowA, rowB;
   constexpr int QW = NDW * 4 * PSZ;                 // floats of a centred query (padded layout)
 #if BANG_K2_QC_ROW16
   // the centred query replicated per 16-lane row: "pivot - query" is one v_subrev_f32 with a DPP row broadcast (bang_device.h)
@@ -814,52 +821,52 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
     }
   };
 #endif
-  Qc qcA, qcB;
-  uint32_t nA = uni(p.d_cnt[q]), nB = 0;
-  if (nA > 64) nA = 64;
-  uint32_t idA = p.d_nbrs[(size_t)q * BANG_NBR_STRIDE + lane], idB = 0;
-  load_qc(qcA, q);
-  if ((uint32_t)lane < nA) pq_row_load(rowA, p.d_codes, p.m, idA);
-  for (;;) {
-    // ---- issue B (the row after A), reduce A
-    const uint32_t qB = q + step;
-    const bool hasB = qB < p.Q;
-    if (hasB) {
-      nB = uni(p.d_cnt[qB]);
-      if (nB > 64) nB = 64;
-      idB = p.d_nbrs[(size_t)qB * BANG_NBR_STRIDE + lane];
-      load_qc(qcB, qB);
-      if ((uint32_t)lane < nB) pq_row_load(rowB, p.d_codes, p.m, idB);
+  // Software pipeline per wave: while row t is reduced, the code rows of rows t+1 .. t+RD-1 are in flight (requested when their ids
+  // had arrived) and so are the ids, count and centred query of row t+RD -- no step waits for a dependent round trip.  Code-row
+  // buffers rotate by RD, the {ids, count, query} slots by RD + 1; the steps are generated with compile-time slot numbers
+  // (RD (RD + 1) of them per trip of the loop) so that everything stays in registers.
+  // (RD = 3 measured the same as 2 for every layout, at 8 and at 16 waves per CU: the memory system is full with two)
+  constexpr int RD = 2, SD = RD + 1;
+  PqRow<NDW, ALIGNED> row[RD];
+  Qc qc[SD];
+  uint32_t ids[SD], cnt[SD], qq[SD];
+  bool has[SD];
+  uint32_t qnext = q;
+  auto load_ids = [&](int s) {
+    has[s] = qnext < p.Q;
+    if (has[s]) {
+      qq[s] = qnext;
+      cnt[s] = p.d_cnt[qnext];                        // (same address in every lane: no readfirstlane, which would wait for the load here)
+      ids[s] = p.d_nbrs[(size_t)qnext * BANG_NBR_STRIDE + lane];
+      load_qc(qc[s], qnext);
     }
-    {
-      // all lanes, full EXEC (DPP / v_readlane read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
-      asm volatile("s_nop 4");
-      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowA, piv_lds, qcA);
-      if ((uint32_t)lane < nA) p.d_dist[(size_t)q * BANG_NBR_STRIDE + lane] = d;
-    }
-    if (!hasB) break;
-    // ---- issue A (the row after B), reduce B
-    q = qB + step;
-    const bool hasA = q < p.Q;
-    if (hasA) {
-      nA = uni(p.d_cnt[q]);
-      if (nA > 64) nA = 64;
-      idA = p.d_nbrs[(size_t)q * BANG_NBR_STRIDE + lane];
-      load_qc(qcA, q);
-      if ((uint32_t)lane < nA) pq_row_load(rowA, p.d_codes, p.m, idA);
-    }
-    {
-      asm volatile("s_nop 4");
-      const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(rowB, piv_lds, qcB);
-      if ((uint32_t)lane < nB) p.d_dist[(size_t)qB * BANG_NBR_STRIDE + lane] = d;
-    }
-    if (!hasA) break;
-  }
+    qnext += step;
+  };
+  auto load_rows = [&](int s, int r) {
+    if (has[s] && (uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) pq_row_load(row[r], p.d_codes, p.m, ids[s]);
+  };
+#pragma unroll
+  for (int i = 0; i < RD; ++i) load_ids(i);
+#pragma unroll
+  for (int i = 0; i < RD - 1; ++i) load_rows(i, i);
+  auto pipe_step = [&](auto U) -> bool {              // one pipeline step with compile-time slot numbers
+    constexpr int u = decltype(U)::value, s = u % SD, r = u % RD;
+    load_ids((s + RD) % SD);
+    load_rows((s + RD - 1) % SD, (r + RD - 1) % RD);
+    if (!has[s]) return false;                        // (queries are handed out in increasing order: nothing behind this one)
+    // all lanes, full EXEC (v_readlane / DPP read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
+    asm volatile("s_nop 4");
+    const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[r], piv_lds, qc[s]);
+    if ((uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) p.d_dist[(size_t)qq[s] * BANG_NBR_STRIDE + lane] = d;
+    return true;
+  };
+  for (;;)
+    if (!pipe_trip(pipe_step, std::make_integer_sequence<int, RD * SD>{})) return;
 }
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  constexpr int MAXT = (NDW >= 18) ? 512 : 1024;          // two long rows in flight need the 256-VGPR budget
+  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? 512 : 1024;   // two long rows in flight need the 256-VGPR budget
   static bool attr_done[BANG_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
