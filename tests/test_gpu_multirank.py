@@ -22,9 +22,9 @@ def _free_port():
     return p
 
 
-def _bench(nproc, extra, timeout=380):
+def _bench(nproc, extra, timeout=380, workload="tiny", L=46):
     env = dict(os.environ, BANG_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    base = ["bench.py", "--gpus", str(nproc), "--workload", "tiny", "--L", "46", "--steps", "2", "--warmup", "1",
+    base = ["bench.py", "--gpus", str(nproc), "--workload", workload, "--L", str(L), "--steps", "2", "--warmup", "1",
             "--no-cpu-baseline", "--no-legs", "--backend", "gloo"] + extra
     if nproc == 1:
         cmd = [sys.executable] + base
@@ -64,3 +64,17 @@ def test_two_ranks_throughput_mode(libbang):
     two = _bench(2, ["--graph", "device", "--batches", "2"])
     assert two["scaling"] == "weak" and two["config"]["batches_per_step"] == 2
     assert two["config"]["parity_vs_oracle_first_64"] is True
+
+
+def test_two_ranks_streamed_sift1b_shape_share_one_rows_file(libbang):
+    """configs[4] in small: the SIFT1B-shape index loaded by STREAMING on every rank (no graph image anywhere), ONE pull-rows file
+    for the node -- rank 0 builds it while its entries stream through, rank 1 maps it and checks its signature at the end of its
+    own stream -- and the sharded batch answers with the properties the single-rank run has."""
+    args = ["--shape-n", "12000000", "--queries", "512"]
+    one = _bench(1, args, workload="sift1b_shape", L=40)
+    two = _bench(2, args, workload="sift1b_shape", L=40)
+    for r in (one, two):
+        c = r["config"]
+        assert c["result_properties_ok"] is True and c["graph"] == "host" and "pulled" in c["host_loop"], c
+        assert "STREAMED" in c["workload"] and "N=12000000" in c["workload"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
