@@ -289,6 +289,7 @@ struct bang_engine {
   void* entry_ctx = nullptr;
   std::string graph_path;              // file loads: `<p>_disk.bin`, mapped only if a walker form ever needs the entries
   bool graph_streamed = false;         // loaded without a resident graph (graph == nullptr): only the pull mode can run as is
+  bool entry_src_rereadable = false;   // the entry source is ours (a file): placements that need the whole graph may read it all
   const uint32_t* d_adj = nullptr;     // device address of h_adj
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
@@ -613,6 +614,68 @@ static int file_entry_source(void* ctx, uint64_t first, uint64_t count, uint8_t*
   return 0;
 }
 
+// DiskANN's own `_disk.index` as an entry source: what the reference's bang_preprocess.py does up front (:28-116) happens while the
+// entries stream through -- sector 0 is the header, every following 4096-byte sector holds nnodes_per_sector records of
+// max_node_len bytes [T vec[D]][u32 degree][u32 id x R]; a record's ids are copied in ascending order (:102-104).
+struct DiskAnnSource {
+  int fd = -1;
+  uint64_t npts = 0, ndims = 0, medoid = 0, max_node_len = 0, per_sector = 0;
+  uint64_t vec_bytes = 0, R = 0;
+  std::vector<uint8_t> buf;
+};
+static int diskann_entry_source(void* ctx, uint64_t first, uint64_t count, uint8_t* dst) {
+  DiskAnnSource* f = (DiskAnnSource*)ctx;
+  const uint64_t SECTOR = 4096, el = f->max_node_len;
+  uint64_t done = 0;
+  while (done < count) {
+    const uint64_t node = first + done, sec = node / f->per_sector, in_sec = node % f->per_sector;
+    const uint64_t secs = std::min<uint64_t>(2048, (count - done + in_sec + f->per_sector - 1) / f->per_sector);     // up to 8 MB per read
+    f->buf.resize((size_t)(secs * SECTOR));
+    size_t left = f->buf.size();
+    off_t off = (off_t)((1 + sec) * SECTOR);
+    uint8_t* b = f->buf.data();
+    while (left) {
+      const ssize_t r = pread(f->fd, b, left, off);
+      if (r < 0) return -1;
+      if (r == 0) { memset(b, 0, left); break; }               // (a short last sector)
+      b += r; off += r; left -= (size_t)r;
+    }
+    for (uint64_t s = 0; s < secs && done < count; ++s)
+      for (uint64_t k = (s == 0 ? in_sec : 0); k < f->per_sector && done < count; ++k, ++done) {
+        const uint8_t* rec = f->buf.data() + s * SECTOR + k * el;
+        uint8_t* out = dst + done * el;
+        memcpy(out, rec, (size_t)el);
+        uint32_t deg;
+        memcpy(&deg, rec + f->vec_bytes, 4);
+        if (deg == 0 || deg > f->R) return -2;                  // bang_preprocess.py:91-94
+        uint32_t ids[BANG_MAX_R];
+        memcpy(ids, rec + f->vec_bytes + 4, (size_t)deg * 4);
+        std::sort(ids, ids + deg);
+        memcpy(out + f->vec_bytes + 4, ids, (size_t)deg * 4);
+      }
+  }
+  return 0;
+}
+
+// a resident private copy of the graph, filled from the entry source (placements that walk or upload the whole graph)
+static int materialize_graph(bang_engine* e) {
+  const size_t gsize = (size_t)e->N * e->entry_len;
+  void* gp = nullptr;
+  if (posix_memalign(&gp, (size_t)2 << 20, gsize) != 0 || !gp) { bang_set_error("malloc(%zu) failed", gsize); return BANG_ERR_NOMEM; }
+  (void)madvise(gp, gsize, MADV_HUGEPAGE);
+  e->graph_owned = (uint8_t*)gp;
+  const size_t chunk = std::max<size_t>(1024, ((size_t)256 << 20) / e->entry_len);
+  for (size_t first = 0; first < e->N; first += chunk) {
+    const size_t n = std::min(chunk, (size_t)e->N - first);
+    if (e->entry_fn(e->entry_ctx, first, n, e->graph_owned + first * e->entry_len) != 0) {
+      bang_set_error("the entry source failed at node %zu", first);
+      return BANG_ERR_IO;
+    }
+  }
+  e->graph = e->graph_owned;
+  return BANG_OK;
+}
+
 // The graph file in host memory, MAPPED shared and read-only, not copied: the ranks of a multi-GPU job (one process per GPU) walk
 // ONE copy in the page cache instead of one 388 GB copy each (:312-328).  MAP_POPULATE reads the file in now, as the reference's
 // fread does.  BANG_GRAPH_MMAP=0 (or a failing mmap) falls back to a private copy, which can ask for transparent huge pages.
@@ -731,7 +794,7 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
     const bool feasible = e->graph_mode != BANG_GRAPH_DEVICE && stream_feasible(e, hbm_reserve, &why);
     const bool from_file = (e->entry_fn == nullptr);
     static const bool want_stream = !(getenv("BANG_STREAM_LOAD") && atoi(getenv("BANG_STREAM_LOAD")) == 0);
-    if (!from_file && !feasible) {
+    if (!from_file && !feasible && !e->entry_src_rereadable) {
       bang_set_error("a streamed load runs in pull mode on the host placement only: %s", why.empty() ? "option graph = device" : why.c_str());
       return BANG_ERR_UNSUPPORTED;
     }
@@ -746,11 +809,12 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       const int rc = stage_entries_streamed(e);
       if (from_file) { close(fsrc.fd); e->entry_fn = nullptr; e->entry_ctx = nullptr; }
       if (rc == BANG_OK) { e->loaded = true; return BANG_OK; }
-      if (!(from_file && rc == BANG_ERR_NOMEM && e->pull_opt != 1)) return rc;
+      if (!((from_file || e->entry_src_rereadable) && rc == BANG_ERR_NOMEM && e->pull_opt != 1)) return rc;
       dfree(e->d_vecs);                               // the rows do not fit this host: keep the graph resident, the walker serves it
       e->vec_on_device = false;
     }
-    BANG_TRY(map_graph_file(e));
+    if (e->entry_fn) BANG_TRY(materialize_graph(e));  // (a DiskANN `_disk.index`: converted into a private resident copy)
+    else BANG_TRY(map_graph_file(e));
   }
   BANG_TRY(stage_medoid(e, e->graph + e->medoid * e->entry_len));
   e->vec_on_device = false;
@@ -951,9 +1015,15 @@ int load_files(bang_engine* e, const char* prefix) {
   FILE* fc = fopen(f_cmp.c_str(), "rb");
   if (!fc) { fclose(fp); printf("Error.. Could not open the PQ Compressed Vectors File: %s\n", f_cmp.c_str()); bang_set_error("cannot open %s", f_cmp.c_str()); return BANG_ERR_IO; }
   FILE* fg = fopen(f_graph.c_str(), "rb");
-  if (!fg) { fclose(fp); fclose(fc); printf("Error.. Could not open the Graph Index File: %s\n", f_graph.c_str()); bang_set_error("cannot open %s", f_graph.c_str()); return BANG_ERR_IO; }
-  FILE* fm = fopen(f_meta.c_str(), "rb");
-  if (!fm) { fclose(fp); fclose(fc); fclose(fg); printf("Error.. Could not open the Metadata File: %s\n", f_meta.c_str()); bang_set_error("cannot open %s", f_meta.c_str()); return BANG_ERR_IO; }
+  FILE* fm = fg ? fopen(f_meta.c_str(), "rb") : nullptr;
+  DiskAnnSource dsrc;
+  if (!fg) {
+    // no converted graph: DiskANN's own `<p>_disk.index` is read directly (what bang_preprocess.py would have written is produced
+    // while the entries stream through)
+    const std::string f_index = p + "_disk.index";
+    dsrc.fd = open(f_index.c_str(), O_RDONLY);
+    if (dsrc.fd < 0) { fclose(fp); fclose(fc); printf("Error.. Could not open the Graph Index File: %s\n", f_graph.c_str()); bang_set_error("cannot open %s (nor %s)", f_graph.c_str(), f_index.c_str()); return BANG_ERR_IO; }
+  } else if (!fm) { fclose(fp); fclose(fc); fclose(fg); printf("Error.. Could not open the Metadata File: %s\n", f_meta.c_str()); bang_set_error("cannot open %s", f_meta.c_str()); return BANG_ERR_IO; }
   int rc = BANG_OK;
   std::vector<uint8_t> codes;
   std::vector<float> pivots, centroid;
@@ -961,14 +1031,28 @@ int load_files(bang_engine* e, const char* prefix) {
   do {
     // 32-byte packed metadata {u64 medoid, u64 entryLen, i32 dtype, u32 D, u32 R, u32 N} (bang_search.cuh:42-50)
     uint8_t md[32];
+    int32_t md_dtype = -1;
+    if (!fg) {
+      // `_disk.index` header (bang_preprocess.py:28-64): skip 8 B; u64 npts, ndims, medoid, max_node_len, nnodes_per_sector
+      uint64_t h[5];
+      if (pread(dsrc.fd, h, 40, 8) != 40 || h[0] == 0 || h[0] > 0xFFFFFFFFull || h[4] == 0) { bang_set_error("bad _disk.index header"); rc = BANG_ERR_IO; break; }
+      dsrc.npts = h[0]; dsrc.ndims = h[1]; dsrc.medoid = h[2]; dsrc.max_node_len = h[3]; dsrc.per_sector = h[4];
+      dsrc.vec_bytes = dsrc.ndims * e->tsize;
+      if (dsrc.max_node_len < dsrc.vec_bytes + 8 || (dsrc.max_node_len - dsrc.vec_bytes - 4) % 4 != 0 || dsrc.per_sector * dsrc.max_node_len > 4096) {
+        bang_set_error("_disk.index: record length %llu does not fit D=%llu elements of %zu B (wrong data type?)", (unsigned long long)dsrc.max_node_len, (unsigned long long)dsrc.ndims, e->tsize);
+        rc = BANG_ERR_IO; break;
+      }
+      dsrc.R = (dsrc.max_node_len - dsrc.vec_bytes - 4) / 4;
+      e->medoid = dsrc.medoid; e->entry_len = dsrc.max_node_len; e->D = (uint32_t)dsrc.ndims; e->R = (uint32_t)dsrc.R; e->N = (uint32_t)dsrc.npts;
+    } else {
     if (!read_exact(fm, md, 32)) { bang_set_error("short metadata file"); rc = BANG_ERR_IO; break; }
     memcpy(&e->medoid, md, 8);
     memcpy(&e->entry_len, md + 8, 8);
-    int32_t md_dtype = -1;
     memcpy(&md_dtype, md + 16, 4);
     memcpy(&e->D, md + 20, 4);
     memcpy(&e->R, md + 24, 4);
     memcpy(&e->N, md + 28, 4);
+    }
     // The reference never looks at uDatatype (bang_search.cu:180-188) and a wrong <data type> argument makes it read vectors and
     // adjacency lists at the wrong offsets.  bang_preprocess.py:12-13 writes 0 = int8, 1 = uint8, 2 = float: refuse an index whose
     // code or entry length contradicts the element type of this engine.
@@ -1013,15 +1097,24 @@ int load_files(bang_engine* e, const char* prefix) {
     ok = ok && read_exact(fp, chunk_off.data(), chunk_off.size() * 4);
     if (!ok) { bang_set_error("pivots file: short section"); rc = BANG_ERR_IO; break; }
     // graph + full-precision vectors (:312-328): only checked here; upload_index streams the file (pull mode) or maps it
-    fseek(fg, 0, SEEK_END);
-    const size_t gsize = (size_t)ftell(fg);
-    fseek(fg, 0, SEEK_SET);
-    if (gsize < (size_t)e->N * e->entry_len) { bang_set_error("graph file too small"); rc = BANG_ERR_IO; break; }
-    e->graph_path = f_graph;
     e->graph = nullptr;
+    if (fg) {
+      fseek(fg, 0, SEEK_END);
+      const size_t gsize = (size_t)ftell(fg);
+      fseek(fg, 0, SEEK_SET);
+      if (gsize < (size_t)e->N * e->entry_len) { bang_set_error("graph file too small"); rc = BANG_ERR_IO; break; }
+      e->graph_path = f_graph;
+    } else {
+      e->graph_path.clear();
+      e->entry_fn = diskann_entry_source; e->entry_ctx = &dsrc; e->entry_src_rereadable = true;
+    }
   } while (0);
-  fclose(fp); fclose(fc); fclose(fg); fclose(fm);
+  fclose(fp); fclose(fc);
+  if (fg) fclose(fg);
+  if (fm) fclose(fm);
   if (rc != BANG_OK) {
+    if (dsrc.fd >= 0) close(dsrc.fd);
+    e->entry_fn = nullptr; e->entry_ctx = nullptr; e->entry_src_rereadable = false;
     free(e->graph_owned); e->graph_owned = nullptr;
     if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
     e->graph_map = nullptr; e->graph_map_len = 0;
@@ -1029,6 +1122,8 @@ int load_files(bang_engine* e, const char* prefix) {
     return rc;
   }
   rc = upload_index(e, codes.data(), nullptr, pivots.data(), centroid.data(), chunk_off.data());
+  if (dsrc.fd >= 0) close(dsrc.fd);
+  e->entry_fn = nullptr; e->entry_ctx = nullptr; e->entry_src_rereadable = false;
   if (rc != BANG_OK) unload_index(e);
   return rc;
 }

@@ -531,3 +531,36 @@ def test_streamed_load_shares_and_checks_the_rows_file(libbang, small_u8, small_
     path.write_bytes(bytes(blob))
     with pytest.raises(bang_amd.BangError, match="another index"):            # a streamed load cannot rebuild behind itself: loud
         run(ix)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["small_u8", "small_f32", "small_i8"])
+def test_bang_load_reads_a_diskann_index_directly(request, libbang, fixture, tmp_path):
+    """No `_disk.bin` / `_disk_metadata.bin`: bang_load takes DiskANN's own sector-padded `<p>_disk.index` (shuffled adjacency
+    lists, garbage behind them) and does the reference's preprocessing on the fly -- streamed in pull mode, converted into a
+    resident copy for the placements that walk or upload the whole graph.  Same bits as the oracle on the converted index."""
+    import os
+    import bang_amd
+    from bang_amd import formats
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q = q.shape[0]
+    prefix = str(tmp_path / "raw")
+    formats.write_index(prefix, ix)
+    os.remove(prefix + "_disk.bin")
+    os.remove(prefix + "_disk_metadata.bin")
+    formats.write_diskann_index(prefix + "_disk.index", ix.vectors(), ix.degrees(), ix.adjacency(), ix.medoid, pad_garbage=True)
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 40)
+    for opts, pulled in ((dict(graph=0), 1), (dict(graph=0, pull=0), 0), (dict(graph=1), 0), (dict(graph=0, persistent=0), 0)):
+        with bang_amd.Engine(ix.dtype, **opts) as e:
+            e.load(prefix)
+            e.set_searchparams(10, 40)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            assert e.stats()["graph_pull"] == pulled, opts
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), opts
+    wrong = "float" if ix.dtype != "float" else "uint8"
+    with bang_amd.Engine(wrong, graph=0) as e:                      # the record length does not fit the element size: refused
+        with pytest.raises(bang_amd.BangError):
+            e.load(prefix)
