@@ -657,6 +657,60 @@ static int diskann_entry_source(void* ctx, uint64_t first, uint64_t count, uint8
   return 0;
 }
 
+// `_disk.index` header (bang_preprocess.py:28-64): skip 8 B; u64 npts, ndims, medoid, max_node_len, nnodes_per_sector
+static int diskann_open(DiskAnnSource& d, const char* path, size_t tsize) {
+  d.fd = open(path, O_RDONLY);
+  if (d.fd < 0) { bang_set_error("cannot open %s", path); return BANG_ERR_IO; }
+  uint64_t h[5];
+  if (pread(d.fd, h, 40, 8) != 40 || h[0] == 0 || h[0] > 0xFFFFFFFFull || h[4] == 0) { bang_set_error("bad _disk.index header"); return BANG_ERR_IO; }
+  d.npts = h[0]; d.ndims = h[1]; d.medoid = h[2]; d.max_node_len = h[3]; d.per_sector = h[4];
+  d.vec_bytes = d.ndims * tsize;
+  if (d.max_node_len < d.vec_bytes + 8 || (d.max_node_len - d.vec_bytes - 4) % 4 != 0 || d.per_sector * d.max_node_len > 4096) {
+    bang_set_error("_disk.index: record length %llu does not fit D=%llu elements of %zu B (wrong data type?)", (unsigned long long)d.max_node_len, (unsigned long long)d.ndims, tsize);
+    return BANG_ERR_IO;
+  }
+  d.R = (d.max_node_len - d.vec_bytes - 4) / 4;
+  if (d.R > BANG_MAX_R) { bang_set_error("_disk.index: degree bound R=%llu unsupported (max %d)", (unsigned long long)d.R, BANG_MAX_R); return BANG_ERR_UNSUPPORTED; }
+  return BANG_OK;
+}
+
+extern "C" int bang_convert_diskann_index(const char* index_path, const char* out_prefix, int dtype) {
+  if (!index_path || !out_prefix || dtype < 0 || dtype > 2) return BANG_ERR_ARG;
+  DiskAnnSource d;
+  const size_t tsize = (dtype == BANG_F32) ? 4 : 1;
+  int rc = diskann_open(d, index_path, tsize);
+  FILE* fb = nullptr;
+  FILE* fm = nullptr;
+  if (rc == BANG_OK) {
+    const std::string pfx(out_prefix);
+    fb = fopen((pfx + "_disk.bin").c_str(), "wb");
+    fm = fopen((pfx + "_disk_metadata.bin").c_str(), "wb");
+    if (!fb || !fm) { bang_set_error("cannot create %s_disk.bin / _disk_metadata.bin", out_prefix); rc = BANG_ERR_IO; }
+  }
+  if (rc == BANG_OK) {
+    const size_t chunk = std::max<size_t>(1024, ((size_t)64 << 20) / d.max_node_len);
+    std::vector<uint8_t> buf(chunk * d.max_node_len);
+    for (uint64_t first = 0; first < d.npts && rc == BANG_OK; first += chunk) {
+      const uint64_t n = std::min<uint64_t>(chunk, d.npts - first);
+      const int sr = diskann_entry_source(&d, first, n, buf.data());
+      if (sr != 0) { bang_set_error(sr == -2 ? "bad degree in index (bang_preprocess.py:91-94)" : "read error in %s", index_path); rc = BANG_ERR_IO; break; }
+      if (fwrite(buf.data(), d.max_node_len, n, fb) != n) { bang_set_error("short write"); rc = BANG_ERR_IO; }
+    }
+  }
+  if (rc == BANG_OK) {
+    static const int32_t code_of[3] = {1 /*BANG_U8*/, 0 /*BANG_I8*/, 2 /*BANG_F32*/};      // bang_preprocess.py:12-13
+    uint8_t md[32];
+    const uint32_t D = (uint32_t)d.ndims, R = (uint32_t)d.R, N = (uint32_t)d.npts;
+    memcpy(md, &d.medoid, 8); memcpy(md + 8, &d.max_node_len, 8); memcpy(md + 16, &code_of[dtype], 4);
+    memcpy(md + 20, &D, 4); memcpy(md + 24, &R, 4); memcpy(md + 28, &N, 4);
+    if (fwrite(md, 32, 1, fm) != 1) { bang_set_error("short write"); rc = BANG_ERR_IO; }
+  }
+  if (fb) fclose(fb);
+  if (fm) fclose(fm);
+  if (d.fd >= 0) close(d.fd);
+  return rc;
+}
+
 // a resident private copy of the graph, filled from the entry source (placements that walk or upload the whole graph)
 static int materialize_graph(bang_engine* e) {
   const size_t gsize = (size_t)e->N * e->entry_len;
@@ -1021,8 +1075,13 @@ int load_files(bang_engine* e, const char* prefix) {
     // no converted graph: DiskANN's own `<p>_disk.index` is read directly (what bang_preprocess.py would have written is produced
     // while the entries stream through)
     const std::string f_index = p + "_disk.index";
-    dsrc.fd = open(f_index.c_str(), O_RDONLY);
-    if (dsrc.fd < 0) { fclose(fp); fclose(fc); printf("Error.. Could not open the Graph Index File: %s\n", f_graph.c_str()); bang_set_error("cannot open %s (nor %s)", f_graph.c_str(), f_index.c_str()); return BANG_ERR_IO; }
+    const int orc = diskann_open(dsrc, f_index.c_str(), e->tsize);
+    if (orc != BANG_OK) {
+      if (dsrc.fd < 0) { printf("Error.. Could not open the Graph Index File: %s\n", f_graph.c_str()); bang_set_error("cannot open %s (nor %s)", f_graph.c_str(), f_index.c_str()); }
+      else close(dsrc.fd);
+      fclose(fp); fclose(fc);
+      return orc;
+    }
   } else if (!fm) { fclose(fp); fclose(fc); fclose(fg); printf("Error.. Could not open the Metadata File: %s\n", f_meta.c_str()); bang_set_error("cannot open %s", f_meta.c_str()); return BANG_ERR_IO; }
   int rc = BANG_OK;
   std::vector<uint8_t> codes;
@@ -1033,16 +1092,6 @@ int load_files(bang_engine* e, const char* prefix) {
     uint8_t md[32];
     int32_t md_dtype = -1;
     if (!fg) {
-      // `_disk.index` header (bang_preprocess.py:28-64): skip 8 B; u64 npts, ndims, medoid, max_node_len, nnodes_per_sector
-      uint64_t h[5];
-      if (pread(dsrc.fd, h, 40, 8) != 40 || h[0] == 0 || h[0] > 0xFFFFFFFFull || h[4] == 0) { bang_set_error("bad _disk.index header"); rc = BANG_ERR_IO; break; }
-      dsrc.npts = h[0]; dsrc.ndims = h[1]; dsrc.medoid = h[2]; dsrc.max_node_len = h[3]; dsrc.per_sector = h[4];
-      dsrc.vec_bytes = dsrc.ndims * e->tsize;
-      if (dsrc.max_node_len < dsrc.vec_bytes + 8 || (dsrc.max_node_len - dsrc.vec_bytes - 4) % 4 != 0 || dsrc.per_sector * dsrc.max_node_len > 4096) {
-        bang_set_error("_disk.index: record length %llu does not fit D=%llu elements of %zu B (wrong data type?)", (unsigned long long)dsrc.max_node_len, (unsigned long long)dsrc.ndims, e->tsize);
-        rc = BANG_ERR_IO; break;
-      }
-      dsrc.R = (dsrc.max_node_len - dsrc.vec_bytes - 4) / 4;
       e->medoid = dsrc.medoid; e->entry_len = dsrc.max_node_len; e->D = (uint32_t)dsrc.ndims; e->R = (uint32_t)dsrc.R; e->N = (uint32_t)dsrc.npts;
     } else {
     if (!read_exact(fm, md, 32)) { bang_set_error("short metadata file"); rc = BANG_ERR_IO; break; }

@@ -100,6 +100,12 @@ int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* desc);
  * where the pull mode is not possible -- vectors that do not fit HBM, rows that do not fit the host, R > 64, option pull = 0 --
  * because nothing else can run without the graph.  bang_load_e streams `<p>_disk.bin` through the same path when the pull mode
  * applies (BANG_STREAM_LOAD=0: map the file as before); should a walker form be asked for later, the file is mapped then. */
+/* The reference's preprocessing step as a library call (host only, no device needed): DiskANN's sector-padded `_disk.index` ->
+ * `<out_prefix>_disk.bin` + `<out_prefix>_disk_metadata.bin`, byte for byte what BANG_Base/bang_preprocess.py writes (header parse
+ * :28-64, sector walk :75-80, ascending adjacency lists :81-109, metadata :42-51,116).  dtype: BANG_U8 / BANG_I8 / BANG_F32.
+ * bang_load_e does the same conversion on the fly when only the `_disk.index` exists. */
+int bang_convert_diskann_index(const char* index_path, const char* out_prefix, int dtype);
+
 typedef int (*bang_entry_source)(void* ctx, uint64_t first, uint64_t count, uint8_t* dst);
 int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* desc, bang_entry_source src, void* ctx);
 

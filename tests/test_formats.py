@@ -135,3 +135,23 @@ def test_converter_matches_reference_preprocess(tmp_path, dtype, D, R, N):
     assert deg.min() == 1 and deg.max() == R
     for i in range(N):
         assert (np.diff(adj[i, :deg[i]].astype(np.int64)) > 0).all()          # sorted ascending by the reference (:102-104)
+
+
+@pytest.mark.parametrize("dtype,D,R,N", [("uint8", 24, 12, 130), ("int8", 16, 8, 170), ("float", 12, 8, 101)])
+def test_native_converter_matches_reference_preprocess(tmp_path, dtype, D, R, N):
+    """PIN: bang_convert_diskann_index (libbang, host only) -- the conversion bang_load also runs on the fly when it is handed a raw
+    `_disk.index` -- reproduces the outputs of the REFERENCE's bang_preprocess.py (tests/golden/pre_*) byte for byte."""
+    import ctypes as C
+    import os
+    import bang_amd
+    from bang_amd import binding
+    bang_amd.build()
+    lib = binding.lib()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"pre_{dtype}")
+    out = str(tmp_path / "n")
+    lib.bang_convert_diskann_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    rc = lib.bang_convert_diskann_index((gold + "_disk.index").encode(), out.encode(), binding.DTYPE_CODE[dtype])
+    assert rc == 0, lib.bang_last_error()
+    assert open(out + "_disk.bin", "rb").read() == open(gold + "_disk.bin", "rb").read()
+    assert open(out + "_disk_metadata.bin", "rb").read() == open(gold + "_disk_metadata.bin", "rb").read()
+    assert lib.bang_convert_diskann_index(b"/nonexistent", out.encode(), 0) != 0
