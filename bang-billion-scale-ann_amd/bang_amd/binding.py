@@ -55,7 +55,7 @@ class SearchParams(C.Structure):
         ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
-        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p),
+        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("d_qskip", C.c_void_p),
     ]
 
 
@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("persistent", C.c_uint64), ("h2d_bytes", C.c_uint64), ("vectors_on_device", C.c_uint64),
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
-                ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64)]
+                ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64),
+                ("filter_loads_skipped", C.c_uint64)]
 
 
 ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source
@@ -236,6 +237,14 @@ class Engine:
         dists = dists_out if dists_out is not None else np.empty((self.k, Q), dtype=np.float32)
         _check(lib().bang_query_e(self._h, _vp(q), Q, _vp(ids), _vp(dists)), "bang_query")
         return ids, dists
+
+    def query_dev(self, queries: np.ndarray, d_ids: int, d_dists: int = 0):
+        """bang_query_dev_e: the result ids [Q][k] u64 (and, if d_dists != 0, the distances [k][Q] f32) are written to DEVICE buffers of
+        the caller (raw device addresses, e.g. torch.Tensor.data_ptr()); nothing returns to the host."""
+        q = np.ascontiguousarray(queries, dtype=NP_DTYPE[self.dtype])
+        fn = lib().bang_query_dev_e
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _check(fn(self._h, _vp(q), q.shape[0], C.c_void_p(d_ids), C.c_void_p(d_dists) if d_dists else None), "bang_query_dev")
 
     def stats(self) -> dict:
         s = Stats()

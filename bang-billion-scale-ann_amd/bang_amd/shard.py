@@ -31,3 +31,38 @@ def gather_ids(ids_local: np.ndarray, Q: int, k: int, rank: int, world: int, dev
         a, b = shard_range(Q, r, world)
         out[a:b] = allv[r * pad: r * pad + (b - a)]
     return out
+
+
+class DeviceGather:
+    """The collective of a sharded step with the ids never leaving device memory: the engine writes this rank's [Q/W][k] block into
+    `mine` (bang_query_dev_e), ONE all_gather_into_tensor (RCCL over xGMI) fills `all` on every rank, and only the rank that hands
+    the batch's answer to its caller copies the gathered block to the host (once).  Buffers are allocated once per allocation, not per step."""
+
+    def __init__(self, Q: int, k: int, rank: int, world: int, device):
+        import torch
+        self.Q, self.k, self.rank, self.world = Q, k, rank, world
+        self.pad = (Q + world - 1) // world
+        self.q0, self.q1 = shard_range(Q, rank, world)
+        self.mine = torch.zeros((self.pad, k), dtype=torch.int64, device=device)
+        self.all = torch.empty((world * self.pad, k), dtype=torch.int64, device=device)
+        self.dists = torch.zeros((k, self.q1 - self.q0), dtype=torch.float32, device=device)   # this rank's distances [k][Q/W] (not gathered)
+
+    def gather(self):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.all, self.mine)
+        return self.all
+
+    def local_ids(self) -> np.ndarray:
+        return self.mine[: self.q1 - self.q0].cpu().numpy().view(np.uint64)
+
+    def local_dists(self) -> np.ndarray:
+        return self.dists.cpu().numpy()
+
+    def batch_ids(self) -> np.ndarray:
+        """[Q][k] u64 on the host, from the gathered block (one D2H copy)."""
+        allv = self.all.cpu().numpy().view(np.uint64)
+        out = np.empty((self.Q, self.k), dtype=np.uint64)
+        for r in range(self.world):
+            a, b = shard_range(self.Q, r, self.world)
+            out[a:b] = allv[r * self.pad: r * self.pad + (b - a)]
+        return out

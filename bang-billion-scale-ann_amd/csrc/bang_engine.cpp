@@ -152,6 +152,8 @@ struct Pool {                       // persistent lane threads, woken once per b
   const void* h_queries = nullptr;
   uint64_t* h_ids = nullptr;
   float* h_dists = nullptr;
+  uint64_t* d_ids_user = nullptr;    // bang_query_dev_e: the results stay on the device, in the caller's buffers
+  float* d_dists_user = nullptr;
   int Q = 0;
   std::vector<std::thread> lane_threads;
 };
@@ -266,6 +268,7 @@ struct bang_engine {
   uint32_t* d_pub_q = nullptr;         // device aliases
   uint32_t* d_pub_c = nullptr;
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
+  uint32_t* d_qskip = nullptr;         // [Q] filter-word loads saved by the on-chip summary (search kernel, self-paced)
   std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
   int pq_ragged = 1;                   // 2-float PQ layouts: exact-size pivot table where possible (0 = always the padded table)
@@ -363,22 +366,31 @@ static size_t host_bytes_available() {
 // One copy per NODE when BANG_PULL_ROWS_DIR names a directory every rank can see (tmpfs): the rows live in the file
 // <dir>/<index name>_pull_rows.bin, built by whichever rank loads first (write to a temporary name, rename) and mapped shared by
 // the others; every rank registers the mapping with its own device.  Without the variable: private anonymous memory.
-struct PullRowsSig { char magic[8]; uint64_t N, medoid, R, sample_hash; };
-// what a rows file must match: sizes, medoid and the adjacency lists of 64 nodes spread over the index (folded in node order)
-static inline size_t sig_sample_node(const bang_engine* e, uint32_t t) { return (size_t)((unsigned __int128)e->N * t / 64); }
-static inline void sig_fold(const bang_engine* e, uint64_t& h, const uint8_t* adj /* [u32 degree][u32 id x R] */) {
+struct PullRowsSig { char magic[8]; uint64_t N, medoid, R, adj_hash; };
+// What a rows file must match: sizes, medoid and EVERY adjacency list.  A node's list is hashed together with its number
+// (word-wise FNV-style over {node, degree, ids}, then a finaliser) and the node hashes are ADDED: order independent, so the threads
+// that split a chunk (or the whole graph) hash their slices on their own and the sums combine.  An index rebuilt or edited in place
+// with the same N / R / medoid therefore never inherits another graph's rows.
+static inline uint64_t sig_node(const bang_engine* e, uint64_t node, const uint8_t* adj /* [u32 degree][u32 id x R] */) {
   uint32_t deg;
   memcpy(&deg, adj, 4);
   if (deg > e->R) deg = e->R;
-  for (size_t b = 0; b < 4 + (size_t)deg * 4; ++b) h = (h ^ adj[b]) * 0x100000001b3ull;
+  uint64_t h = (0xcbf29ce484222325ull ^ node) * 0x100000001b3ull;
+  h = (h ^ deg) * 0x100000001b3ull;
+  for (uint32_t k = 0; k < deg; ++k) {
+    uint32_t id;
+    memcpy(&id, adj + 4 + 4 * (size_t)k, 4);
+    h = (h ^ id) * 0x100000001b3ull;
+  }
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  return h;
 }
 static PullRowsSig sig_make(const bang_engine* e, uint64_t h) {
   PullRowsSig g;
-  memcpy(g.magic, "BANGROWS", 8);
-  g.N = e->N; g.medoid = e->medoid; g.R = e->R; g.sample_hash = h;
+  memcpy(g.magic, "BANGROW2", 8);
+  g.N = e->N; g.medoid = e->medoid; g.R = e->R; g.adj_hash = h;
   return g;
 }
-static const uint64_t kSigSeed = 0xcbf29ce484222325ull;
 
 // one node's adjacency list as a pull row: 64 slots, ids first (ascending), the rest padded
 static inline void pull_row_from_entry(const bang_engine* e, uint32_t* row, const uint8_t* adj) {
@@ -458,8 +470,9 @@ static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig
     pr.tmp.clear();
   } else if (memcmp((const uint8_t*)pr.m + pr.sig_off, &sig, sizeof(sig)) != 0) {
     pull_rows_abandon(pr);
-    bang_set_error("pull rows: %s belongs to another index (delete it)", pr.path.c_str());
-    return BANG_ERR_IO;
+    (void)unlink(pr.path.c_str());                        // stale: rows of another graph (the caller rebuilds them)
+    bang_set_error("pull rows: %s belonged to another index", pr.path.c_str());
+    return BANG_ERR_STALE_ROWS;
   }
   if (hipHostRegister(pr.m, pr.bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
@@ -483,14 +496,26 @@ static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig
 // rows from a graph that is resident in host memory
 static int build_pull_rows(bang_engine* e) {
   const size_t vb = vec_bytes(e);
-  uint64_t h = kSigSeed;
-  for (uint32_t t = 0; t < 64; ++t) sig_fold(e, h, e->graph + sig_sample_node(e, t) * e->entry_len + vb);
+  const int T = std::max(1, std::min(16, usable_cpus()));
+  uint64_t h = 0;
+  {
+    std::vector<uint64_t> part((size_t)T, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        const size_t a = (size_t)e->N * t / T, b = (size_t)e->N * (t + 1) / T;
+        uint64_t acc = 0;
+        for (size_t i = a; i < b; ++i) acc += sig_node(e, i, e->graph + i * e->entry_len + vb);
+        part[(size_t)t] = acc;
+      });
+    for (auto& x : th) x.join();
+    for (uint64_t v : part) h += v;
+  }
   const PullRowsSig sig = sig_make(e, h);
   PullRows pr;
-  BANG_TRY(pull_rows_open(e, pr, &sig));
+  BANG_TRY(pull_rows_open(e, pr, &sig));                 // (a rows file of another graph is not mapped: rebuilt below)
   if (pr.fill) {
     uint32_t* rows = (uint32_t*)pr.m;
-    const int T = std::max(1, std::min(16, usable_cpus()));
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
       th.emplace_back([=]() {
@@ -538,7 +563,7 @@ static bool stream_feasible(bang_engine* e, size_t hbm_reserve, std::string* why
 
 // STREAMED load: every chunk of graph entries the source hands over is split on the spot -- vectors into HBM (through a pinned
 // staging buffer), adjacency lists into the pull rows -- and dropped.  Host memory: the rows (N x 256 B) and one chunk.
-static int stage_entries_streamed(bang_engine* e) {
+static int stage_entries_streamed(bang_engine* e, bool retried = false) {
   const size_t vb = vec_bytes(e), N = e->N, el = e->entry_len;
   HIP_TRY(hipMalloc((void**)&e->d_vecs, N * vb + 256));
   PullRows pr;
@@ -559,32 +584,32 @@ static int stage_entries_streamed(bang_engine* e) {
     if (hipHostMalloc((void**)&stage[b], chunk * vb, hipHostMallocDefault) != hipSuccess || hipEventCreate(&ev[b]) != hipSuccess) {
       (void)hipGetLastError(); bang_set_error("streamed load: no pinned staging buffer"); rc = BANG_ERR_HIP;
     }
-  uint64_t h = kSigSeed;
-  uint32_t next_t = 0;
+  uint64_t h = 0;
   uint32_t* rows = (uint32_t*)pr.m;
   const int T = std::max(1, std::min(16, usable_cpus()));
+  std::vector<uint64_t> part((size_t)T, 0);
   int b = 0;
   for (size_t first = 0; first < N && rc == BANG_OK; first += chunk, b ^= 1) {
     const size_t n = std::min(chunk, N - first);
     if (e->entry_fn(e->entry_ctx, first, n, buf) != 0) { bang_set_error("streamed load: the entry source failed at node %zu", first); rc = BANG_ERR_IO; break; }
-    while (next_t < 64 && sig_sample_node(e, next_t) < first + n) {
-      sig_fold(e, h, buf + (sig_sample_node(e, next_t) - first) * el + vb);
-      ++next_t;
-    }
     if (e->medoid >= first && e->medoid < first + n) memcpy(medoid_entry.data(), buf + (e->medoid - first) * el, el);
     if (hipEventSynchronize(ev[b]) != hipSuccess) { bang_set_error("streamed load: event"); rc = BANG_ERR_HIP; break; }   // the previous copy out of this buffer is done
     {
       uint8_t* st = stage[b];
       const bool fill = pr.fill;
+      uint64_t* part_p = part.data();
       std::vector<std::thread> th;
       for (int t = 0; t < T; ++t)
         th.emplace_back([=]() {
           const size_t a = n * t / T, z = n * (t + 1) / T;
+          uint64_t acc = 0;
           for (size_t i = a; i < z; ++i) {
             const uint8_t* ent = buf + i * el;
             memcpy(st + i * vb, ent, vb);
+            acc += sig_node(e, first + i, ent + vb);
             if (fill) pull_row_from_entry(e, rows + (first + i) * 64, ent + vb);
           }
+          part_p[t] += acc;
         });
       for (auto& x : th) x.join();
     }
@@ -594,8 +619,17 @@ static int stage_entries_streamed(bang_engine* e) {
   if (rc == BANG_OK && hipDeviceSynchronize() != hipSuccess) { bang_set_error("streamed load: sync"); rc = BANG_ERR_HIP; }
   cleanup();
   if (rc != BANG_OK) { (void)hipGetLastError(); pull_rows_abandon(pr); return rc; }
+  for (uint64_t v : part) h += v;
+  {
+    const int frc = pull_rows_finish(e, pr, sig_make(e, h));
+    if (frc == BANG_ERR_STALE_ROWS && !retried) {
+      // a rows file of ANOTHER graph sat under this name (it has been removed): the entries pass through once more to build ours
+      dfree(e->d_vecs);
+      return stage_entries_streamed(e, true);
+    }
+    if (frc != BANG_OK) return frc == BANG_ERR_STALE_ROWS ? BANG_ERR_IO : frc;
+  }
   e->vec_on_device = true;
-  BANG_TRY(pull_rows_finish(e, pr, sig_make(e, h)));
   BANG_TRY(stage_medoid(e, medoid_entry.data()));
   e->graph_streamed = true;
   return BANG_OK;
@@ -901,7 +935,9 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   if (e->graph_mode != BANG_GRAPH_DEVICE && e->pull_opt != 0) {
     // pull needs the re-rank's vectors in HBM (nothing walks the graph entries any more) and rows of <= 64 ids
     if (e->vec_on_device && e->R <= 64) {
-      const int rc = build_pull_rows(e);
+      int rc = build_pull_rows(e);
+      if (rc == BANG_ERR_STALE_ROWS) rc = build_pull_rows(e);     // (another rank swapped the file between open and check)
+      if (rc == BANG_ERR_STALE_ROWS) rc = BANG_ERR_IO;
       if (rc != BANG_OK && e->pull_opt == 1) return rc;            // asked for explicitly: report; auto: the walker serves the graph
     } else if (e->pull_opt == 1) {
       bang_set_error("option pull = 1 needs the full-precision vectors resident in HBM (option vectors) and R <= 64");
@@ -940,6 +976,7 @@ void unload_index(bang_engine* e) {
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
   e->graph_path.clear(); e->graph_streamed = false; e->entry_fn = nullptr; e->entry_ctx = nullptr;
+  e->rows_key.clear();
   free(e->graph_owned);
   e->graph_owned = nullptr;
   if (e->graph_map) (void)munmap(e->graph_map, e->graph_map_len);
@@ -1036,7 +1073,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
-  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_fp); dfree(e->d_results);
+  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_fp); dfree(e->d_results);
   e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
   if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
   dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
@@ -1368,6 +1405,7 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
       cl[1] = counts[0]; cl[2] = counts[1]; cl[3] = counts[2]; cl[4] = counts[3];
       for (int z = 5; z < 16; ++z) cl[z] = 0;
       cl[0] = it;
+      if (ln.pw_error.load(std::memory_order_relaxed)) cl[0] = 0xFFFFFFFFu;   // another thread has stopped the kernel meanwhile: STOP stays
       bytes += 64;
     }
     served_unfenced = true;
@@ -1618,6 +1656,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     if (!dev_graph) { sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1; }   // pull mode
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
+    sp.d_qskip = e->d_qskip + ln.q0;
     sp.d_ktime = ktime_slot(e, ln);
     {
       static const int env_wgs = getenv("BANG_SEARCH_MAX_WGS") ? atoi(getenv("BANG_SEARCH_MAX_WGS")) : 0;   // experiment / test knobs
@@ -1819,12 +1858,23 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   // a 1 250-query shard, 92-107 -> 73-82 us for the 10 K batch); only a very large batch keeps the direct, runtime-pipelined copies.
   const bool whole = ln.q0 == 0 && (int)ln.nq == Q && (int)ln.nq == e->Qcur;
   static const size_t mailbox_max = getenv("BANG_MAILBOX_BYTES") ? (size_t)atoll(getenv("BANG_MAILBOX_BYTES")) : (size_t)BANG_RESULT_MAILBOX_BYTES;
-  const bool mailbox = whole && e->res_off_iters <= mailbox_max;
-  uint32_t* h_abort = (uint32_t*)(e->h_results + e->res_bytes - 64) + ln.index;   // (one word per lane in the last line)
+  uint64_t* d_ids_user = e->pool.d_ids_user;
+  float* d_dists_user = e->pool.d_dists_user;
+  const bool to_device = d_ids_user != nullptr;               // bang_query_dev_e: no result leaves the device
+  const bool mailbox = !to_device && whole && e->res_off_iters <= mailbox_max;
+  uint32_t* h_abort = (uint32_t*)(e->h_results + e->res_bytes - BANG_MAX_LANES * 4) + ln.index;   // (one word per lane behind the results)
   *h_abort = 0;
   if (e->search_host) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
   const bool iters = e->search_v2 || e->search_host;
-  if (mailbox) {
+  if (to_device) {
+    LANE_HIP(hipMemcpyAsync(d_ids_user + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k, (size_t)ln.nq * e->k * sizeof(uint64_t),
+                            hipMemcpyDeviceToDevice, ln.s_main));
+    if (d_dists_user)
+      LANE_HIP(hipMemcpy2DAsync(d_dists_user + ln.q0, (size_t)Q * 4, e->d_dists_out + ln.q0, (size_t)Q * 4, (size_t)ln.nq * 4, (size_t)e->k,
+                                hipMemcpyDeviceToDevice, ln.s_main));
+    if (iters) LANE_HIP(hipMemcpyAsync(e->h_results + e->res_off_iters + (size_t)ln.q0 * 4, e->d_qiters + ln.q0, (size_t)ln.nq * 4,
+                                       hipMemcpyDeviceToHost, ln.s_main));
+  } else if (mailbox) {
     LANE_HIP(hipMemcpyAsync(e->h_results, e->d_results, iters ? e->res_off_iters + (size_t)ln.nq * 4 : e->res_off_iters,
                             hipMemcpyDeviceToHost, ln.s_main));
   } else {
@@ -1938,7 +1988,7 @@ extern "C" int bang_create(int dtype, bang_engine_t** out) {
     e->graph_mode = (strcmp(v, "device") == 0 || strcmp(v, "1") == 0) ? BANG_GRAPH_DEVICE
                   : (strcmp(v, "auto") == 0 || strcmp(v, "2") == 0) ? BANG_GRAPH_AUTO : BANG_GRAPH_HOST;
   e->graph_opt = e->graph_mode;
-  if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::max(0, atoi(v));
+  if (const char* v = getenv("BANG_LANES")) e->lanes_opt = std::min(BANG_MAX_LANES, std::max(0, atoi(v)));
   if (const char* v = getenv("BANG_THREADS")) e->threads_opt = std::max(0, atoi(v));
   if (const char* v = getenv("BANG_CHECK_EVERY")) e->check_every = std::max(1, atoi(v));
   if (const char* v = getenv("BANG_FRONT_WGS")) e->front_wgs_opt = atoi(v);
@@ -1980,7 +2030,7 @@ extern "C" int bang_set_option(bang_engine_t* e, const char* key, long value) {
     bang_set_error("option %s must be set before bang_alloc", key); return BANG_ERR_ARG;
   }
   if (k == "graph") { if (value != BANG_GRAPH_HOST && value != BANG_GRAPH_DEVICE && value != BANG_GRAPH_AUTO) return BANG_ERR_ARG; e->graph_mode = e->graph_opt = (int)value; }
-  else if (k == "lanes") { if (value < 0 || value > 256) return BANG_ERR_ARG; e->lanes_opt = (int)value; }
+  else if (k == "lanes") { if (value < 0 || value > BANG_MAX_LANES) return BANG_ERR_ARG; e->lanes_opt = (int)value; }
   else if (k == "threads") { if (value < 0) return BANG_ERR_ARG; e->threads_opt = (int)value; }
   else if (k == "device") { e->device = (int)value; }
   else if (k == "pq") { e->pq_mode = (int)value; }
@@ -2137,11 +2187,12 @@ static int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_cand_ids, nq * rows));
   BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
   BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
+  BANG_TRY(dmalloc(&e->d_qskip, nq));
   {
     const size_t a64 = 63;
     e->res_off_dists = ((size_t)nq * e->k * 8 + a64) & ~a64;
     e->res_off_iters = (e->res_off_dists + (size_t)nq * e->k * 4 + a64) & ~a64;
-    e->res_bytes = (e->res_off_iters + (size_t)nq * 4 + 64 + a64) & ~a64;                   // + one line: the kernel's abort word
+    e->res_bytes = (e->res_off_iters + (size_t)nq * 4 + BANG_MAX_LANES * 4 + a64) & ~a64;   // + the kernel's abort word, one per lane
     BANG_TRY(dmalloc(&e->d_results, e->res_bytes));
     HIP_TRY(hipHostMalloc((void**)&e->h_results, e->res_bytes, hipHostMallocDefault));
     e->d_ids_out = (uint64_t*)e->d_results;
@@ -2286,6 +2337,7 @@ extern "C" int bang_init_e(bang_engine_t* e, int Q) {
   const size_t nq = (size_t)Q;
   HIP_TRY(hipMemsetAsync(e->d_bloom, 0, nq * BANG_BF_WORDS * 4, nullptr));                  // :443
   HIP_TRY(hipMemsetAsync(e->d_qstats, 0, nq * 8, nullptr));
+  HIP_TRY(hipMemsetAsync(e->d_qskip, 0, nq * 4, nullptr));
   if (e->d_active) HIP_TRY(hipMemsetAsync(e->d_active, 0, ((size_t)e->cand_stride + 2) * 4, nullptr));
   BANG_TRY(bang_k_init_state((uint32_t)Q, (uint32_t)e->medoid, e->cand_stride, e->d_cand_ids, e->d_cand_row, e->d_cand_cnt,
                              e->d_wl_cnt, e->d_mark, e->d_parents_dev, e->d_cnt, nullptr));
@@ -2295,8 +2347,19 @@ extern "C" int bang_init_e(bang_engine_t* e, int Q) {
   return BANG_OK;
 }
 
+static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists, uint64_t* d_ids_user, float* d_dists_user);
+
 extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists) {
   if (!e || !h_queries || !h_ids || !h_dists) return BANG_ERR_ARG;
+  return query_impl(e, h_queries, Q, h_ids, h_dists, nullptr, nullptr);
+}
+
+extern "C" int bang_query_dev_e(bang_engine_t* e, const void* h_queries, int Q, uint64_t* d_ids, float* d_dists) {
+  if (!e || !h_queries || !d_ids) return BANG_ERR_ARG;
+  return query_impl(e, h_queries, Q, nullptr, nullptr, d_ids, d_dists);
+}
+
+static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists, uint64_t* d_ids_user, float* d_dists_user) {
   if (!e->allocated || !e->inited) { bang_set_error("bang_query: bang_alloc + bang_init must precede every query"); return BANG_ERR_ARG; }
   if (Q <= 0 || Q > e->Qcap) { bang_set_error("bang_query: numQueries %d exceeds allocation %d", Q, e->Qcap); return BANG_ERR_ARG; }
   e->inited = false;   // state is consumed
@@ -2336,6 +2399,7 @@ extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint
   {
     std::lock_guard<std::mutex> lk(pool.m);
     pool.h_queries = h_queries; pool.h_ids = h_ids; pool.h_dists = h_dists; pool.Q = Q;
+    pool.d_ids_user = d_ids_user; pool.d_dists_user = d_dists_user;
     pool.lanes_done = 0;
     ++pool.query_seq;
   }
@@ -2422,6 +2486,11 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     std::vector<uint32_t> qs((size_t)e->Qcur * 2);
     HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < qs.size(); i += 2) { s.dist_evals += qs[i]; s.fetched += qs[i + 1]; }
+    if (e->search_v2) {
+      std::vector<uint32_t> sk((size_t)e->Qcur);
+      HIP_TRY(hipMemcpy(sk.data(), e->d_qskip, sk.size() * 4, hipMemcpyDeviceToHost));
+      for (uint32_t v : sk) s.filter_loads_skipped += v;
+    }
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t c : cc) s.candidates += c;

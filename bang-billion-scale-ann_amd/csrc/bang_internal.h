@@ -36,6 +36,9 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
 #define BANG_KERNEL_GO_TIMEOUT_TICKS 3000000000ull   /* 30 s of the 100 MHz s_memrealtime clock */
 #define BANG_RESULT_MAILBOX_BYTES (8 * 1024 * 1024)   // results (ids + distances) up to this size return through the pinned mirror in one copy (BANG_MAILBOX_BYTES)
 
+#define BANG_MAX_LANES 256          /* option "lanes" / BANG_LANES; one abort word per lane sits behind the result mirror */
+#define BANG_ERR_STALE_ROWS (-100)  /* internal: a pull-rows file of another graph was found (and removed); the caller rebuilds */
+
 int bang_num_cus(void);
 // 1 if the fused kernel has an instance for the exact-size ("ragged") pivot table of this layout
 int bang_ragged_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t m);

@@ -122,6 +122,64 @@ __device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K5: exact on-chip summary "this filter word has been stored to" -- one bit per 32-bit word of the query's filter
+// ---------------------------------------------------------------------------------------------------------------------
+// A query's filter starts all-zero (bang_init :443) and only its own wave ever stores to it, so the wave knows which words are still
+// zero without asking memory.  A probe of such a word needs no load (the bit is clear: the id passes, :1157) and a survivor's store
+// to it needs no old value (old | bit == bit).  The hash positions and the snapshot semantics (:1140-1165) are untouched; only
+// requests whose answer is known are dropped (with ~7 K of 400 K slots set at the end of a SIFT1M-like query, ~3/4 of all probed
+// words are still zero when probed).
+// Layout: 12 288 bits in SIX VGPRs of the owning wave -- word w lives in lane (w & 63), position p = w >> 6 (0..195; the 209 words
+// with p >= 192 share the positions p - 192: a set bit then also covers an alias, which only costs that word its shortcut),
+// register p >> 5, bit p & 31.  Read: six ds_bpermute (no LDS memory touched) + selects.  Set: the survivors' bits are transposed
+// through 128 words of the wave's LDS scratch, two registers per pass (ds_or_b32), and OR-ed into the registers.
+#ifndef BANG_FILTER_SUMMARY
+#define BANG_FILTER_SUMMARY 1
+#endif
+#define SUMM_REGS 6
+struct FilterSummary {
+  uint32_t s[SUMM_REGS];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int r = 0; r < SUMM_REGS; ++r) s[r] = 0u;
+  }
+  static __device__ __forceinline__ uint32_t pos_of(uint32_t w) { const uint32_t p = w >> 6; return p >= 32u * SUMM_REGS ? p - 32u * SUMM_REGS : p; }
+  // has word w been stored to?  (every lane asks about its own w; all lanes of the wave must be executing)
+  __device__ __forceinline__ bool test(uint32_t w) const {
+    const uint32_t p = pos_of(w);
+    const int src = (int)((w & 63u) << 2);
+    uint32_t v = 0;
+#pragma unroll
+    for (int r = 0; r < SUMM_REGS; ++r) {
+      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s[r]);
+      v = ((p >> 5) == (uint32_t)r) ? t : v;
+    }
+    return ((v >> (p & 31u)) & 1u) != 0u;
+  }
+  // mark up to three words per lane (a, b: this lane's survivor; c: the 65th id of the seed list, lane 0) as stored to
+  __device__ __forceinline__ void set(uint32_t* tbl /* 128 LDS words of the wave */, int lane, bool ha, uint32_t wa, bool hb, uint32_t wb,
+                                      bool hc, uint32_t wc0, uint32_t wc1) {
+    const uint32_t pa = pos_of(wa), pb = pos_of(wb), pc0 = pos_of(wc0), pc1 = pos_of(wc1);
+#pragma unroll
+    for (int pass = 0; pass < SUMM_REGS / 2; ++pass) {
+      const bool ia = ha && (pa >> 6) == (uint32_t)pass, ib = hb && (pb >> 6) == (uint32_t)pass;
+      const bool ic0 = hc && (pc0 >> 6) == (uint32_t)pass, ic1 = hc && (pc1 >> 6) == (uint32_t)pass;
+      if (__ballot(ia || ib || ic0 || ic1) == 0) continue;                         // uniform
+      *(uint2*)(tbl + 2 * lane) = make_uint2(0u, 0u);
+      wave_sync();
+      if (ia) (void)__hip_atomic_fetch_or(&tbl[(wa & 63u) * 2u + ((pa >> 5) & 1u)], 1u << (pa & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ib) (void)__hip_atomic_fetch_or(&tbl[(wb & 63u) * 2u + ((pb >> 5) & 1u)], 1u << (pb & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ic0) (void)__hip_atomic_fetch_or(&tbl[(wc0 & 63u) * 2u + ((pc0 >> 5) & 1u)], 1u << (pc0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ic1) (void)__hip_atomic_fetch_or(&tbl[(wc1 & 63u) * 2u + ((pc1 >> 5) & 1u)], 1u << (pc1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      wave_sync();
+      const uint2 v = *(const uint2*)(tbl + 2 * lane);
+      s[2 * pass] |= v.x; s[2 * pass + 1] |= v.y;
+      wave_sync();
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K3a + K3b on LDS-resident state (compute_BestLSets_par_sort_msort :1533-1585, compute_BestLSets_par_merge :1605-1715)
 // ---------------------------------------------------------------------------------------------------------------------
 struct WaveLds {
@@ -434,6 +492,11 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       qc.v[r] = src[i < (uint32_t)QW ? i : 0u];
     }
   };
+  // which words of the current query's filter have been stored to (self-paced form; the host-paced instances have no registers to spare)
+  constexpr bool SUMM = !HOST && (BANG_FILTER_SUMMARY != 0);
+  FilterSummary summ;
+  summ.clear();
+  uint32_t probes_skipped = 0;                     // diagnostic counter (d_qstats2): filter words not loaded thanks to the summary
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -521,6 +584,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
         active = true;
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
+        if (SUMM) { summ.clear(); probes_skipped = 0; }
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
@@ -551,8 +615,16 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       const bool v1 = ci > 64;                               // the 65th id exists in the seed list only (uniform)
       const uint32_t h0a = hash1(x0), h0b = hash2(x0);
       uint32_t h1a = 0, h1b = 0, w0a = 0, w0b = 0, w1a = 0, w1b = 0;
-      // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip
-      if (v0) { w0a = ld_bypass_l1(&bloom[h0a >> 5]); w0b = ld_bypass_l1(&bloom[h0b >> 5]); }
+      // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip.
+      // A word the summary knows to be untouched is zero: no request (FilterSummary).
+      bool la = v0, lb = v0;                                 // load word a / b?
+      if (SUMM) {
+        la = summ.test(h0a >> 5) && v0;
+        lb = summ.test(h0b >> 5) && v0;
+        probes_skipped += (uint32_t)__popcll(__ballot(v0 && !la)) + (uint32_t)__popcll(__ballot(v0 && !lb));
+      }
+      if (la) w0a = ld_bypass_l1(&bloom[h0a >> 5]);
+      if (lb) w0b = ld_bypass_l1(&bloom[h0b >> 5]);
       if (v1) {
         h1a = hash1(x1); h1b = hash2(x1);
         if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
@@ -593,6 +665,8 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
             (void)__hip_atomic_fetch_or(&bloom[h1b >> 5], 1u << (h1b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        // the words just stored to are no longer zero (only those the summary did not know yet need marking)
+        if (SUMM) summ.set(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
       }
 
       PH(3);   // filter update (claim table + stores issued)
@@ -720,6 +794,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
           p.d_cand_cnt[q] = cc;
           if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
           if (p.d_qiters) p.d_qiters[q] = iter;
+          if (p.d_qskip) p.d_qskip[q] = probes_skipped;
         }
         active = false;
       } else {

@@ -2,21 +2,28 @@
 """bench.py -- queries/sec @ 10-recall@10 >= 0.9 on a 10K-query batch (BASELINE.json metric), the roofline of the search
 kernel and of the PQ-distance stage (K2) alone, and the CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1m|sift1b_shape|deep100m_shape|small|tiny]
-                    [--graph host|device|auto] [--batches B] [--no-legs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1b_shape|sift1m|sift10m|deep100m_shape|small|tiny]
+                    [--graph host|device|auto] [--pull -1|0|1] [--batches B] [--no-legs] [--legs k2,sift1m,...]
 
 One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
 
-* N = 1 (the default): the workload is BASELINE.json configs[1] (SIFT1M-like, 10 000 queries) with the engine's default
-  placement ("auto": a 388 MB graph goes to HBM).  The same JSON line carries, under `config`, the other single-GPU
-  configurations as LEGS, each timed the same way on its own index: `at_host_graph` (configs[1] on the north-star path: graph
-  in host RAM, C++ walker, adjacency rows through the PCIe BAR), `at_L200` (configs[1]'s L = 200),
-  `at_deep100m_shape` (configs[2]), `at_sift1b_shape` (configs[3]: the shape the target number is quoted on) and `at_sift10m`
-  (a recall-verified structured index whose code table no longer fits the Infinity Cache).
+* For EVERY N the workload is `sift1b_shape` = BASELINE.json configs[3] (N = 1) / configs[4] (N > 1): the configuration the target
+  number is quoted on (BANG_Base/test_driver.cpp:433-439, Cost_Analysis.pdf p.3) -- uint8, D = 128, R = 64, m = 70, 10 000 queries,
+  L = 152, graph in host RAM.  The index is streamed through bang_load_stream_e (vectors + PQ codes into HBM, adjacency lists into
+  256-byte pull rows in pinned host memory) and searched by ONE self-paced search-kernel launch per batch that pulls the rows over
+  PCIe.  N is scaled to what the box's host memory holds (stated in config.workload).  `value`, `config`, `roofline` (that launch +
+  `k2_alone` at m = 70) and `cpu_baseline` (the oracle on the same layout at reduced N, where the HIP engine is also checked
+  against it) all belong to this configuration.
+* N = 1 also carries the other single-GPU configurations as LEGS, each timed the same way on its own index, as nested objects
+  `config.at_*` and -- because the driver's record keeps scalars only -- flattened into `config.<leg>_qps`, `_recall`, `_L`, `_frac`
+  ...: `sift1m` (configs[1], recall-verified; default placement = HBM, plus `sift1m_host_pull`, `sift1m_host_walker`,
+  `sift1m_L200`), `deep100m_shape` (configs[2]), `walker` (sift1b_shape with a resident graph image served by the C++ walker
+  threads: the north-star data flow) and `sift10m` (a recall-verified structured index beyond the Infinity Cache).
 * N > 1: the 10K-query batch is split into contiguous shards, one per rank; every rank searches its shard on its own replica of
-  the PQ table, all ranks share ONE read-only host graph, and ONE RCCL all-gather of the result ids ends the step
-  ("scaling": "strong": the total work is fixed).  `--batches B` instead streams B whole 10K batches per rank and step
-  ("scaling": "weak": throughput mode, no collective on the data path).
+  the PQ table and vectors, all ranks share ONE copy of the pull rows in host memory (BANG_PULL_ROWS_DIR), and ONE RCCL all-gather
+  of the result ids -- straight from the device buffers bang_query_dev_e leaves them in -- ends the step ("scaling": "strong": the
+  total work is fixed).  `--batches B` instead streams B whole 10K batches per rank and step ("scaling": "weak": throughput mode,
+  no collective on the data path).
 
 A "step" = one bang_query over the whole batch.  bang_init (visited-filter / worklist reset) is outside the timed bracket,
 exactly as in the reference harness (BANG_Base/test_driver.cpp:432-439); the init-inclusive rate is reported beside it.  Every
@@ -112,7 +119,8 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False):
             if not stream:                       # (a streamed index has no graph image to share: every rank runs the generator)
                 shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
         ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
-            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows, stream=stream)
+            name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows, stream=stream,
+            planned=(world > 1))
 
         def rel():
             shape_workload.release(ix)
@@ -193,6 +201,9 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
 
 
 def run_once(eng, my_q, ctx, timed=False, gather=True):
+    """One step: bang_init (untimed), then bang_query over this rank's shard and -- N > 1, strong scaling -- the single collective
+    of the job.  With RCCL the shard's ids stay in device memory (bang_query_dev_e) and are all-gathered from there; rank 0 copies
+    the gathered [Q][k] block to the host once.  Returns (ids of this rank, dists of this rank or None, seconds, search s, gather s)."""
     import torch
     import torch.distributed as dist
     from bang_amd import shard
@@ -201,15 +212,32 @@ def run_once(eng, my_q, ctx, timed=False, gather=True):
         if ctx.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    collective = ctx.world > 1 and gather and not ctx.weak
+    dg = getattr(ctx, "dgather", None) if collective else None
     t_a = time.perf_counter()
-    ids, dists = eng.query(my_q)
-    if ctx.world > 1 and gather and not ctx.weak:        # the single RCCL collective of the job (none in throughput mode)
-        shard.gather_ids(ids, ctx.Q_total, ctx.k, ctx.rank, ctx.world, device=ctx.cdev)
+    if dg is not None:
+        eng.query_dev(my_q, dg.mine.data_ptr(), dg.dists.data_ptr())
+        t_b = time.perf_counter()
+        dg.gather()
+        if ctx.rank == 0:
+            ctx.batch_ids = dg.batch_ids()               # the batch's answer reaches the host on one rank (one D2H copy)
+        else:
+            torch.cuda.synchronize()
+        ids, dists = None, None
+    else:
+        ids, dists = eng.query(my_q)
+        t_b = time.perf_counter()
+        if collective:                                   # (gloo dry runs: host buffers)
+            ctx.batch_ids = shard.gather_ids(ids, ctx.Q_total, ctx.k, ctx.rank, ctx.world, device=ctx.cdev)
+    t_c = time.perf_counter()
     if timed:
         torch.cuda.synchronize()
         if ctx.world > 1:
             dist.barrier()
-    return ids, dists, time.perf_counter() - t_a
+    t_d = time.perf_counter()
+    if dg is not None:
+        ids, dists = dg.local_ids(), dg.local_dists()    # (untimed: this rank's block for the recall / parity / property checks)
+    return ids, dists, t_d - t_a, t_b - t_a, t_c - t_b
 
 
 def check_properties(ix, my_q, ids, dists, k):
@@ -239,25 +267,30 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
     Qr = my_q.shape[0]
     for _ in range(warmup):
         run_once(eng, my_q, ctx, timed=True)
-    step_s, init_s = [], []
+    step_s, init_s, search_s, gather_s = [], [], [], []
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
                 "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
-               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0)
+               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0)
     agg.update({kk: 0 for kk in keys_max})
     ids = dists = None
     for _ in range(steps):
         ti = time.perf_counter()
         el = 0.0
+        e_s = e_g = 0.0
         for b in range(batches):
-            ids, dists, e1 = run_once(eng, my_q, ctx, timed=True, gather=(batches == 1))
+            ids, dists, e1, es1, eg1 = run_once(eng, my_q, ctx, timed=True, gather=(batches == 1))
             el += e1
+            e_s += es1
+            e_g += eg1
             st = eng.stats()
             for key in agg:
                 agg[key] = max(agg[key], st[key]) if key in keys_max else agg[key] + st[key]
         init_s.append(time.perf_counter() - ti)
         step_s.append(el)
-    times = torch.tensor([step_s, init_s], dtype=torch.float64, device=ctx.cdev)
+        search_s.append(e_s)
+        gather_s.append(e_g)
+    times = torch.tensor([step_s, init_s, search_s, gather_s], dtype=torch.float64, device=ctx.cdev)
     if ctx.world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     total = float(times[0].sum().item())
@@ -267,7 +300,9 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         n_q = ctx.Q_total if batches == 1 else Qr * ctx.world * batches       # queries all ranks processed per step
     res = dict(L=L, queries_per_s=round(n_q * steps / total, 1), ms_per_step=round(1e3 * total / steps, 4),
                qps_incl_init=round(n_q * steps / float(times[1].sum().item()), 1),
-               step_ms=[round(1e3 * float(t), 2) for t in times[0].tolist()][:64], ids=ids, dists=dists, agg=agg)
+               step_ms=[round(1e3 * float(t), 2) for t in times[0].tolist()][:64], ids=ids, dists=dists, agg=agg,
+               search_ms=round(1e3 * float(times[2].sum().item()) / steps, 4),      # bang_query of the slowest rank, mean over the steps
+               gather_ms=round(1e3 * float(times[3].sum().item()) / steps, 4))      # the collective (+ rank 0's copy of the batch to the host)
     # ---- roofline of the search kernel of this measurement
     m = ix.m
     bpe = m + 8                                         # m code bytes + 4 B id + 4 B distance per evaluation
@@ -412,17 +447,178 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------- one configuration
+def batch_recall(O, gt_i, gt_d, ids, k, q0, q1, ctx):
+    """10-recall@10 of the WHOLE batch: the ranks' shard recalls weighted by their shard sizes (== the single-process number;
+    a MIN over shards would make the L sweep depend on the rank count)."""
+    import torch
+    import torch.distributed as dist
+    if gt_i is None:
+        return float("nan")
+    r = O.recall(gt_i[q0:q1], gt_d[q0:q1], ids, k)
+    if ctx.world == 1:
+        return r
+    t = torch.tensor([r * (q1 - q0), float(q1 - q0)], dtype=torch.float64, device=ctx.cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0].item() / t[1].item())
+
+
+def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1, stream=True, reserve_rows=True, Q=0, shape_n=0,
+               traffic=True, batches=1, lanes=0, threads=0, keep=False):
+    """Builds workload `name`, loads an engine in the requested placement, chooses L (structured workloads: the smallest L on the
+    harness grid k, k+12, ... with 10-recall@10 >= target; shape-only workloads: 152, the reference's SIFT1B setting), times
+    `steps` steps and checks the results (structured: first 64 queries of this rank against the oracle; shape-only: the
+    size-independent result properties).  Returns a dict; with keep=True the workload / engine stay alive (caller releases)."""
+    import torch
+    from bang_amd import shard
+    k = ctx.k
+    wl = build_workload(name, ctx, Q=Q, shape_n=shape_n, reserve_rows=reserve_rows, stream=stream)
+    ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
+    graph = graph or ("auto" if gt_i is not None else wl["graph"])
+    Qt = queries.shape[0]
+    ctx.Q_total = Qt
+    weak = ctx.world > 1 and batches > 1
+    ctx.weak = weak
+    q0, q1 = (0, Qt) if weak else shard.shard_range(Qt, ctx.rank, ctx.world)
+    my_q = np.ascontiguousarray(queries[q0:q1])
+    Qr = q1 - q0
+    eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=pull)
+    # N > 1 over RCCL: the shard's ids never leave device memory before the collective (host buffers only in gloo dry runs)
+    ctx.dgather = shard.DeviceGather(Qt, k, ctx.rank, ctx.world, ctx.dev) if (ctx.world > 1 and not weak and ctx.cdev == ctx.dev) else None
+    recall = float("nan")
+    if L == 0 and gt_i is not None:
+        for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
+            eng.set_searchparams(k, cand)
+            eng.alloc(Qr)
+            ids = run_once(eng, my_q, ctx)[0]
+            eng.free()
+            r = batch_recall(O, gt_i, gt_d, ids, k, q0, q1, ctx)
+            log(f"[bench] {name} L={cand:3d} recall={r:.2f}")
+            if r >= args.recall_target:
+                L, recall = cand, r
+                break
+        if L == 0:
+            raise RuntimeError("recall target not reached on the L grid")
+    elif L == 0:
+        L = 152                                          # reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
+    eng.set_searchparams(k, L)
+    eng.alloc(Qr)
+    placement_note = None
+    if graph == "auto":                                  # what did "auto" resolve to?
+        run_once(eng, my_q, ctx)
+        graph = "device" if eng.stats()["graph_mode"] == 1 else "host"
+        placement_note = f"auto -> {graph} (engine default: graph in HBM when it fits next to the PQ codes with 16 GB to spare)"
+    res = measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=(f"{name}_{graph}" if traffic else None),
+                  batches=batches if weak else 1)
+    orc = None
+    if gt_i is not None:
+        recall = batch_recall(O, gt_i, gt_d, res["ids"], k, q0, q1, ctx)
+        orc = O.Oracle(ix)
+        chk = min(64, Qr)
+        ids_o, _ = orc.search(my_q[:chk], k, L)
+        ok = bool(np.array_equal(res["ids"][:chk], ids_o))
+    else:
+        ok = check_properties(ix, my_q, res["ids"], res["dists"], k)
+    out = dict(wl=wl, eng=eng, res=res, L=L, recall=recall, ok=ok, graph=graph, orc=orc, my_q=my_q, q0=q0, q1=q1, Qr=Qr,
+               placement_note=placement_note, structured=gt_i is not None, name=name)
+    if not keep:
+        release_config(out)
+    return out
+
+
+def release_config(rc):
+    import torch
+    if rc.get("eng") is not None:
+        e = rc["eng"]
+        e.free(); e.unload(); e.close()
+        rc["eng"] = None
+    if rc.get("wl") is not None:
+        rc["wl"]["release"]()
+        rc["wl"] = None
+    rc["orc"] = None
+    torch.cuda.empty_cache()
+
+
+def flat(cfg, prefix, leg):
+    """The key facts of a leg as SCALARS of `config` (the driver's record keeps scalars only; the nested leg stays beside them)."""
+    for kk, name in (("queries_per_s", "qps"), ("ms_per_batch", "ms"), ("L", "L"), ("recall_at_10", "recall"),
+                     ("parity_vs_oracle_first_64", "parity_ok"), ("result_properties_ok", "props_ok")):
+        if kk in leg and leg[kk] is not None:
+            cfg[f"{prefix}_{name}"] = leg[kk]
+    if isinstance(leg.get("roofline"), dict):
+        cfg[f"{prefix}_frac"] = leg["roofline"].get("frac")
+    if "hops_p50_p99_max" in leg:
+        cfg[f"{prefix}_hops_p50"], cfg[f"{prefix}_hops_p99"] = leg["hops_p50_p99_max"][0], leg["hops_p50_p99_max"][1]
+
+
+# ---------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline_structured(rc, O, k, queries):
+    nthreads = usable_cpus()
+    orc, L, Q = rc["orc"], rc["L"], queries.shape[0]
+    orc.search(queries[: min(Q, 512)], k, L, nthreads=nthreads)     # warm
+    reps, t_cpu = 0, 0.0
+    while reps < 5 and t_cpu < 10.0:
+        t_a = time.perf_counter()
+        orc.search(queries, k, L, nthreads=nthreads)
+        t_cpu += time.perf_counter() - t_a
+        reps += 1
+    return {"value": round(Q * reps / t_cpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
+            "sample": f"{reps} x the full {Q}-query batch at L={L} through oracle/ (C + OpenMP, {nthreads} threads = "
+                      f"the CPU quota of this box; {os.cpu_count()} hardware threads visible), same timed region (search only)"}
+
+
+def cpu_baseline_shape(name, ctx, args, O, L):
+    """The oracle beside a shape-only workload: the same layout (dtype, D, R, m, L, iteration cap, ~56 evaluations per
+    iteration) on an index of REDUCED N whose PQ codes also exist in host memory (the full-size index keeps them only in HBM).
+    Per-query work does not depend on N once the tables are far larger than the CPU caches (N = 2e7: 1.4 GB of codes, 7.8 GB of
+    graph entries vs 2 x 384 MB of L3).  The HIP engine runs the SAME reduced index first: its ids must equal the oracle's on
+    every sampled query, which puts an oracle-checked run of this layout into every bench run."""
+    from tools import shape_workload
+    k = ctx.k
+    n_small = int(os.environ.get("BANG_CPU_BASELINE_N", "20000000"))
+    t0 = time.time()
+    ix, queries, _, _, _, wl_name, _ = shape_workload.make(name, ctx.dev, n_override=n_small, Q=2048, log=log, host_codes=True, planned=True)
+    wl = dict(ix=ix, queries=queries, gt_i=None, gt_d=None, d_codes=None, name=wl_name, graph="host", prefix=None, shared_dir=None)
+    eng = make_engine(wl, "host", ctx, timing=0)
+    eng.set_searchparams(k, L)
+    eng.alloc(queries.shape[0])
+    ids_g = run_once(eng, queries, ctx)[0]
+    eng.free(); eng.unload(); eng.close()
+    nthreads = usable_cpus()
+    orc = O.Oracle(ix)
+    orc.search(queries[:256], k, L, nthreads=nthreads)               # warm
+    done, t_cpu, ids_all = 0, 0.0, []
+    while done < queries.shape[0] and t_cpu < 12.0:
+        n = min(512, queries.shape[0] - done)
+        t_a = time.perf_counter()
+        ids_o, _ = orc.search(queries[done:done + n], k, L, nthreads=nthreads)
+        t_cpu += time.perf_counter() - t_a
+        ids_all.append(ids_o)
+        done += n
+    ids_o = np.concatenate(ids_all)
+    parity = bool(np.array_equal(ids_g[:done], ids_o))
+    shape_workload.release(ix)
+    log(f"[bench] cpu baseline ({name}, N={ix.N}): {done} queries in {t_cpu:.1f}s on {nthreads} threads, parity with the HIP engine: {parity} "
+        f"({time.time() - t0:.0f}s in all)")
+    return {"value": round(done / t_cpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
+            "sample": f"{done} queries of the {name} layout (m={ix.m}, L={L}, iteration cap L+49) at reduced N={ix.N} with the PQ codes in "
+                      f"host memory, through oracle/ (C + OpenMP, {nthreads} threads = the CPU quota of this box; {os.cpu_count()} hardware "
+                      f"threads visible), search only; per-query work is N-independent once the tables exceed the caches",
+            "hip_ids_equal_oracle_on_sample": parity}
+
+
 # ---------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sift1m", choices=sorted(WORKLOADS) + ["sift1b_shape", "deep100m_shape"])
+    ap.add_argument("--workload", default="sift1b_shape", choices=sorted(WORKLOADS) + ["sift1b_shape", "deep100m_shape"],
+                    help="default: sift1b_shape = BASELINE.json configs[3] / [4], the configuration the target number is quoted on")
     ap.add_argument("--shape-n", type=int, default=0, help="override N of a *_shape workload")
     ap.add_argument("--graph", default="", choices=["", "host", "device", "auto"],
-                    help="host: graph in host RAM + C++ walker (BANG_Base, the north-star path); device: graph in HBM")
-    ap.add_argument("--L", type=int, default=0, help="worklist length; 0 = smallest L on the harness grid with recall >= target")
+                    help="host: graph in host RAM (BANG_Base placement; rows pulled by the kernel, or --pull 0: C++ walker); device: graph in HBM")
+    ap.add_argument("--L", type=int, default=0, help="worklist length; 0 = smallest L on the harness grid with recall >= target (shape-only: 152)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--queries", type=int, default=0, help="override the batch size of the workload")
     ap.add_argument("--recall-target", type=float, default=90.0)
@@ -436,6 +632,7 @@ def main():
                          "instead of streaming the generator through the engine (default: streamed, N fits the pull rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
+    ap.add_argument("--legs", default="", help="comma list of legs to run (default: all): k2,sift1m,deep100m,walker,sift10m")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--no-events", action="store_true", help="do not stamp the launches of the timed steps")
@@ -464,7 +661,6 @@ def main():
             dist.init_process_group("gloo")
 
     import bang_amd
-    from bang_amd import shard
     from oracle import oracle as O           # checker + cpu_baseline leg only
     if rank == 0:                            # one builder per node; the others wait (make is not re-entrant)
         bang_amd.build()
@@ -472,109 +668,30 @@ def main():
     if world > 1:
         dist.barrier()
 
-    wl = build_workload(args.workload, ctx, Q=args.queries, shape_n=args.shape_n, reserve_rows=(args.pull != 0),
-                        stream=(args.pull != 0 and not args.resident_graph))
-    ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
-    # placement: the engine's own default ("auto": the whole graph in HBM when it fits next to the PQ codes with 16 GB to spare,
-    # else host RAM + C++ walker) for the structured workloads; the shape-only workloads use the placement BASELINE.json names
-    graph = args.graph or ("auto" if gt_i is not None else wl["graph"])
-    ctx.Q_total = Q = queries.shape[0]
-    weak = world > 1 and args.batches > 1
-    ctx.weak = weak
-    if weak:
-        q0, q1 = 0, Q                          # throughput mode: every rank searches whole batches
-    else:
-        q0, q1 = shard.shard_range(Q, rank, world)
-    my_q = np.ascontiguousarray(queries[q0:q1])
-    Qr = q1 - q0
-
     lanes = args.lanes or int(os.environ.get("BANG_LANES", "0"))
     threads = args.threads or int(os.environ.get("BANG_THREADS", "0"))
-    if world > 1 and graph in ("host", "auto"):
-        # all ranks of the node share one CPU quota: size the walker team from this rank's share of it
+    if world > 1 and not threads and args.pull == 0:
+        # walker form: all ranks of the node share one CPU quota -- size the walker team from this rank's share of it
         share = max(1, usable_cpus() // world)
-        if not threads:
-            threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // max(1, lanes or 1)))
-    eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=args.pull)
+        threads = max(1, min(12, share - 1)) if os.environ.get("BANG_PERSISTENT", "-1") != "0" else max(1, min(4, share // max(1, lanes or 1)))
 
-    def recall_of(ids, a=q0, b=q1):
-        if gt_i is None:
-            return float("nan")
-        return O.recall(gt_i[a:b], gt_d[a:b], ids, k)
-
-    # ------------------------------------------------------------------ choose L (untimed)
-    L = args.L
-    recall = float("nan")
-    if L == 0 and gt_i is not None:
-        for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
-            eng.set_searchparams(k, cand)
-            eng.alloc(Qr)
-            ids, _, _ = run_once(eng, my_q, ctx)
-            eng.free()
-            r = recall_of(ids)
-            if world > 1:
-                t = torch.tensor([r], device=ctx.cdev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                r = float(t.item())
-            log(f"[bench] L={cand:3d} recall={r:.2f}")
-            if r >= args.recall_target:
-                L, recall = cand, r
-                break
-        if L == 0:
-            raise SystemExit("recall target not reached on the L grid")
-    elif L == 0:
-        L = 152                                          # reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
-
-    # ------------------------------------------------------------------ timed steps of the primary workload
-    eng.set_searchparams(k, L)
-    eng.alloc(Qr)
-    placement_note = None
-    if graph == "auto":                                  # what did "auto" resolve to?
-        run_once(eng, my_q, ctx)
-        graph = "device" if eng.stats()["graph_mode"] == 1 else "host"
-        placement_note = f"auto -> {graph} (engine default: graph in HBM when it fits next to the PQ codes with 16 GB to spare)"
-    res = measure(eng, wl, my_q, L, args.steps, args.warmup, ctx, graph, traffic_key=f"{args.workload}_{graph}",
-                  batches=args.batches if weak else 1)
-    ids, dists, agg = res["ids"], res["dists"], res["agg"]
-    if gt_i is not None:
-        recall = recall_of(ids)
-        if world > 1:
-            rc = torch.tensor([recall], dtype=torch.float64, device=ctx.cdev)
-            dist.all_reduce(rc, op=dist.ReduceOp.MIN)
-            recall = float(rc.item())
-    # parity spot check on the real workload: first 64 queries of this rank vs the oracle (structured workloads), or the
-    # size-independent result properties (shape-only workloads)
-    orc = None
-    if gt_i is not None:
-        orc = O.Oracle(ix)
-        chk = min(64, Qr)
-        ids_o, _ = orc.search(my_q[:chk], k, L)
-        parity_ok = bool(np.array_equal(ids[:chk], ids_o))
-    else:
-        parity_ok = check_properties(ix, my_q, ids, dists, k)
-
-    out = None
-    cfg = {}
+    # ------------------------------------------------------------------ the primary configuration (value / config / roofline)
+    weak = world > 1 and args.batches > 1
+    prim = run_config(args.workload, ctx, args, O, graph=args.graph, pull=args.pull, L=args.L, steps=args.steps, warmup=args.warmup,
+                      stream=(args.pull != 0 and not args.resident_graph), reserve_rows=(args.pull != 0), Q=args.queries,
+                      shape_n=args.shape_n, batches=args.batches, lanes=lanes, threads=threads, keep=True)
+    res, agg, L, graph = prim["res"], prim["res"]["agg"], prim["L"], prim["graph"]
+    ix = prim["wl"]["ix"]
+    ids_primary = res["ids"]
+    m_primary, D_primary, dtype_primary = ix.m, ix.D, ix.dtype
+    out, cfg = None, {}
     if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline and orc is not None:
-            nthreads = usable_cpus()
-            orc.search(queries[: min(Q, 512)], k, L, nthreads=nthreads)     # warm
-            reps, t_cpu = 0, 0.0
-            while reps < 5 and t_cpu < 10.0:
-                t_a = time.perf_counter()
-                orc.search(queries, k, L, nthreads=nthreads)
-                t_cpu += time.perf_counter() - t_a
-                reps += 1
-            cpu = {"value": round(Q * reps / t_cpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
-                   "sample": f"{reps} x the full {Q}-query batch at L={L} through oracle/ (C + OpenMP, {nthreads} threads = "
-                             f"the CPU quota of this box; {os.cpu_count()} hardware threads visible), same timed region "
-                             f"(search only)"}
-        cfg = {"workload": wl["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
-               "graph": graph, "graph_placement": placement_note or f"{graph} (requested)",
+        recall = prim["recall"]
+        cfg = {"workload": prim["wl"]["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
+               "graph": graph, "graph_placement": prim["placement_note"] or f"{graph} (requested)",
                "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
                "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
-               "iterations": agg["iterations"], "hops_p50_p99_max": [agg["hops_p50"], agg["hops_p99"], agg["hops_max"]],
+               "iterations": agg["iterations"], "hops_p50": agg["hops_p50"], "hops_p99": agg["hops_p99"], "hops_max": agg["hops_max"],
                "host_loop": host_loop_name(agg, graph),
                "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                                   "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
@@ -582,123 +699,167 @@ def main():
                "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
                "pcie_pulled_bytes_per_step": int(agg["pulled_bytes"] // args.steps),
                "qps_incl_init": res["qps_incl_init"],
-               "parity_vs_oracle_first_64" if gt_i is not None else "result_properties_ok": parity_ok,
+               "parity_vs_oracle_first_64" if prim["structured"] else "result_properties_ok": prim["ok"],
                "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
                "front_busy_ms_per_step": round(agg["front_busy_ms"] / args.steps, 3),
                "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
                "dist_evals_per_step": agg["dist_evals"] // args.steps,
-               "step_ms_min_max": [min(res["step_ms"]), max(res["step_ms"])], "step_ms": res["step_ms"]}
+               "filter_probes_per_step": 2 * agg["fetched"] // args.steps,
+               "filter_loads_skipped_per_step": agg["filter_loads_skipped"] // args.steps,
+               "search_ms_per_step_max_over_ranks": res.get("search_ms"), "gather_ms_per_step_max_over_ranks": res.get("gather_ms"),
+               "step_ms_min": min(res["step_ms"]), "step_ms_max": max(res["step_ms"]), "step_ms": res["step_ms"]}
         out = {"metric": "queries/sec @ recall@10>=0.9, 10K-query batch", "value": res["queries_per_s"], "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": ARITH_DTYPE,
-               "data": "synthetic", "config": cfg, "roofline": res["roofline"], "cpu_baseline": cpu}
+               "data": "synthetic", "config": cfg, "roofline": res["roofline"], "cpu_baseline": None}
 
-    # ------------------------------------------------------------------ legs (single GPU only): the other BASELINE configs
-    legs = world == 1 and not args.no_legs and args.workload == "sift1m" and not os.environ.get("BANG_BENCH_NO_LEGS")
-    leg_steps, leg_warm = 5, 1
-    if legs and gt_i is not None and L != 200 and not os.environ.get("BANG_BENCH_NO_L200"):
+    want = set(x for x in args.legs.split(",") if x)
+    legs = world == 1 and not args.no_legs and not os.environ.get("BANG_BENCH_NO_LEGS")
+
+    def leg_on(name):
+        return legs and (not want or name in want)
+
+    # the CPU baseline of a structured primary needs its index: before the release
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and prim["structured"]:
+        out["cpu_baseline"] = cpu_baseline_structured(prim, O, k, prim["wl"]["queries"])
+    if leg_on("L200") and prim["structured"] and L != 200:
         # BASELINE.json configs[1] also names L = 200: the same batch at that worklist length
-        eng.free()
-        eng.set_searchparams(k, 200)
-        eng.alloc(Qr)
-        r2 = measure(eng, wl, my_q, 200, 3, 1, ctx, graph)
-        ids_o, _ = orc.search(my_q[:64], k, 200)
-        cfg["at_L200"] = leg_summary(r2, wl, graph, recall=recall_of(r2["ids"]),
+        e = prim["eng"]
+        e.free(); e.set_searchparams(k, 200); e.alloc(prim["Qr"])
+        r2 = measure(e, prim["wl"], prim["my_q"], 200, 3, 1, ctx, graph)
+        ids_o, _ = prim["orc"].search(prim["my_q"][:64], k, 200)
+        cfg["at_L200"] = leg_summary(r2, prim["wl"], graph, recall=O.recall(prim["wl"]["gt_i"], prim["wl"]["gt_d"], r2["ids"], k),
                                      extra={"parity_vs_oracle_first_64": bool(np.array_equal(r2["ids"][:64], ids_o))})
-    eng.free()
-    eng.unload()
-    eng.close()
-    if legs and gt_i is not None:
-        other = "device" if graph == "host" else "host"
-        e2 = make_engine(wl, other, ctx, timing=0 if args.no_events else 1)
-        e2.set_searchparams(k, L)
-        e2.alloc(Qr)
-        r3 = measure(e2, wl, my_q, L, leg_steps, leg_warm, ctx, other, traffic_key=f"{args.workload}_{other}")
-        cfg[f"at_{other}_graph"] = leg_summary(r3, wl, other, recall=recall_of(r3["ids"]),
-                                               extra={"ids_equal_primary_run": bool(np.array_equal(r3["ids"], ids))})
-        e2.free(); e2.unload(); e2.close()
-        # the north-star data flow (C++ walker threads serve the adjacency lists) beside the pull mode
-        e2 = make_engine(wl, "host", ctx, timing=0 if args.no_events else 1, pull=0)
-        e2.set_searchparams(k, L)
-        e2.alloc(Qr)
-        r3 = measure(e2, wl, my_q, L, leg_steps, leg_warm, ctx, "host")
-        cfg["at_host_graph_walker"] = leg_summary(r3, wl, "host", recall=recall_of(r3["ids"]),
-                                                  extra={"ids_equal_primary_run": bool(np.array_equal(r3["ids"], ids))})
-        e2.free(); e2.unload(); e2.close()
+        flat(cfg, "L200", cfg["at_L200"])
+    release_config(prim)
+
+    # ------------------------------------------------------------------ K2 alone (the stage the BASELINE metric quotes an HBM figure for)
     k2 = {}
-    if legs:
-        k2[f"m{ix.m}"] = k2_alone(ix.D, ix.m, ix.dtype, ctx)
-    wl["release"]()
-    del wl, ix, queries
-    torch.cuda.empty_cache()
-    if legs:
-        for name in ("deep100m_shape", "sift1b_shape"):
-            try:
-                w2 = build_workload(name, ctx, stream=True)      # sift1b_shape: streamed load, N as large as the pull rows allow
-                q2 = np.ascontiguousarray(w2["queries"])
-                e3 = make_engine(w2, w2["graph"], ctx, timing=0 if args.no_events else 1)
-                e3.set_searchparams(k, 152)                  # the reference's SIFT1B setting, BANG_Inmemory/parANN.h:99
-                e3.alloc(q2.shape[0])
-                r4 = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, w2["graph"], traffic_key=f"{name}_{w2['graph']}")
-                props = check_properties(w2["ix"], q2, r4["ids"], r4["dists"], k)
-                cfg[f"at_{name}"] = leg_summary(r4, w2, w2["graph"], props=props)
-                e3.free(); e3.unload(); e3.close()
-                k2[f"m{w2['ix'].m}"] = k2_alone(w2["ix"].D, w2["ix"].m, w2["ix"].dtype, ctx)
-                w2["release"]()
-                del w2, q2, e3
-                torch.cuda.empty_cache()
-            except Exception as ex:                          # a leg must never take the primary line down
-                cfg[f"at_{name}"] = {"error": repr(ex)[:300]}
+    if leg_on("k2") and out is not None and out["roofline"] is not None:
         try:
+            k2[f"m{m_primary}"] = k2_alone(D_primary, m_primary, dtype_primary, ctx)
+            out["roofline"]["k2_alone"] = k2[f"m{m_primary}"]
+            cfg["k2_alone_frac"] = k2[f"m{m_primary}"]["frac"]
+            cfg["k2_alone_GBps"] = k2[f"m{m_primary}"]["achieved"]
+        except Exception as ex:
+            out["roofline"]["k2_alone"] = {"error": repr(ex)[:300]}
+
+    # ------------------------------------------------------------------ CPU baseline beside a shape-only primary
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not prim["structured"]:
+        try:
+            out["cpu_baseline"] = cpu_baseline_shape(args.workload, ctx, args, O, L)
+            cfg["reduced_n_hip_ids_equal_oracle"] = out["cpu_baseline"]["hip_ids_equal_oracle_on_sample"]
+        except Exception as ex:
+            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": usable_cpus(), "kind": "port", "sample": "FAILED: " + repr(ex)[:300]}
+
+    # ------------------------------------------------------------------ legs (single GPU only): the other BASELINE configurations
+    leg_steps, leg_warm = 5, 1
+
+    def guarded(key, fn):
+        try:
+            fn()
+        except Exception as ex:                              # a leg must never take the primary line down
+            cfg[key] = {"error": repr(ex)[:300]}
+            cfg[key.replace("at_", "") + "_error"] = repr(ex)[:120]
+            torch.cuda.empty_cache()
+
+    if leg_on("sift1m") and args.workload != "sift1m":
+        def leg_sift1m():
+            # configs[1]: SIFT1M-like, recall-verified; engine default placement (HBM), then the host placement in both loop forms
+            r1 = run_config("sift1m", ctx, args, O, steps=leg_steps, warmup=leg_warm, keep=True)
+            wl1 = r1["wl"]
+            cfg["at_sift1m"] = leg_summary(r1["res"], wl1, r1["graph"], recall=r1["recall"], extra={"parity_vs_oracle_first_64": r1["ok"]})
+            flat(cfg, "sift1m", cfg["at_sift1m"])
+            ids1, L1, q1_ = r1["res"]["ids"], r1["L"], r1["my_q"]
+            e = r1["eng"]
+            e.free(); e.set_searchparams(k, 200); e.alloc(r1["Qr"])
+            r2 = measure(e, wl1, q1_, 200, 3, 1, ctx, r1["graph"])
+            ids_o, _ = r1["orc"].search(q1_[:64], k, 200)
+            cfg["at_sift1m_L200"] = leg_summary(r2, wl1, r1["graph"], recall=O.recall(wl1["gt_i"], wl1["gt_d"], r2["ids"], k),
+                                                extra={"parity_vs_oracle_first_64": bool(np.array_equal(r2["ids"][:64], ids_o))})
+            flat(cfg, "sift1m_L200", cfg["at_sift1m_L200"])
+            if not args.no_cpu_baseline:
+                cb = cpu_baseline_structured(r1, O, k, wl1["queries"])
+                cfg["at_sift1m"]["cpu_baseline"] = cb
+                cfg["sift1m_cpu_qps"] = cb["value"]
+            k2[f"m{wl1['ix'].m}"] = k2_alone(wl1["ix"].D, wl1["ix"].m, wl1["ix"].dtype, ctx)
+            e.free(); e.unload(); e.close()
+            r1["eng"] = None
+            for key, pull in (("sift1m_host_pull", -1), ("sift1m_host_walker", 0)):
+                e2 = make_engine(wl1, "host", ctx, timing=0 if args.no_events else 1, pull=pull)
+                e2.set_searchparams(k, L1)
+                e2.alloc(q1_.shape[0])
+                r3 = measure(e2, wl1, q1_, L1, leg_steps, leg_warm, ctx, "host", traffic_key=("sift1m_host" if pull else None))
+                cfg["at_" + key] = leg_summary(r3, wl1, "host", recall=O.recall(wl1["gt_i"], wl1["gt_d"], r3["ids"], k),
+                                               extra={"ids_equal_device_run": bool(np.array_equal(r3["ids"], ids1))})
+                flat(cfg, key, cfg["at_" + key])
+                cfg[key + "_ids_equal_device_run"] = cfg["at_" + key]["ids_equal_device_run"]
+                e2.free(); e2.unload(); e2.close()
+            release_config(r1)
+        guarded("at_sift1m", leg_sift1m)
+
+    if leg_on("deep100m") and args.workload != "deep100m_shape":
+        def leg_deep():
+            r = run_config("deep100m_shape", ctx, args, O, steps=leg_steps, warmup=leg_warm, keep=True)
+            cfg["at_deep100m_shape"] = leg_summary(r["res"], r["wl"], r["graph"], props=r["ok"])
+            flat(cfg, "deep100m_shape", cfg["at_deep100m_shape"])
+            ixd = r["wl"]["ix"]
+            mm, DD, dt = ixd.m, ixd.D, ixd.dtype
+            release_config(r)
+            k2[f"m{mm}"] = k2_alone(DD, mm, dt, ctx)
+        guarded("at_deep100m_shape", leg_deep)
+
+    if leg_on("sift1b") and args.workload != "sift1b_shape":
+        def leg_1b():
+            r = run_config("sift1b_shape", ctx, args, O, steps=leg_steps, warmup=leg_warm, keep=True)
+            cfg["at_sift1b_shape"] = leg_summary(r["res"], r["wl"], r["graph"], props=r["ok"])
+            flat(cfg, "sift1b_shape", cfg["at_sift1b_shape"])
+            release_config(r)
+        guarded("at_sift1b_shape", leg_1b)
+
+    if leg_on("walker"):
+        def leg_walker():
             # the north-star data flow on its own configuration: a resident graph image served by the C++ walker threads
-            w2 = build_workload("sift1b_shape", ctx, reserve_rows=False, stream=False)
-            q2 = np.ascontiguousarray(w2["queries"])
-            e3 = make_engine(w2, "host", ctx, timing=0 if args.no_events else 1, pull=0)
-            e3.set_searchparams(k, 152)
-            e3.alloc(q2.shape[0])
-            r4w = measure(e3, w2, q2, 152, leg_steps, leg_warm, ctx, "host")
-            cfg["at_sift1b_shape_walker"] = leg_summary(r4w, w2, "host", props=check_properties(w2["ix"], q2, r4w["ids"], r4w["dists"], k))
-            e3.free(); e3.unload(); e3.close()
-            w2["release"]()
-            del w2, q2, e3
-            torch.cuda.empty_cache()
-        except Exception as ex:
-            cfg["at_sift1b_shape_walker"] = {"error": repr(ex)[:300]}
-        # a structured index beyond the Infinity Cache (N = 10 M: 320 MB of codes, 3.9 GB graph), recall-verified, both placements
-        try:
-            w3 = build_workload("sift10m", ctx)
-            q3 = np.ascontiguousarray(w3["queries"])
-            orc3 = O.Oracle(w3["ix"])
-            L3 = 0
-            for gname in ("host", "device"):
-                e4 = make_engine(w3, gname, ctx, timing=0 if args.no_events else 1)
-                if L3 == 0:
-                    for cand in range(k, 513, 12):           # smallest L on the harness grid with recall >= target
-                        e4.set_searchparams(k, cand)
-                        e4.alloc(q3.shape[0])
-                        ids_c, _, _ = run_once(e4, q3, ctx)
-                        e4.free()
-                        if O.recall(w3["gt_i"], w3["gt_d"], ids_c, k) >= args.recall_target:
-                            L3 = cand
-                            break
-                    if L3 == 0:
-                        raise RuntimeError("recall target not reached")
-                e4.set_searchparams(k, L3)
-                e4.alloc(q3.shape[0])
-                r5 = measure(e4, w3, q3, L3, leg_steps, leg_warm, ctx, gname)
-                ids_o3, _ = orc3.search(q3[:64], k, L3)
-                cfg["at_sift10m" if gname == "host" else "at_sift10m_device_graph"] = leg_summary(
-                    r5, w3, gname, recall=O.recall(w3["gt_i"], w3["gt_d"], r5["ids"], k),
-                    extra={"parity_vs_oracle_first_64": bool(np.array_equal(r5["ids"][:64], ids_o3))})
-                e4.free(); e4.unload(); e4.close()
-            w3["release"]()
-            del w3, q3, orc3
-            torch.cuda.empty_cache()
-        except Exception as ex:
-            cfg["at_sift10m"] = {"error": repr(ex)[:300]}
-        if out is not None and out["roofline"] is not None:
-            out["roofline"]["k2_alone"] = k2.get(f"m{WORKLOADS[args.workload][4]}")
-            out["roofline"]["k2_alone_other_layouts"] = {kk: v for kk, v in k2.items() if kk != f"m{WORKLOADS[args.workload][4]}"}
+            r = run_config("sift1b_shape", ctx, args, O, graph="host", pull=0, steps=leg_steps, warmup=leg_warm, stream=False,
+                           reserve_rows=False, traffic=False, keep=True)
+            cfg["at_sift1b_shape_walker"] = leg_summary(r["res"], r["wl"], "host", props=r["ok"])
+            flat(cfg, "walker", cfg["at_sift1b_shape_walker"])
+            rf = r["res"]["roofline"] or {}
+            if "pcie_h2d" in rf:
+                cfg["walker_bar_GBps"] = rf["pcie_h2d"]["achieved_GBps"]
+                cfg["at_sift1b_shape_walker"]["pcie_h2d"] = rf["pcie_h2d"]
+            a = r["res"]["agg"]
+            cfg["walker_threads"] = a["walker_threads"]
+            cfg["walker_step_ms_min"], cfg["walker_step_ms_max"] = min(r["res"]["step_ms"]), max(r["res"]["step_ms"])
+            release_config(r)
+        guarded("at_sift1b_shape_walker", leg_walker)
+
+    if leg_on("sift10m"):
+        def leg_10m():
+            # a structured index beyond the Infinity Cache (N = 10 M: 320 MB of codes, 3.9 GB graph), recall-verified, both placements
+            r = run_config("sift10m", ctx, args, O, graph="host", steps=leg_steps, warmup=leg_warm, keep=True)
+            w3 = r["wl"]
+            cfg["at_sift10m"] = leg_summary(r["res"], w3, "host", recall=r["recall"], extra={"parity_vs_oracle_first_64": r["ok"]})
+            flat(cfg, "sift10m", cfg["at_sift10m"])
+            e = r["eng"]
+            e.free(); e.unload(); e.close()
+            r["eng"] = None
+            e4 = make_engine(w3, "device", ctx, timing=0 if args.no_events else 1)
+            e4.set_searchparams(k, r["L"])
+            e4.alloc(r["Qr"])
+            r5 = measure(e4, w3, r["my_q"], r["L"], leg_steps, leg_warm, ctx, "device")
+            cfg["at_sift10m_device_graph"] = leg_summary(r5, w3, "device", recall=O.recall(w3["gt_i"], w3["gt_d"], r5["ids"], k),
+                                                         extra={"ids_equal_host_run": bool(np.array_equal(r5["ids"], r["res"]["ids"]))})
+            flat(cfg, "sift10m_device", cfg["at_sift10m_device_graph"])
+            e4.free(); e4.unload(); e4.close()
+            release_config(r)
+        guarded("at_sift10m", leg_10m)
+
+    if out is not None and out["roofline"] is not None and k2:
+        out["roofline"]["k2_alone_other_layouts"] = {kk: v for kk, v in k2.items() if kk != f"m{m_primary}"}
+        for kk, v in k2.items():
+            if v:
+                cfg[f"k2_alone_{kk}_frac"] = v["frac"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

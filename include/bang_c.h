@@ -114,6 +114,11 @@ int bang_alloc_e(bang_engine_t* e, int num_queries);                            
 int bang_init_e(bang_engine_t* e, int num_queries);                                         /* bang.h:56 */
 /* bang_query, bang.h:75: ids [Q][k] u64, dists [k][Q] f32 (rank-major, bang_search.cu:999) */
 int bang_query_e(bang_engine_t* e, const void* h_queries, int num_queries, uint64_t* h_ids, float* h_dists);
+/* The same search with the results LEFT ON THE DEVICE: d_ids [Q][k] u64 and (optional, may be NULL) d_dists [k][Q] f32 are device
+ * buffers of the caller on the engine's device; nothing but the per-query iteration counts returns to the host.  For callers that
+ * hand the ids on from device memory -- the multi-GPU job all-gathers the shards' id blocks over xGMI straight from here (SURVEY
+ * 8(e)) instead of bouncing them through the host.  Complete (stream synchronised) on return. */
+int bang_query_dev_e(bang_engine_t* e, const void* h_queries, int num_queries, uint64_t* d_ids, float* d_dists);
 int bang_free_e(bang_engine_t* e);                                                          /* bang.h:80 */
 int bang_unload_e(bang_engine_t* e);                                                        /* bang.h:82 */
 
@@ -153,6 +158,8 @@ typedef struct {
   uint64_t graph_pull;        /* host-graph placement: 1 = PULL mode -- the adjacency lists live as 256-byte rows in pinned host memory
                                  and the self-paced search kernel fetches them over PCIe by itself (no walker thread in the loop) */
   uint64_t pulled_bytes;      /* pull mode: bytes of adjacency rows the kernel fetched over PCIe (256 per expansion) */
+  uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
+                                 summary knew the word was still zero (of 2 x `fetched` probes) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -315,6 +322,8 @@ typedef struct {
                                           advance independently; pacing group index = (g * groups_per_workgroup + group) * nctx + c */
   unsigned long long* d_prof;          /* diagnostic, host-paced form: [G][8] 100 MHz ticks thread 0 of each workgroup spent {waiting for
                                           rows, in the front half up to the publish barrier, publishing, in sort/merge}, [4] = half-rounds; or NULL */
+  uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the
+                                          word was still zero (self-paced form; 0 in the host-paced form) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */

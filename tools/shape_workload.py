@@ -125,7 +125,7 @@ class ShapeIndex:
 
 
 def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None, reserve_rows=True,
-         stream=False):
+         stream=False, planned=False):
     """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
     can run on the index (parity tests at > 4 GiB offsets); default: straight on the device, host copy absent.
     shared=(path, is_creator, barrier): the graph image lives in ONE mapping of the file `path` shared by every rank of the node
@@ -141,8 +141,9 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     ncpu = usable_cpus()
     note = ""
     stream = bool(stream and sh["graph"] == "host" and not host_codes)
-    if shared is not None and n_override:
-        pass                                   # N was planned once for the node (plan_n on the creator) and handed to every rank
+    if n_override and (planned or shared is not None):
+        pass                                   # N was planned once for the node (plan_n on rank 0) and handed to every rank: final.  Ranks that
+                                               # re-scaled it from their own momentary memory figures could end up with different indices
     elif stream:
         # STREAMED: the graph image never exists -- the engine pulls the generator's entries through in chunks (vectors -> HBM,
         # adjacency lists -> 256-byte pull rows in host memory).  Host budget: the rows; HBM budget: codes + vectors + 28 GB.
