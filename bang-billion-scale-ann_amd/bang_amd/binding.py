@@ -55,7 +55,7 @@ class SearchParams(C.Structure):
         ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
-        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("d_qskip", C.c_void_p),
+        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
     ]
 
 

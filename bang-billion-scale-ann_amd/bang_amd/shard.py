@@ -36,20 +36,24 @@ def gather_ids(ids_local: np.ndarray, Q: int, k: int, rank: int, world: int, dev
 class DeviceGather:
     """The collective of a sharded step with the ids never leaving device memory: the engine writes this rank's [Q/W][k] block into
     `mine` (bang_query_dev_e), ONE all_gather_into_tensor (RCCL over xGMI) fills `all` on every rank, and only the rank that hands
-    the batch's answer to its caller copies the gathered block to the host (once).  Buffers are allocated once per allocation, not per step."""
+    the batch's answer to its caller copies the gathered block to the host (once).  Buffers are allocated once per allocation, not
+    per step.  coll_device != device (gloo dry runs on a shared GPU -- RCCL refuses two ranks on one device): the engine still
+    leaves the ids in `mine` on the device; the block is staged to the collective's device for the gather."""
 
-    def __init__(self, Q: int, k: int, rank: int, world: int, device):
+    def __init__(self, Q: int, k: int, rank: int, world: int, device, coll_device=None):
         import torch
         self.Q, self.k, self.rank, self.world = Q, k, rank, world
         self.pad = (Q + world - 1) // world
         self.q0, self.q1 = shard_range(Q, rank, world)
+        self.coll_device = coll_device if coll_device is not None else device
         self.mine = torch.zeros((self.pad, k), dtype=torch.int64, device=device)
-        self.all = torch.empty((world * self.pad, k), dtype=torch.int64, device=device)
+        self.all = torch.empty((world * self.pad, k), dtype=torch.int64, device=self.coll_device)
         self.dists = torch.zeros((k, self.q1 - self.q0), dtype=torch.float32, device=device)   # this rank's distances [k][Q/W] (not gathered)
 
     def gather(self):
         import torch.distributed as dist
-        dist.all_gather_into_tensor(self.all, self.mine)
+        src = self.mine if self.mine.device == self.all.device else self.mine.to(self.all.device)
+        dist.all_gather_into_tensor(self.all, src)
         return self.all
 
     def local_ids(self) -> np.ndarray:

@@ -1,0 +1,343 @@
+// bang_cabi.cpp -- the engine-level C-ABI of include/bang_c.h: thin entry points over the engine (bang.h:36-87 / :89-101).
+#include "bang_engine.h"
+
+using namespace bang;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+extern "C" void bang_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* bang_last_error(void) { return g_err; }
+
+extern "C" int bang_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------ device helpers
+extern "C" int bang_dev_malloc(void** d_ptr, size_t bytes) {
+  if (!d_ptr) return BANG_ERR_ARG;
+  if (bang_device_count() == 0) { bang_set_error("no HIP device"); return BANG_ERR_NOGPU; }
+  HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 4));
+  return BANG_OK;
+}
+extern "C" int bang_dev_free(void* d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return BANG_OK; }
+extern "C" int bang_dev_memset(void* d_ptr, int value, size_t bytes) { HIP_TRY(hipMemset(d_ptr, value, bytes)); return BANG_OK; }
+extern "C" int bang_dev_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return BANG_OK;
+}
+extern "C" int bang_dev_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return BANG_OK;
+}
+extern "C" int bang_dev_sync(void) { HIP_TRY(hipDeviceSynchronize()); return BANG_OK; }
+
+// ------------------------------------------------------------------ C-ABI, engine level
+extern "C" int bang_create(int dtype, bang_engine_t** out) {
+  if (!out || dtype < BANG_U8 || dtype > BANG_F32) { bang_set_error("bad dtype"); return BANG_ERR_ARG; }
+  bang_engine* e = new (std::nothrow) bang_engine();
+  if (!e) return BANG_ERR_NOMEM;
+  e->dtype = dtype;
+  e->tsize = (dtype == BANG_F32) ? 4 : 1;
+  // presets from the environment, so that callers of the bang.h class API (no option methods, e.g. the bang_search CLI) can still
+  // choose placement and loop form (bang_options.cpp: BANG_GRAPH=host|device|auto, BANG_PULL, BANG_THREADS, ...)
+  apply_env_defaults(e);
+  *out = e;
+  return BANG_OK;
+}
+
+extern "C" int bang_destroy(bang_engine_t* e) {
+  if (!e) return BANG_OK;
+  if (e->allocated) free_batch(e);
+  if (e->loaded) unload_index(e);
+  delete e;
+  return BANG_OK;
+}
+
+extern "C" int bang_load_e(bang_engine_t* e, const char* prefix) {
+  if (!e || !prefix) return BANG_ERR_ARG;
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  return load_files(e, prefix);
+}
+
+extern "C" int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* d) {
+  if (!e || !d || !d->graph || !d->pivots || !d->centroid || !d->chunk_off || (!d->codes && !d->d_codes)) {
+    bang_set_error("bad index descriptor");
+    return BANG_ERR_ARG;
+  }
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
+  e->graph = d->graph;
+  e->graph_owned = nullptr;
+  e->graph_path.clear();
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+extern "C" int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* d, bang_entry_source src, void* ctx) {
+  if (!e || !d || !src || d->graph || !d->pivots || !d->centroid || !d->chunk_off || (!d->codes && !d->d_codes)) {
+    bang_set_error("bad index descriptor (a streamed load takes an entry source and no graph pointer)");
+    return BANG_ERR_ARG;
+  }
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
+  e->graph = nullptr;
+  e->graph_owned = nullptr;
+  e->graph_path.clear();
+  if (e->graph_mode == BANG_GRAPH_DEVICE) { bang_set_error("a streamed load keeps the adjacency lists on the host (pull mode): option graph = device does not apply"); return BANG_ERR_UNSUPPORTED; }
+  e->graph_mode = BANG_GRAPH_HOST;                       // (auto included: there is no graph image to put into HBM)
+  if (e->entry_len != (uint64_t)e->D * e->tsize + 4 + 4ull * e->R) {
+    bang_set_error("index entry length %llu does not match D=%u x %zu B + 4 + 4 x R=%u", (unsigned long long)e->entry_len, e->D, e->tsize, e->R);
+    return BANG_ERR_ARG;
+  }
+  e->entry_fn = src; e->entry_ctx = ctx;
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  e->entry_fn = nullptr; e->entry_ctx = nullptr;
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+extern "C" int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn) {
+  if (!e) return BANG_ERR_ARG;
+  if (recall <= 0 || worklist_length < recall || worklist_length > BANG_MAX_L ||            // assert(2L <= 1024) :439
+      (distfn != BANG_DIST_L2 && distfn != BANG_DIST_MIPS)) {
+    bang_set_error("bad search params: recall=%d L=%d distfn=%d", recall, worklist_length, distfn);
+    return BANG_ERR_ARG;
+  }
+  if (e->allocated && (recall != e->k || worklist_length != e->L)) {
+    bang_set_error("bang_free must be called before changing recall / worklist length");   // sizes depend on them :370-384
+    return BANG_ERR_ARG;
+  }
+  e->k = recall; e->L = worklist_length; e->distfn = distfn;
+  e->params_set = true;
+  return BANG_OK;
+}
+
+extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
+  if (!e || Q <= 0) return BANG_ERR_ARG;
+  if (!e->loaded || !e->params_set) { bang_set_error("bang_alloc: load an index and set search params first"); return BANG_ERR_ARG; }
+  if (e->allocated) { bang_set_error("bang_alloc: already allocated (call bang_free)"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->Qcap = Q;
+  e->Qcur = 0;
+  e->cand_stride = (uint32_t)e->L + BANG_EXTRA_ITERS;
+  const int rc = alloc_buffers(e, Q);
+  if (rc != BANG_OK) { free_batch(e); return rc; }
+  e->allocated = true;
+  e->inited = false;
+  return BANG_OK;
+}
+
+extern "C" int bang_init_e(bang_engine_t* e, int Q) {
+  if (!e || !e->allocated || Q <= 0 || Q > e->Qcap) { bang_set_error("bang_init: bad state / numQueries"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  const size_t nq = (size_t)Q;
+  HIP_TRY(hipMemsetAsync(e->d_bloom, 0, nq * BANG_BF_WORDS * 4, nullptr));                  // :443
+  HIP_TRY(hipMemsetAsync(e->d_qstats, 0, nq * 8, nullptr));
+  HIP_TRY(hipMemsetAsync(e->d_qskip, 0, nq * 4, nullptr));
+  if (e->d_active) HIP_TRY(hipMemsetAsync(e->d_active, 0, ((size_t)e->cand_stride + 2) * 4, nullptr));
+  BANG_TRY(bang_k_init_state((uint32_t)Q, (uint32_t)e->medoid, e->cand_stride, e->d_cand_ids, e->d_cand_row, e->d_cand_cnt,
+                             e->d_wl_cnt, e->d_mark, e->d_parents_dev, e->d_cnt, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->h_parents) for (size_t i = 0; i < nq; ++i) e->h_parents[i] = BANG_NO_PARENT;
+  e->inited = true;
+  return BANG_OK;
+}
+
+static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists, uint64_t* d_ids_user, float* d_dists_user);
+
+extern "C" int bang_query_e(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists) {
+  if (!e || !h_queries || !h_ids || !h_dists) return BANG_ERR_ARG;
+  return query_impl(e, h_queries, Q, h_ids, h_dists, nullptr, nullptr);
+}
+
+extern "C" int bang_query_dev_e(bang_engine_t* e, const void* h_queries, int Q, uint64_t* d_ids, float* d_dists) {
+  if (!e || !h_queries || !d_ids) return BANG_ERR_ARG;
+  return query_impl(e, h_queries, Q, nullptr, nullptr, d_ids, d_dists);
+}
+
+static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* h_ids, float* h_dists, uint64_t* d_ids_user, float* d_dists_user) {
+  if (!e->allocated || !e->inited) { bang_set_error("bang_query: bang_alloc + bang_init must precede every query"); return BANG_ERR_ARG; }
+  if (Q <= 0 || Q > e->Qcap) { bang_set_error("bang_query: numQueries %d exceeds allocation %d", Q, e->Qcap); return BANG_ERR_ARG; }
+  e->inited = false;   // state is consumed
+  e->Qcur = Q;
+  // the calling thread is lane 0's walker: it joins the GPU's NUMA node for the duration of the query
+  cpu_set_t caller_cpus;
+  const bool repin = e->numa_on && sched_getaffinity(0, sizeof(caller_cpus), &caller_cpus) == 0;
+  if (repin) pin_walker_thread(e, 0);
+  const auto t0 = Clock::now();
+  const int nl = (int)e->lanes.size();
+  for (int i = 0; i < nl; ++i) {                       // lanes were laid out for Qcap; re-slice for this Q
+    Lane& ln = *e->lanes[(size_t)i];
+    ln.q0 = (uint32_t)((size_t)Q * i / nl);
+    ln.nq = (uint32_t)((size_t)Q * (i + 1) / nl) - ln.q0;
+  }
+  std::atomic<bool> wd_stop{false};
+  std::thread wd;
+  if (const char* wd_path = env_str("BANG_WATCHDOG")) {
+    wd = std::thread([&, wd_path] {
+      FILE* wf = fopen(wd_path, "a");
+      if (!wf) wf = stderr;
+      int ticks = 0;
+      while (!wd_stop.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (++ticks % 50 == 0) {
+          for (auto& lp : e->lanes)
+            fprintf(wf, "[watchdog] lane %d phase %d iter %u pending %u epoch %u flag %u active %d\n", lp->index, lp->phase.load(),
+                    lp->phase_iter.load(), lp->pending.load(), lp->epoch.load(), e->h_done ? e->h_done[(size_t)lp->index * 16] : 0u,
+                    (int)lp->team_active.load());
+          fflush(wf);
+        }
+      }
+      if (wf != stderr) fclose(wf);
+    });
+  }
+  Pool& pool = e->pool;
+  {
+    std::lock_guard<std::mutex> lk(pool.m);
+    pool.h_queries = h_queries; pool.h_ids = h_ids; pool.h_dists = h_dists; pool.Q = Q;
+    pool.d_ids_user = d_ids_user; pool.d_dists_user = d_dists_user;
+    pool.lanes_done = 0;
+    ++pool.query_seq;
+  }
+  pool.cv_start.notify_all();
+  lane_job(e, *e->lanes[0]);                           // lane 0 on the calling thread
+  if (nl > 1) {
+    std::unique_lock<std::mutex> lk(pool.m);
+    pool.cv_done.wait(lk, [&] { return pool.lanes_done == nl - 1; });
+  }
+  if (wd.joinable()) { wd_stop.store(true); wd.join(); }
+  if (repin) (void)sched_setaffinity(0, sizeof(caller_cpus), &caller_cpus);
+  int rc = BANG_OK;
+  for (auto& lp : e->lanes)
+    if (lp->rc != BANG_OK) { rc = lp->rc; bang_set_error("%s", lp->err.c_str()); break; }
+  bang_stats& s = e->stats;
+  memset(&s, 0, sizeof(s));
+  s.wall_ms = ms_since(t0);
+  for (auto& lp : e->lanes) {
+    Lane& ln = *lp;
+    s.iterations = std::max<uint64_t>(s.iterations, ln.iterations);
+    s.front_launches += ln.front_launches;
+    s.front_ms += ln.front_ms; s.back_ms += ln.back_ms; s.rerank_ms += ln.rerank_ms; s.walker_ms += ln.walker_ms;
+    s.sync_ms += ln.sync_ms; s.enqueue_ms += ln.enqueue_ms;
+    s.h2d_bytes += ln.h2d_bytes.load();
+  }
+  s.persistent = (e->search_v2 || e->search_host) ? 1 : 0;
+  s.vectors_on_device = e->vec_on_device ? 1 : 0;
+  s.graph_mode = (uint64_t)e->graph_mode;
+  s.lanes = (uint64_t)nl;
+  s.walker_threads = (e->graph_mode == BANG_GRAPH_DEVICE || e->search_v2) ? 0 : (uint64_t)e->threads_eff;   // (pull mode: nothing walks)
+  s.wg_queries = e->search_host ? e->sv_W * e->sv_C : 0;
+  s.pacing_groups = e->search_host ? e->sv_NG : 0;
+  s.graph_pull = (e->pull && e->search_v2 && e->graph_mode != BANG_GRAPH_DEVICE) ? 1 : 0;
+  s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
+  s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
+  return rc;
+}
+
+// reduce the in-kernel stamps of a lane: per launch max(end) - min(start) over the workgroups that ran
+static int reduce_ktimes(Lane& ln, std::vector<std::pair<unsigned long long, unsigned long long>>& intervals) {
+  if (!ln.d_ktime || ln.kt_used == 0) return BANG_OK;
+  std::vector<unsigned long long> kt(ln.kt_used * KT_WGS * 2);
+  HIP_TRY(hipMemcpy(kt.data(), ln.d_ktime, kt.size() * 8, hipMemcpyDeviceToHost));
+  ln.front_ms = 0;
+  for (size_t l = 0; l < ln.kt_used; ++l) {
+    unsigned long long lo = ~0ull, hi = 0;
+    for (size_t w = 0; w < KT_WGS; ++w) {
+      const unsigned long long a = kt[(l * KT_WGS + w) * 2], b = kt[(l * KT_WGS + w) * 2 + 1];
+      if (a == 0 || b == 0) continue;                  // workgroup slot not used by this launch
+      lo = std::min(lo, a);
+      hi = std::max(hi, b);
+    }
+    if (hi > lo) { ln.front_ms += (double)(hi - lo) * 1e-5; intervals.emplace_back(lo, hi); }   // 100 MHz ticks -> ms
+  }
+  if (const char* path = env_str("BANG_KT_TRACE")) {            // raw stamps of lane 0 for offline analysis
+    if (ln.index == 0) if (FILE* f = fopen(path, "wb")) {
+      const uint64_t hdr[2] = {(uint64_t)ln.kt_used, (uint64_t)KT_WGS};
+      fwrite(hdr, 8, 2, f);
+      fwrite(kt.data(), 8, kt.size(), f);
+      fclose(f);
+    }
+  }
+  HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_used * KT_WGS * 16));
+  ln.kt_used = 0;
+  return BANG_OK;
+}
+
+extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
+  if (!e || !out) return BANG_ERR_ARG;
+  bang_stats& s = e->stats;
+  if (e->allocated && e->timing && s.front_ms == 0) {
+    std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+    for (auto& lp : e->lanes) { BANG_TRY(reduce_ktimes(*lp, iv)); s.front_ms += lp->front_ms; }
+    std::sort(iv.begin(), iv.end());                   // the stamps of all lanes share one 100 MHz clock: merge the intervals
+    unsigned long long cur_lo = 0, cur_hi = 0, busy = 0;
+    for (auto& p : iv) {
+      if (p.first > cur_hi) { busy += cur_hi - cur_lo; cur_lo = p.first; cur_hi = p.second; }
+      else cur_hi = std::max(cur_hi, p.second);
+    }
+    busy += cur_hi - cur_lo;
+    s.front_busy_ms = (double)busy * 1e-5;
+  }
+  if (e->allocated && e->Qcur > 0 && s.candidates == 0) {   // device-side counters are fetched lazily
+    std::vector<uint32_t> qs((size_t)e->Qcur * 2);
+    HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < qs.size(); i += 2) { s.dist_evals += qs[i]; s.fetched += qs[i + 1]; }
+    if (e->search_v2) {
+      std::vector<uint32_t> sk((size_t)e->Qcur);
+      HIP_TRY(hipMemcpy(sk.data(), e->d_qskip, sk.size() * 4, hipMemcpyDeviceToHost));
+      for (uint32_t v : sk) s.filter_loads_skipped += v;
+    }
+    std::vector<uint32_t> cc((size_t)e->Qcur);
+    HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t c : cc) s.candidates += c;
+    std::sort(cc.begin(), cc.end());
+    s.hops_p50 = cc[cc.size() / 2];
+    s.hops_p99 = cc[std::min(cc.size() - 1, (cc.size() * 99) / 100)];
+    s.hops_max = cc.back();
+    if (s.graph_pull) s.pulled_bytes = (s.candidates - (uint64_t)e->Qcur) * 256;      // one row per expansion (the seed list is on the device)
+  }
+  *out = s;
+  return BANG_OK;
+}
+
+extern "C" int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, uint32_t* fetched, uint32_t* candidates, uint32_t* iterations) {
+  if (!e) return BANG_ERR_ARG;
+  if (!e->allocated || e->Qcur <= 0) { bang_set_error("bang_get_query_counters: no query has run on this allocation"); return BANG_ERR_ARG; }
+  const size_t Q = (size_t)e->Qcur;
+  if (dist_evals || fetched) {
+    std::vector<uint32_t> qs(Q * 2);
+    HIP_TRY(hipMemcpy(qs.data(), e->d_qstats, qs.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < Q; ++i) { if (dist_evals) dist_evals[i] = qs[2 * i]; if (fetched) fetched[i] = qs[2 * i + 1]; }
+  }
+  if (candidates) HIP_TRY(hipMemcpy(candidates, e->d_cand_cnt, Q * 4, hipMemcpyDeviceToHost));
+  if (iterations) {
+    if ((e->search_v2 || e->search_host) && e->h_qiters.size() >= Q) memcpy(iterations, e->h_qiters.data(), Q * 4);
+    else memset(iterations, 0, Q * 4);
+  }
+  return BANG_OK;
+}
+
+extern "C" int bang_free_e(bang_engine_t* e) {
+  if (!e) return BANG_ERR_ARG;
+  if (e->allocated) { (void)hipSetDevice(e->device); free_batch(e); }
+  return BANG_OK;
+}
+
+extern "C" int bang_unload_e(bang_engine_t* e) {
+  if (!e) return BANG_ERR_ARG;
+  if (e->allocated) free_batch(e);
+  if (e->loaded) { (void)hipSetDevice(e->device); unload_index(e); }
+  return BANG_OK;
+}
+

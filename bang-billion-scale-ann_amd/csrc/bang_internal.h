@@ -30,9 +30,9 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
-// Hand-shake timeouts of the host-paced persistent kernel.  The HOST gives up first (it then stores STOP into every pacing
-// word, which ends the kernel at once); a workgroup only gives up on its own -- the host process is gone -- well after that.
-#define BANG_HOST_WALK_TIMEOUT_MS 20000.0
+// Hand-shake timeouts of the host-paced search kernel are run-time options (host_walk_timeout_ms = 20 000, kernel_go_timeout_ms =
+// 30 000: bang_options.cpp).  The HOST gives up first -- it then stores STOP into every pacing word, which ends the kernel at once;
+// a pacing group only gives up on its own (the host process is gone) well after that.  Default of a launch without the field set:
 #define BANG_KERNEL_GO_TIMEOUT_TICKS 3000000000ull   /* 30 s of the 100 MHz s_memrealtime clock */
 #define BANG_RESULT_MAILBOX_BYTES (8 * 1024 * 1024)   // results (ids + distances) up to this size return through the pinned mirror in one copy (BANG_MAILBOX_BYTES)
 

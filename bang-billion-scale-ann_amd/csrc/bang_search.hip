@@ -435,6 +435,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   const uint32_t nwaves = blockDim.x >> 6;
   const uint32_t nctx = HOST ? a.nctx : 1u;
   const uint32_t L = p.L, medoid = p.medoid, cap_iter = p.cap_iter;
+  const unsigned long long go_timeout = p.go_timeout_ticks ? p.go_timeout_ticks : BANG_KERNEL_GO_TIMEOUT_TICKS;   // 100 MHz ticks
   // a wave's LDS region: [worklist of context 0]([worklist of context 1])[scratch 144]([parked context state 2 x 16]: nctx == 2 only)
   uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
   uint32_t* scratch = wbase + (size_t)nctx * a.wl_words;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
           while (v < round - 1u) {                           // SRCH_GO_STOP is the largest value: it also ends the wait
             __builtin_amdgcn_s_sleep(4);
             v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > BANG_KERNEL_GO_TIMEOUT_TICKS) {   // the host is gone (it gives up first)
+            if (__builtin_amdgcn_s_memrealtime() - t0 > go_timeout) {                     // the host is gone (it gives up first)
               v = SRCH_GO_STOP;
               if (p.d_abort) *p.d_abort = 1u;
               break;

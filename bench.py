@@ -92,7 +92,7 @@ def shared_dir(ctx):
     return os.path.join("/tmp", tag)
 
 
-def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False):
+def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False, host_codes=False):
     """Returns a dict: ix, queries, gt_i, gt_d, d_codes, name, graph (natural placement), prefix (index files, N > 1), release().
 
     N > 1 (one process per GPU): ONE host graph for the node (the reference keeps one pIndex in host RAM,
@@ -111,7 +111,7 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False):
     if name.endswith("_shape"):
         from tools import shape_workload
         shared = None
-        stream = bool(stream and shape_workload.SHAPES[name]["graph"] == "host")
+        stream = bool(stream and shape_workload.SHAPES[name]["graph"] == "host" and not host_codes)
         if world > 1:
             n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows, stream) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
             dist.broadcast(n_plan, 0)
@@ -120,7 +120,7 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False):
                 shared = (os.path.join(sdir, f"{name}.graph"), rank == 0, dist.barrier)
         ix, queries, gt_i, gt_d, d_codes, wl_name, shape_graph = shape_workload.make(
             name, ctx.dev, n_override=shape_n, Q=Q or 10_000, log=log, shared=shared, reserve_rows=reserve_rows, stream=stream,
-            planned=(world > 1))
+            planned=(world > 1), host_codes=host_codes)
 
         def rel():
             shape_workload.release(ix)
@@ -464,7 +464,7 @@ def batch_recall(O, gt_i, gt_d, ids, k, q0, q1, ctx):
 
 
 def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1, stream=True, reserve_rows=True, Q=0, shape_n=0,
-               traffic=True, batches=1, lanes=0, threads=0, keep=False):
+               traffic=True, batches=1, lanes=0, threads=0, keep=False, host_codes=False):
     """Builds workload `name`, loads an engine in the requested placement, chooses L (structured workloads: the smallest L on the
     harness grid k, k+12, ... with 10-recall@10 >= target; shape-only workloads: 152, the reference's SIFT1B setting), times
     `steps` steps and checks the results (structured: first 64 queries of this rank against the oracle; shape-only: the
@@ -472,7 +472,7 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     import torch
     from bang_amd import shard
     k = ctx.k
-    wl = build_workload(name, ctx, Q=Q, shape_n=shape_n, reserve_rows=reserve_rows, stream=stream)
+    wl = build_workload(name, ctx, Q=Q, shape_n=shape_n, reserve_rows=reserve_rows, stream=stream, host_codes=host_codes)
     ix, queries, gt_i, gt_d = wl["ix"], wl["queries"], wl["gt_i"], wl["gt_d"]
     graph = graph or ("auto" if gt_i is not None else wl["graph"])
     Qt = queries.shape[0]
@@ -483,8 +483,10 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     my_q = np.ascontiguousarray(queries[q0:q1])
     Qr = q1 - q0
     eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=pull)
-    # N > 1 over RCCL: the shard's ids never leave device memory before the collective (host buffers only in gloo dry runs)
-    ctx.dgather = shard.DeviceGather(Qt, k, ctx.rank, ctx.world, ctx.dev) if (ctx.world > 1 and not weak and ctx.cdev == ctx.dev) else None
+    # N > 1: the shard's ids stay in device memory (bang_query_dev_e) until the collective (BANG_BENCH_HOST_GATHER=1: the r02 host bounce)
+    ctx.dgather = None
+    if ctx.world > 1 and not weak and not os.environ.get("BANG_BENCH_HOST_GATHER"):
+        ctx.dgather = shard.DeviceGather(Qt, k, ctx.rank, ctx.world, ctx.dev, coll_device=ctx.cdev)
     recall = float("nan")
     if L == 0 and gt_i is not None:
         for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
@@ -519,8 +521,16 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
         ok = bool(np.array_equal(res["ids"][:chk], ids_o))
     else:
         ok = check_properties(ix, my_q, res["ids"], res["dists"], k)
+    gathered_ok = None
+    if ctx.world > 1 and not weak and ctx.rank == 0 and getattr(ctx, "batch_ids", None) is not None:
+        # what the collective delivered, against the oracle over the WHOLE batch (where the oracle can run: host-side PQ codes)
+        if orc is None and getattr(ix, "codes", None) is not None and ix.codes.shape[0] == ix.N:
+            orc = O.Oracle(ix)
+        if orc is not None and Qt <= 20_000:
+            ids_all, _ = orc.search(queries, k, L, nthreads=usable_cpus())
+            gathered_ok = bool(np.array_equal(ctx.batch_ids, ids_all))
     out = dict(wl=wl, eng=eng, res=res, L=L, recall=recall, ok=ok, graph=graph, orc=orc, my_q=my_q, q0=q0, q1=q1, Qr=Qr,
-               placement_note=placement_note, structured=gt_i is not None, name=name)
+               placement_note=placement_note, structured=gt_i is not None, name=name, gathered_ok=gathered_ok)
     if not keep:
         release_config(out)
     return out
@@ -630,6 +640,9 @@ def main():
     ap.add_argument("--resident-graph", action="store_true",
                     help="sift1b_shape: build the whole 388-byte-per-node graph image in host memory (N then fits graph + pull rows) "
                          "instead of streaming the generator through the engine (default: streamed, N fits the pull rows)")
+    ap.add_argument("--host-codes", action="store_true",
+                    help="shape-only workloads: generate the PQ codes in HOST memory too (resident graph image, N must fit) so that the "
+                         "oracle can check the results -- parity runs of the sharded job at reduced N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
     ap.add_argument("--legs", default="", help="comma list of legs to run (default: all): k2,sift1m,deep100m,walker,sift10m")
@@ -679,7 +692,7 @@ def main():
     weak = world > 1 and args.batches > 1
     prim = run_config(args.workload, ctx, args, O, graph=args.graph, pull=args.pull, L=args.L, steps=args.steps, warmup=args.warmup,
                       stream=(args.pull != 0 and not args.resident_graph), reserve_rows=(args.pull != 0), Q=args.queries,
-                      shape_n=args.shape_n, batches=args.batches, lanes=lanes, threads=threads, keep=True)
+                      shape_n=args.shape_n, batches=args.batches, lanes=lanes, threads=threads, keep=True, host_codes=args.host_codes)
     res, agg, L, graph = prim["res"], prim["res"]["agg"], prim["L"], prim["graph"]
     ix = prim["wl"]["ix"]
     ids_primary = res["ids"]
@@ -706,6 +719,7 @@ def main():
                "dist_evals_per_step": agg["dist_evals"] // args.steps,
                "filter_probes_per_step": 2 * agg["fetched"] // args.steps,
                "filter_loads_skipped_per_step": agg["filter_loads_skipped"] // args.steps,
+               "gathered_ids_equal_oracle_whole_batch": prim["gathered_ok"],
                "search_ms_per_step_max_over_ranks": res.get("search_ms"), "gather_ms_per_step_max_over_ranks": res.get("gather_ms"),
                "step_ms_min": min(res["step_ms"]), "step_ms_max": max(res["step_ms"]), "step_ms": res["step_ms"]}
         out = {"metric": "queries/sec @ recall@10>=0.9, 10K-query batch", "value": res["queries_per_s"], "unit": "queries/s",
@@ -829,7 +843,7 @@ def main():
                 cfg["walker_bar_GBps"] = rf["pcie_h2d"]["achieved_GBps"]
                 cfg["at_sift1b_shape_walker"]["pcie_h2d"] = rf["pcie_h2d"]
             a = r["res"]["agg"]
-            cfg["walker_threads"] = a["walker_threads"]
+            cfg["walker_leg_threads"] = a["walker_threads"]
             cfg["walker_step_ms_min"], cfg["walker_step_ms_max"] = min(r["res"]["step_ms"]), max(r["res"]["step_ms"])
             release_config(r)
         guarded("at_sift1b_shape_walker", leg_walker)

@@ -73,6 +73,9 @@ int bang_destroy(bang_engine_t* e);                          /* ~BANGSearch()   
  *               2-socket measurement box)
  *   "search"  : graph in HBM: 1 = the query-resident search kernel (bang_k_search), 0 = the round-1 loops, -1 = auto */
 int bang_set_option(bang_engine_t* e, const char* key, long value);
+/* The whole table of options and environment switches as text (csrc/bang_options.cpp is the one place they are defined): writes at
+ * most cap bytes (NUL-terminated) to buf, returns the size needed.  buf may be NULL. */
+int bang_describe_options(char* buf, size_t cap);
 
 /* bang_load, bang.h:51 / bang_search.cu:138-362 */
 int bang_load_e(bang_engine_t* e, const char* indexfile_path_prefix);
@@ -322,6 +325,8 @@ typedef struct {
                                           advance independently; pacing group index = (g * groups_per_workgroup + group) * nctx + c */
   unsigned long long* d_prof;          /* diagnostic, host-paced form: [G][8] 100 MHz ticks thread 0 of each workgroup spent {waiting for
                                           rows, in the front half up to the publish barrier, publishing, in sort/merge}, [4] = half-rounds; or NULL */
+  unsigned long long go_timeout_ticks; /* host-paced form: a pacing group that has waited this many 100 MHz ticks for its rows sets *d_abort and
+                                          leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the
                                           word was still zero (self-paced form; 0 in the host-paced form) */
 } bang_search_params;

@@ -166,3 +166,43 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for f, _ in cls._fields_:
             assert got[(cname, f)] == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_every_option_lives_in_one_table(libbang):
+    """bang_describe_options prints the table csrc/bang_options.cpp defines; every key it lists is accepted by bang_set_option at
+    both ends of its range and refused outside it, unknown keys are refused (no device needed: options are plain engine state)."""
+    lib = libbang
+    lib.bang_describe_options.argtypes = [C.c_char_p, C.c_size_t]
+    need = lib.bang_describe_options(None, 0)
+    buf = C.create_string_buffer(need)
+    assert lib.bang_describe_options(buf, need) == need
+    text = buf.value.decode()
+    rows = re.findall(r"^  (\w+)\s+(BANG_\w+|-)\s+\[(-?\d+), (-?\d+)\]\s+(any time|bang_load|bang_alloc)", text, flags=re.M)
+    keys = [r[0] for r in rows]
+    for must in ("graph", "pull", "vectors", "lanes", "threads", "persistent", "search", "numa", "timing", "stage_zero_copy", "use_flag",
+                 "compact", "fp_batch", "front_wgs", "check_every", "pq", "pq_ragged", "device", "host_walk_timeout_ms",
+                 "kernel_go_timeout_ms"):
+        assert must in keys, must
+    for sw in ("BANG_PULL_ROWS_DIR", "BANG_STREAM_LOAD", "BANG_SEARCH_MAX_WAVES", "BANG_TIMELINE", "BANG_AMD_LIB"):
+        assert sw in text
+    h = C.c_void_p()
+    assert lib.bang_create(0, C.byref(h)) == 0
+    lib.bang_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    for key, env, lo, hi, _ in rows:
+        lo, hi = int(lo), int(hi)
+        assert lib.bang_set_option(h, key.encode(), lo) == 0, key
+        assert lib.bang_set_option(h, key.encode(), hi) == 0, key
+        if key not in ("pq_ragged", "use_flag", "compact"):      # flags take any value (non-zero = on)
+            assert lib.bang_set_option(h, key.encode(), hi + 1) != 0, key
+            assert lib.bang_set_option(h, key.encode(), lo - 1) != 0, key
+    assert lib.bang_set_option(h, b"no_such_option", 1) != 0
+    lib.bang_destroy.argtypes = [C.c_void_p]
+    lib.bang_destroy(h)
+    # every environment variable the engine sources read is in that table
+    import glob
+    known = set(re.findall(r"BANG_[A-Z_0-9]+", text))
+    for src in glob.glob(os.path.join(ROOT, "bang-billion-scale-ann_amd", "csrc", "bang_*.cpp")):
+        for name in re.findall(r'env_(?:long|flag|str)\("(BANG_[A-Z_0-9]+)"', open(src).read()):
+            assert name in known, (src, name)
+        if not src.endswith("bang_options.cpp"):
+            assert "getenv(" not in open(src).read(), src

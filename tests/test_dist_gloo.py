@@ -33,6 +33,14 @@ def _worker(rank, world, port, Q, out_dir):
     ids, _ = O.Oracle(ix).search(q[a:b], 10, 24, nthreads=1)
     full = shard.gather_ids(ids, Q, 10, rank, world)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), full)
+    # the same collective through the pre-allocated buffers of the device-side gather (CPU tensors stand in for device memory here;
+    # on the GPU the engine writes `mine` itself: bang_query_dev_e)
+    import torch
+    dg = shard.DeviceGather(Q, 10, rank, world, torch.device("cpu"))
+    dg.mine[: b - a] = torch.from_numpy(np.ascontiguousarray(ids).view(np.int64))
+    dg.gather()
+    assert np.array_equal(dg.local_ids(), ids)
+    np.save(os.path.join(out_dir, f"dg{rank}.npy"), dg.batch_ids())
     if rank == 0:
         ref, _ = O.Oracle(ix).search(q, 10, 24, nthreads=2)
         np.save(os.path.join(out_dir, "ref.npy"), ref)
@@ -46,6 +54,7 @@ def test_two_rank_sharding_reproduces_the_single_process_result(tmp_path):
     ref = np.load(tmp_path / "ref.npy")
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), ref)
+        assert np.array_equal(np.load(tmp_path / f"dg{r}.npy"), ref)
 
 
 def test_shard_ranges_cover_the_batch():

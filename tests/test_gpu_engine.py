@@ -416,6 +416,20 @@ def test_pull_rows_file_is_shared_and_validated(libbang, small_u8, small_i8, tmp
     ids3, _ = run(ix, q)
     assert np.array_equal(ids3, ids_o) and path.stat().st_ino != ino
     assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    # the signature covers EVERY adjacency list: an index edited in place (same N, R, medoid) gets its own rows
+    import copy
+    ix2 = copy.copy(ix)
+    ix2.graph = np.array(ix.graph, copy=True)
+    vb = ix.D * (4 if ix.dtype == "float" else 1)
+    node = 2049
+    adj2 = ix2.graph[node, vb + 4: vb + 4 + 4 * ix.R].view(np.uint32)
+    deg2 = int(ix2.graph[node, vb: vb + 4].view(np.uint32)[0])
+    repl = next(c for c in range(ix.N) if c != node and c not in set(adj2[:deg2].tolist()))
+    adj2[0] = repl
+    adj2[:deg2] = np.sort(adj2[:deg2])
+    ino4 = path.stat().st_ino
+    ids4, _ = run(ix2, q)
+    assert np.array_equal(ids4, O.Oracle(ix2).search(q, 10, 40)[0]) and path.stat().st_ino != ino4
 
 
 # -------------------------------------------------------------------------------------------------------------- streamed load
@@ -529,8 +543,24 @@ def test_streamed_load_shares_and_checks_the_rows_file(libbang, small_u8, small_
     blob = bytearray(path.read_bytes())
     blob[ix.N * 256 + 2048 + 33] ^= 0xFF
     path.write_bytes(bytes(blob))
-    with pytest.raises(bang_amd.BangError, match="another index"):            # a streamed load cannot rebuild behind itself: loud
-        run(ix)
+    ino2 = path.stat().st_ino
+    assert np.array_equal(run(ix), ids_o) and path.stat().st_ino != ino2      # stale file: removed, the entries stream through once more
+    # an index EDITED IN PLACE (same N, R, medoid; one adjacency list differs, far from any sampled node) must not inherit the rows
+    import copy
+    ix2 = copy.copy(ix)
+    ix2.graph = np.array(ix.graph, copy=True)
+    vb = ix.D * (4 if ix.dtype == "float" else 1)
+    node = 1237
+    adj = ix2.graph[node, vb + 4: vb + 4 + 4 * ix.R].view(np.uint32)
+    deg = int(ix2.graph[node, vb: vb + 4].view(np.uint32)[0])
+    repl = next(c for c in range(ix.N) if c != node and c not in set(adj[:deg].tolist()))
+    adj[0] = repl
+    adj[:deg] = np.sort(adj[:deg])
+    ids_o2, _ = O.Oracle(ix2).search(q, 10, 40)
+    ino3 = path.stat().st_ino
+    assert np.array_equal(run(ix2), ids_o2) and path.stat().st_ino != ino3
+    rows = np.fromfile(path, np.uint32, ix.N * 64).reshape(ix.N, 64)
+    assert repl in rows[node, :deg].tolist()
 
 
 @pytest.mark.gpu
@@ -564,3 +594,70 @@ def test_bang_load_reads_a_diskann_index_directly(request, libbang, fixture, tmp
     with bang_amd.Engine(wrong, graph=0) as e:                      # the record length does not fit the element size: refused
         with pytest.raises(bang_amd.BangError):
             e.load(prefix)
+
+
+def test_query_dev_leaves_identical_results_in_device_buffers(libbang, small_u8):
+    """bang_query_dev_e: ids [Q][k] / dists [k][Q] written to the caller's DEVICE buffers equal what bang_query_e returns to the host
+    (both placements; the N > 1 job all-gathers straight from such a buffer)."""
+    import bang_amd
+    from bang_amd import binding as B
+    ix, q, _, _ = small_u8
+    Q, k, L = q.shape[0], 10, 48
+    for graph in (bang_amd.GRAPH_HOST, bang_amd.GRAPH_DEVICE):
+        with bang_amd.Engine("uint8", graph=graph) as e:
+            e.load_index(ix)
+            e.set_searchparams(k, L)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            d_ids, d_dists = B.DeviceBuffer(Q * k * 8), B.DeviceBuffer(Q * k * 4)
+            for with_dists in (True, False):
+                e.init(Q)
+                e.query_dev(q, d_ids.ptr, d_dists.ptr if with_dists else 0)
+                assert np.array_equal(d_ids.download(np.uint64, (Q, k)), ids)
+                if with_dists:
+                    assert np.array_equal(d_dists.download(np.float32, (k, Q)).view(np.uint32), dists.view(np.uint32))
+            # a shorter batch on the same allocation
+            e.init(Q // 2)
+            e.query_dev(q[: Q // 2], d_ids.ptr, d_dists.ptr)
+            assert np.array_equal(d_ids.download(np.uint64, (Q, k))[: Q // 2], ids[: Q // 2])
+            d_ids.free(); d_dists.free()
+            e.free()
+            e.unload()
+
+
+def test_host_paced_hand_shake_failure_is_reported_and_survivable(libbang, small_u8):
+    """The abort path of the host-paced search kernel (the reference's loop, bang_search.cu:771-838, would block forever).  The
+    walker team is stalled by the test hook for longer than kernel_go_timeout_ms: every pacing group gives up on its own, sets the
+    abort word and leaves; the walker, back from its stall, finds nobody to serve and gives up after host_walk_timeout_ms;
+    bang_query reports BANG_ERR_HIP naming the side that gave up first, the process lives, and the NEXT bang_init + bang_query on
+    the same allocation returns the oracle's answer.  Both timeouts are run-time options (range-checked)."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 40)
+    with bang_amd.Engine(ix.dtype, graph=0, search=1, pull=0, threads=3) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 40)
+        e.alloc(q.shape[0])
+        e.init(q.shape[0])
+        ids, dists = e.query(q)
+        assert e.stats()["search_kernel"] == 1 and e.stats()["graph_pull"] == 0
+        assert np.array_equal(ids, ids_o)
+        e.set_option("kernel_go_timeout_ms", 150)
+        e.set_option("host_walk_timeout_ms", 400)
+        e.set_option("walker_stall_ms", 900)
+        e.init(q.shape[0])
+        with pytest.raises(bang_amd.BangError, match="gave up waiting for the host walker"):
+            e.query(q)
+        # the allocation is still good: state is rebuilt by bang_init, the hand-shake words by the next query
+        e.set_option("kernel_go_timeout_ms", 30000)
+        e.set_option("host_walk_timeout_ms", 20000)
+        for _ in range(2):
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        with pytest.raises(bang_amd.BangError):
+            e.set_option("kernel_go_timeout_ms", 1)              # out of range
+        e.free()
+        e.unload()

@@ -1,7 +1,8 @@
 """The N > 1 path of bench.py on a 1-GPU box: two ranks (one process each, launched exactly as the driver launches them) share
 GPU 0 (BANG_BENCH_SHARE_GPU) and ONE host graph -- rank 0 writes the index files into tmpfs, both ranks load them through
-bang_load, which maps `_disk.bin` shared.  Each rank searches its shard with the real engine; the result ids are gathered with
-the job's single collective (gloo here: RCCL refuses two ranks on one device).  Every rank checks its shard against the oracle."""
+bang_load, which maps `_disk.bin` shared.  Each rank searches its shard with the real engine; the result ids stay in device
+buffers (bang_query_dev_e) and are gathered with the job's single collective (gloo here, staged through the host: RCCL refuses two
+ranks on one device).  Every rank checks its shard against the oracle and rank 0 checks the gathered block of the whole batch."""
 import json
 import os
 import socket
@@ -54,9 +55,13 @@ def test_two_ranks_one_gpu_one_host_graph(libbang, graph):
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["config"]["parity_vs_oracle_first_64"] is True and two["config"]["parity_vs_oracle_first_64"] is True
     assert two["config"]["graph"] == graph and two["config"]["L"] == 46
-    # the sharded job answers the same 1000 queries: the worst shard's recall cannot beat the whole batch's by much, nor fall far
-    assert abs(two["config"]["recall_at_10"] - one["config"]["recall_at_10"]) < 3.0
+    # what the collective delivered on rank 0 -- the [Q][k] block of the WHOLE batch, gathered from the device buffers the engine
+    # left the shards' ids in (bang_query_dev_e) -- equals the oracle's answer for every query
+    assert two["config"]["gathered_ids_equal_oracle_whole_batch"] is True
+    # the sharded job answers the same 1000 queries: the batch recall (shard recalls weighted by shard size) is the single-process one
+    assert abs(two["config"]["recall_at_10"] - one["config"]["recall_at_10"]) < 2e-3
     assert two["value"] > 0 and two["ms_per_step"] > 0
+    assert two["config"]["search_ms_per_step_max_over_ranks"] > 0 and two["config"]["gather_ms_per_step_max_over_ranks"] > 0
 
 
 def test_two_ranks_throughput_mode(libbang):
@@ -78,3 +83,15 @@ def test_two_ranks_streamed_sift1b_shape_share_one_rows_file(libbang):
         assert c["result_properties_ok"] is True and c["graph"] == "host" and "pulled" in c["host_loop"], c
         assert "STREAMED" in c["workload"] and "N=12000000" in c["workload"]
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+
+
+def test_two_ranks_sift1b_shape_gathered_batch_equals_oracle(libbang):
+    """configs[4] with the oracle in the loop: the SIFT1B-shape layout (uint8, m = 70, rows pulled from ONE shared rows file) at an
+    N whose PQ codes also fit host memory, sharded over two ranks; the gathered [Q][k] block must equal the oracle's ids for EVERY
+    query of the batch, and so must each rank's shard (first 64)."""
+    args = ["--shape-n", "3000000", "--queries", "512", "--host-codes"]
+    one = _bench(1, args, workload="sift1b_shape", L=40)
+    two = _bench(2, args, workload="sift1b_shape", L=40)
+    assert one["config"]["result_properties_ok"] is True and two["config"]["result_properties_ok"] is True
+    assert two["config"]["gathered_ids_equal_oracle_whole_batch"] is True, two["config"]
+    assert two["n_gpus"] == 2 and "pulled" in two["config"]["host_loop"]
