@@ -1,15 +1,20 @@
 """Index construction at 10-100 M points on one MI355X (the reference delegates it to DiskANN's
-``build_disk_index``: root README.md:46-58, BANG_Base/ReadMe.pdf p.1-2).
+``build_disk_index -R 64 -L 200``: root README.md:46-58, BANG_Base/ReadMe.pdf p.1-2).
 
 `synth.build_graph` finds exact nearest neighbours by brute force, which stops being practical beyond a few million points
-(the selection over N^2 distances, not the matmul).  This module builds a Vamana-STYLE graph instead:
+(the selection over N^2 distances, not the matmul).  This module builds a Vamana-STYLE graph in batched passes instead:
 
-1. candidate neighbours by a partitioned search on the GPU: coarse k-means (C ~ sqrt(N) cells), every point is compared with
-   the points of its own and the `probes` nearest cells (one [cell x candidates] matmul + top-k per cell);
+1. candidate neighbours by a partitioned search on the GPU: a two-level k-means partition (cells of ~2 K points), every point
+   is compared with the points of its own and the `probes` nearest cells (one [cell x candidates] matmul + top-k per cell;
+   uint8 / int8 data is held as bfloat16, in which its values, their products and the f32-accumulated dot products are exact);
 2. DiskANN's robust prune (the alpha rule of Vamana) over each point's candidate list, fully batched: a candidate c is dropped
-   once a kept neighbour p* satisfies alpha * d(p*, c) <= d(p, c); at most R/2 survive;
-3. the remaining slots are filled with uniformly random long-range links (what keeps greedy search short on a graph that was
-   not grown incrementally), adjacency sorted ascending as bang_preprocess.py:102-104 leaves it.
+   once a kept neighbour p* satisfies alpha * d(p*, c) <= d(p, c);
+3. REVERSE edges (Vamana inserts p into the list of every neighbour it selects): every kept edge p -> c offers p to c; a point's
+   kept and offered neighbours together go through a SECOND robust prune.  This is what makes the graph navigable from any
+   direction -- a one-pass pruned kNN graph leaves many points with few or no inbound near edges;
+4. the remaining slots (at least `n_random`) are filled with uniformly random long-range links (the shortcut edges Vamana gets
+   from inserting points along greedy-search paths from the medoid), adjacency sorted ascending as bang_preprocess.py:102-104
+   leaves it.
 
 The PQ side (DiskANN's layout: global centroid, D split into m chunks, 256 pivots per chunk) is `synth.train_pq`.
 
@@ -27,7 +32,7 @@ from .formats import Index, pack_graph
 
 def _kmeans(x: torch.Tensor, C: int, iters: int, g: torch.Generator, sample: int = 262144):
     N = x.shape[0]
-    s = x[torch.randperm(N, generator=g, device=x.device)[: min(N, sample)]]
+    s = x[torch.randperm(N, generator=g, device=x.device)[: min(N, sample)]].float()
     cen = s[torch.randperm(s.shape[0], generator=g, device=x.device)[:C]].clone()
     for _ in range(iters):
         lab = _assign(s, cen)
@@ -40,32 +45,74 @@ def _kmeans(x: torch.Tensor, C: int, iters: int, g: torch.Generator, sample: int
 
 def _assign(x: torch.Tensor, cen: torch.Tensor, block: int = 1 << 18) -> torch.Tensor:
     cn = (cen * cen).sum(1)
+    cw = cen.to(x.dtype)
     out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
     for a in range(0, x.shape[0], block):
         b = x[a:a + block]
-        out[a:a + block] = (cn[None, :] - 2.0 * (b @ cen.T)).argmin(dim=1)
+        out[a:a + block] = (cn[None, :] - 2.0 * (b @ cw.T).float()).argmin(dim=1)
     return out
 
 
-def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = synth.SEED, cells: int = 0, log=None):
+def partition(x: torch.Tensor, cell: int, g: torch.Generator):
+    """Two-level k-means partition into cells of ~`cell` points.  Returns (labels int64 [N], centroids f32 [C, D]).
+    One level of C ~ N / cell centroids would cost an [N x C] distance matrix (N = 1e8: 5e12 entries); two levels cost
+    N x (C1 + C2) with C1 ~ C2 ~ sqrt(C)."""
+    N = x.shape[0]
+    C = max(1, int(round(N / cell)))
+    if C <= 1024:
+        cen = _kmeans(x, max(1, min(C, N)), 6, g)
+        return _assign(x, cen), cen
+    C1 = int(max(16, min(1024, round(C ** 0.5))))
+    cen1 = _kmeans(x, C1, 6, g)
+    lab1 = _assign(x, cen1)
+    order = torch.argsort(lab1, stable=True)
+    counts = torch.bincount(lab1, minlength=C1).tolist()
+    labels = torch.empty(N, dtype=torch.int64, device=x.device)
+    cens, base, a = [], 0, 0
+    for c in range(C1):
+        n = counts[c]
+        if n == 0:
+            continue
+        rows = order[a:a + n]
+        a += n
+        k = max(1, min(int(round(n / cell)), n))
+        xs = x[rows]
+        cen = _kmeans(xs, k, 4, g, sample=65536)
+        labels[rows] = _assign(xs, cen) + base
+        cens.append(cen)
+        base += k
+    return labels, torch.cat(cens)
+
+
+def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = synth.SEED, cells: int = 0, log=None, cell: int = 2048,
+                         idx_dtype=torch.int64):
     """Approximate K nearest neighbours of every point (excluding itself) through a coarse partition.
-    Returns (ids int64 [N, K], squared distances f32 [N, K]) sorted ascending."""
+    Returns (ids [N, K] of idx_dtype, squared distances f32 [N, K]) sorted ascending.  x may be f32 or (exact for 8-bit data) bf16."""
     N, D = x.shape
     dev = x.device
     g = synth._gen(seed + 11, dev)
-    C = cells or int(max(16, min(8192, round((N ** 0.5) / 1.5))))
-    cen = _kmeans(x, C, 6, g)
-    lab = _assign(x, cen)
+    t0 = time.time()
+    if cells:
+        cen = _kmeans(x, cells, 6, g)
+        lab = _assign(x, cen)
+    else:
+        lab, cen = partition(x, cell, g)
+    C = cen.shape[0]
     order = torch.argsort(lab, stable=True)
     counts = torch.bincount(lab, minlength=C)
+    del lab
     starts = torch.cumsum(counts, 0) - counts
-    cd = torch.cdist(cen, cen)
-    near = torch.topk(cd, min(probes, C), dim=1, largest=False).indices           # [C, probes], self first
-    xn = (x * x).sum(1)
-    out_i = torch.empty((N, K), dtype=torch.int64, device=dev)
+    near = torch.empty((C, min(probes, C)), dtype=torch.int64, device=dev)
+    for a in range(0, C, 4096):                                                   # [C, probes], self first
+        near[a:a + 4096] = torch.topk(torch.cdist(cen[a:a + 4096], cen), min(probes, C), dim=1, largest=False).indices
+    if log:
+        log(f"[build] partition: {C} cells of ~{N // max(1, C)} points in {time.time() - t0:.1f}s")
+    xn = (x.float() * x.float()).sum(1) if x.dtype == torch.float32 else torch.cat([(x[a:a + (1 << 22)].float() ** 2).sum(1) for a in range(0, N, 1 << 22)])
+    out_i = torch.empty((N, K), dtype=idx_dtype, device=dev)
     out_d = torch.empty((N, K), dtype=torch.float32, device=dev)
     starts_h, counts_h, near_h = starts.tolist(), counts.tolist(), near.tolist()
     t0 = time.time()
+    step = max(512, C // 8)
     for c in range(C):
         if counts_h[c] == 0:
             continue
@@ -74,32 +121,35 @@ def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = s
         if cand.shape[0] <= K:                                   # tiny neighbourhood: widen to a random sample
             extra = torch.randint(0, N, (4 * K,), generator=g, device=dev)
             cand = torch.unique(torch.cat([cand, extra]))
-        xr = x[rows]
+        xc = x[cand]
+        xnc = xn[cand]
         for a in range(0, rows.shape[0], 8192):                  # bound the distance tile
             r = rows[a:a + 8192]
-            d = xn[r][:, None] + xn[cand][None, :] - 2.0 * (xr[a:a + 8192] @ x[cand].T)
+            d = xn[r][:, None] + xnc[None, :] - 2.0 * (x[r] @ xc.T).float()
             d.masked_fill_(r[:, None] == cand[None, :], float("inf"))
             dd, ii = torch.topk(d, K, dim=1, largest=False)
-            out_i[r] = cand[ii]
+            out_i[r] = cand[ii].to(idx_dtype)
             out_d[r] = dd.clamp_min_(0.0)
-        if log and (c + 1) % 512 == 0:
+        if log and (c + 1) % step == 0:
             log(f"[build] candidate search: cell {c + 1}/{C} ({time.time() - t0:.1f}s)")
     return out_i, out_d
 
 
 def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, keep: int, alpha: float = 1.2, block: int = 32768):
-    """DiskANN / Vamana robust prune, batched.  cand_* [N, K] sorted ascending by distance to the point.  Walks the list in order;
-    a candidate that is still alive is KEPT and kills every later candidate c with alpha * d(kept, c) <= d(point, c) (distances, not
-    squares: the comparison is done as alpha^2 * d2 <= d2').  Returns (mask bool [N, K] of kept candidates, at most `keep` per row)."""
+    """DiskANN / Vamana robust prune, batched.  cand_* [N, K] sorted ascending by distance to the point (padding: distance +inf).
+    Walks the list in order; a candidate that is still alive is KEPT and kills every later candidate c with
+    alpha * d(kept, c) <= d(point, c) (distances, not squares: the comparison is done as alpha^2 * d2 <= d2').
+    Returns (mask bool [N, K] of kept candidates, at most `keep` per row)."""
     N, K = cand_i.shape
     out = torch.zeros((N, K), dtype=torch.bool, device=x.device)
     a2 = alpha * alpha
     for s in range(0, N, block):
-        ci = cand_i[s:s + block]
+        ci = cand_i[s:s + block].long()
         dp = cand_d[s:s + block]                                  # d2(point, c)
-        v = x[ci]                                                 # [B, K, D]
-        n2 = (v * v).sum(2)
-        dcc = (n2[:, :, None] + n2[:, None, :] - 2.0 * torch.bmm(v, v.transpose(1, 2))).clamp_min_(0.0)   # [B, K, K] d2(c_i, c_j)
+        v = x[ci.clamp_min(0)]                                    # [B, K, D]
+        n2 = (v.float() * v.float()).sum(2)
+        dcc = (n2[:, :, None] + n2[:, None, :] - 2.0 * torch.bmm(v, v.transpose(1, 2)).float()).clamp_min_(0.0)   # [B, K, K] d2(c_i, c_j)
+        del v
         alive = torch.isfinite(dp)
         kept = torch.zeros_like(alive)
         n_kept = torch.zeros(ci.shape[0], dtype=torch.int64, device=x.device)
@@ -113,68 +163,169 @@ def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, ke
     return out
 
 
-def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None):
-    """(degrees int64 [N], adjacency int64 [N, R]): <= R/2 robust-pruned near neighbours + random long-range links up to R,
-    distinct, != self, sorted ascending; the tail of a short row is 0."""
+def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tensor, slots: int = 24, block: int = 1 << 20):
+    """Every kept edge p -> c offers p to c (Vamana's reverse insertion).  near_i [N, K1] (-1 = empty), near_d [N, K1].
+    A point keeps at most `slots` offers: an offer lands in slot hash(p, c) % slots and the largest p wins a contested slot
+    (scatter-max: deterministic, no global sort of the ~N x 30 edges).  Returns the merged candidate lists -- own kept + offered,
+    distinct, sorted ascending by distance, padding id -1 / distance +inf: (ids [N, K1 + slots] of near_i.dtype, d2 f32)."""
+    N, K1 = near_i.shape
+    dev = x.device
+    rev = torch.full((N * slots,), -1, dtype=torch.int64, device=dev)
+    for s in range(0, N, block):
+        c = near_i[s:s + block].long()
+        p = torch.arange(s, s + c.shape[0], device=dev)[:, None].expand_as(c)
+        ok = c >= 0
+        cc, pp = c[ok], p[ok]
+        slot = ((pp * 0x9E3779B1 + cc * 0x85EBCA77) >> 7) % slots
+        rev.scatter_reduce_(0, cc * slots + slot, pp, reduce="amax", include_self=True)
+    rev = rev.view(N, slots)
+    out_i = torch.empty((N, K1 + slots), dtype=near_i.dtype, device=dev)
+    out_d = torch.empty((N, K1 + slots), dtype=torch.float32, device=dev)
+    for s in range(0, N, 1 << 18):
+        r = rev[s:s + (1 << 18)]
+        B = r.shape[0]
+        xr = x[r.clamp_min(0)].float()                            # [B, slots, D]
+        xp = x[s:s + B].float()
+        rd = ((xr - xp[:, None, :]) ** 2).sum(2)
+        rd = torch.where(r >= 0, rd, torch.full_like(rd, float("inf")))
+        ids = torch.cat([near_i[s:s + B].long(), r], 1)
+        dd = torch.cat([torch.where(near_i[s:s + B] >= 0, near_d[s:s + B], torch.full_like(near_d[s:s + B], float("inf"))), rd], 1)
+        # distinct: sort by id, drop repeats (an offered point may already be a kept neighbour), then sort by distance
+        ids_s, o = torch.sort(ids, dim=1)
+        dd_s = torch.gather(dd, 1, o)
+        dup = torch.zeros_like(ids_s, dtype=torch.bool)
+        dup[:, 1:] = ids_s[:, 1:] == ids_s[:, :-1]
+        dd_s = torch.where(dup | (ids_s < 0), torch.full_like(dd_s, float("inf")), dd_s)
+        dd_o, o2 = torch.sort(dd_s, dim=1, stable=True)
+        ids_o = torch.gather(ids_s, 1, o2)
+        ids_o = torch.where(torch.isfinite(dd_o), ids_o, torch.full_like(ids_o, -1))
+        out_i[s:s + B] = ids_o.to(near_i.dtype)
+        out_d[s:s + B] = dd_o
+    return out_i, out_d
+
+
+def _compact_kept(ci: torch.Tensor, cd: torch.Tensor, kept: torch.Tensor, width: int):
+    """The kept candidates of every row moved to the front (order preserved): (ids [N, width] with -1 padding, d2 with +inf)."""
+    N, K = ci.shape
+    out_i = torch.full((N, width), -1, dtype=ci.dtype, device=ci.device)
+    out_d = torch.full((N, width), float("inf"), dtype=torch.float32, device=ci.device)
+    for s in range(0, N, 1 << 20):
+        k = kept[s:s + (1 << 20)]
+        pos = torch.cumsum(k.to(torch.int64), 1) - 1
+        ok = k & (pos < width)
+        rows = torch.arange(k.shape[0], device=ci.device)[:, None].expand_as(k)
+        oi, od = out_i[s:s + (1 << 20)], out_d[s:s + (1 << 20)]
+        oi[rows[ok], pos[ok]] = ci[s:s + (1 << 20)][ok]
+        od[rows[ok], pos[ok]] = cd[s:s + (1 << 20)][ok]
+    return out_i, out_d
+
+
+def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None,
+                      reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64):
+    """(degrees int64 [N], adjacency [N, R] of idx_dtype): robust-pruned near neighbours (two passes with reverse edges in
+    between; at most R - n_random of them) + random long-range links up to R, distinct, != self, sorted ascending; the tail of a
+    short row is 0.  reverse=False, n_random=R//2: the one-pass builder of round 2."""
     N = x.shape[0]
     dev = x.device
     t0 = time.time()
-    ci, cd = candidate_neighbours(x, K, probes=probes, seed=seed, log=log)
+    ci, cd = candidate_neighbours(x, K, probes=probes, seed=seed, log=log, cell=cell, cells=cells, idx_dtype=idx_dtype)
     if log:
         log(f"[build] {K} candidate neighbours per point in {time.time() - t0:.1f}s")
     t0 = time.time()
-    kept = robust_prune(x, ci, cd, keep=R // 2, alpha=alpha)
+    n_near = R - n_random
+    keep1 = min(n_near, R // 2)
+    kept = robust_prune(x, ci, cd, keep=keep1, alpha=alpha)
     if log:
         log(f"[build] robust prune (alpha {alpha}): {float(kept.sum(1).float().mean()):.1f} of {K} kept on average, {time.time() - t0:.1f}s")
+    near_i, near_d = _compact_kept(ci, cd, kept, keep1)
+    del ci, cd, kept
+    if reverse:
+        t0 = time.time()
+        mi, md = reverse_candidates(x, near_i, near_d, slots=max(8, R // 2 - 8))
+        del near_i, near_d
+        kept2 = robust_prune(x, mi, md, keep=n_near, alpha=alpha)
+        near_i, near_d = _compact_kept(mi, md, kept2, n_near)
+        if log:
+            log(f"[build] reverse edges + second prune: {float(kept2.sum(1).float().mean()):.1f} near neighbours per point, {time.time() - t0:.1f}s")
+        del mi, md, kept2, near_d
     g = synth._gen(seed + 1, dev)
-    near = torch.where(kept, ci, torch.full_like(ci, -1))
-    # per row: the kept neighbours first, then random links; R entries in all
-    near_sorted, _ = torch.sort(near, dim=1, descending=True)                    # valid ids first, -1 at the end
-    near_sorted = near_sorted[:, : R // 2]
-    rnd = torch.randint(0, N, (N, R), generator=g, device=dev)
-    n_near = (near_sorted >= 0).sum(1, keepdim=True)
-    col = torch.arange(R, device=dev)[None, :]
-    pad = torch.full((N, R - near_sorted.shape[1]), -1, dtype=torch.int64, device=dev)
-    adj = torch.where(col < n_near, torch.cat([near_sorted, pad], 1), rnd)
-    adj, _ = torch.sort(adj, dim=1)
-    self_id = torch.arange(N, device=dev)[:, None]
-    ok = torch.ones_like(adj, dtype=torch.bool)
-    ok[:, 1:] = adj[:, 1:] != adj[:, :-1]
-    ok &= adj != self_id
-    deg = ok.sum(dim=1)
-    pos = torch.cumsum(ok.to(torch.int64), dim=1) - 1
-    out = torch.zeros_like(adj)
-    rows = torch.arange(N, device=dev)[:, None].expand_as(adj)
-    out[rows[ok], pos[ok]] = adj[ok]
-    return deg, out
+    adj_out = torch.zeros((N, R), dtype=idx_dtype, device=dev)
+    deg_out = torch.empty(N, dtype=torch.int64, device=dev)
+    W = near_i.shape[1]
+    for s in range(0, N, 1 << 20):                               # per row: the near neighbours, then random links; R entries in all
+        near = near_i[s:s + (1 << 20)].long()
+        B = near.shape[0]
+        rnd = torch.randint(0, N, (B, R), generator=g, device=dev)
+        n_n = (near >= 0).sum(1, keepdim=True)
+        col = torch.arange(R, device=dev)[None, :]
+        pad = torch.full((B, R - W), -1, dtype=torch.int64, device=dev)
+        adj = torch.where(col < n_n, torch.cat([near, pad], 1), rnd)
+        adj, _ = torch.sort(adj, dim=1)
+        self_id = torch.arange(s, s + B, device=dev)[:, None]
+        ok = torch.ones_like(adj, dtype=torch.bool)
+        ok[:, 1:] = adj[:, 1:] != adj[:, :-1]
+        ok &= adj != self_id
+        deg_out[s:s + B] = ok.sum(dim=1)
+        pos = torch.cumsum(ok.to(torch.int64), dim=1) - 1
+        out = torch.zeros_like(adj)
+        rows = torch.arange(B, device=dev)[:, None].expand_as(adj)
+        out[rows[ok], pos[ok]] = adj[ok]
+        adj_out[s:s + B] = out.to(idx_dtype)
+    return deg_out, adj_out
+
+
+def pack_graph_device(x: torch.Tensor, dtype: str, deg: torch.Tensor, adj: torch.Tensor, block: int = 1 << 21) -> np.ndarray:
+    """formats.pack_graph for a large index: the [T vec[D]][u32 degree][u32 id x R] entries are assembled on the device block by
+    block and land in ONE host array (N x entryLen bytes: 38.8 GB for 1e8 SIFT-like points) -- no [N, R] int64 host copies."""
+    N, D = x.shape
+    R = adj.shape[1]
+    isz = 4 if dtype == "float" else 1
+    el = D * isz + 4 + 4 * R
+    out = np.empty((N, el), dtype=np.uint8)
+    for s in range(0, N, block):
+        xb = x[s:s + block]
+        B = xb.shape[0]
+        if dtype == "float":
+            vec = xb.float().contiguous().view(torch.uint8).view(B, D * 4)
+        elif dtype == "uint8":
+            vec = xb.to(torch.uint8)
+        else:
+            vec = xb.to(torch.int8).view(torch.uint8)
+        d32 = deg[s:s + B].to(torch.int32).contiguous().view(torch.uint8).view(B, 4)
+        a32 = adj[s:s + B].to(torch.int32).contiguous().view(torch.uint8).view(B, 4 * R)
+        out[s:s + B] = torch.cat([vec, d32, a32], 1).cpu().numpy()
+    return out
 
 
 def make_index_large(N: int, D: int, dtype: str, R: int, m: int, Q: int, K: int = 10, n_clusters: int = 1024,
-                     seed: int = synth.SEED, device="cuda", pq_iters: int = 6, log=None):
+                     seed: int = synth.SEED, device="cuda", pq_iters: int = 6, log=None, **graph_kw):
     """A structured index of N >= a few million points with brute-force ground truth for Q queries.
     Returns (Index, queries np [Q, D], gt_ids np u32 [Q, K], gt_dists np f32 [Q, K])."""
     t0 = time.time()
-    x = synth.make_vectors(N, D, dtype, n_clusters=n_clusters, seed=seed, device=device)
-    deg, adj = build_graph_large(x, R, seed=seed, log=log)
-    medoid = int(synth._sq_norms(x - x.mean(dim=0)).argmin())
-    deg_np = deg.cpu().numpy().astype(np.uint32)
-    adj_np = adj.cpu().numpy().astype(np.uint32)
-    del deg, adj
-    torch.cuda.empty_cache() if str(device).startswith("cuda") else None
+    big = N > 20_000_000
+    x = synth.make_vectors(N, D, dtype, n_clusters=n_clusters, seed=seed, device=device, out_dtype=(torch.bfloat16 if dtype != "float" and str(device).startswith("cuda") else None))
+    if log:
+        log(f"[build] {N} vectors generated in {time.time() - t0:.1f}s")
+    deg, adj = build_graph_large(x, R, seed=seed, log=log, idx_dtype=(torch.int32 if big else torch.int64), **graph_kw)
+    medoid = synth.medoid_of(x)
     t1 = time.time()
     pivots, centroid, off, codes = synth.train_pq(x, m, iters=pq_iters, seed=seed)
     if log:
         log(f"[build] PQ: {m} chunks trained and {N} points encoded in {time.time() - t1:.1f}s")
     q = synth.make_queries(x, Q, dtype, seed=seed)
     t1 = time.time()
-    gt_i, gt_d = synth.knn(x, q, K, row_block=2048)
+    gt_i, gt_d = synth.knn(x, q.to(x.dtype), K, row_block=2048)
     if log:
         log(f"[build] brute-force ground truth for {Q} queries in {time.time() - t1:.1f}s")
-    vec_np = synth.to_numpy(x, dtype)
-    del x
-    graph = pack_graph(vec_np, deg_np, adj_np)
+    t1 = time.time()
+    graph = pack_graph_device(x, dtype, deg, adj)
+    del x, deg, adj
+    if str(device).startswith("cuda"):
+        torch.cuda.empty_cache()
+    if log:
+        log(f"[build] graph entries assembled on the host in {time.time() - t1:.1f}s")
     ix = Index(dtype=dtype, N=N, D=D, R=R, m=m, medoid=medoid, graph=graph, codes=codes.cpu().numpy(),
                pivots=pivots.cpu().numpy().astype(np.float32), centroid=centroid.cpu().numpy().astype(np.float32), chunk_off=off)
     if log:
         log(f"[build] index of {N} points built in {time.time() - t0:.1f}s")
-    return ix, synth.to_numpy(q, dtype), gt_i.cpu().numpy().astype(np.uint32), gt_d.cpu().numpy().astype(np.float32)
+    return ix, synth.to_numpy(q.float(), dtype), gt_i.cpu().numpy().astype(np.uint32), gt_d.cpu().numpy().astype(np.float32)

@@ -35,7 +35,7 @@ def _gen(seed: int, device) -> torch.Generator:
 
 
 def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, d_lat: int = 16, spread: float = 3.0,
-                 noise: float = 2.0, seed: int = SEED, device="cpu") -> torch.Tensor:
+                 noise: float = 2.0, seed: int = SEED, device="cpu", out_dtype=None) -> torch.Tensor:
     """float32 tensor [N, D] already rounded/clipped to the value range of ``dtype``.
 
     Low intrinsic dimension, like real descriptor data: a ``d_lat``-dimensional Gaussian-mixture latent
@@ -47,6 +47,27 @@ def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, d_lat: int =
     A = torch.randn(d_lat, D, generator=g, device=device)
     A = A / A.norm(dim=0, keepdim=True)
     centres = torch.randn(n_clusters, d_lat, generator=g, device=device) * spread
+    if out_dtype is not None and N > (1 << 24):
+        # large N: generated block by block into a tensor of out_dtype (bfloat16 holds 8-bit values exactly) -- the [N, D] float32
+        # intermediate of the one-shot path is 51 GB at N = 1e8.  Same distribution, its own random stream; the scale comes from
+        # the first block.
+        out = torch.empty((N, D), dtype=out_dtype, device=device)
+        scale = None
+        for a in range(0, N, 1 << 22):
+            n = min(1 << 22, N - a)
+            assign = torch.randint(0, n_clusters, (n,), generator=g, device=device)
+            xb = (centres[assign] + torch.randn(n, d_lat, generator=g, device=device)) @ A
+            if scale is None:
+                scale = 36.0 / float(xb.std())
+            xb = xb * scale + 128.0 + torch.randn(n, D, generator=g, device=device) * noise
+            if dtype == "uint8":
+                xb = xb.round().clamp_(0, 255)
+            elif dtype == "int8":
+                xb = (xb - 128.0).round().clamp_(-128, 127)
+            else:
+                xb = (xb - 128.0) / 128.0
+            out[a:a + n] = xb.to(out_dtype)
+        return out
     assign = torch.randint(0, n_clusters, (N,), generator=g, device=device)
     z = centres[assign] + torch.randn(N, d_lat, generator=g, device=device)
     x = z @ A
@@ -57,7 +78,23 @@ def make_vectors(N: int, D: int, dtype: str, n_clusters: int = 256, d_lat: int =
         x = (x - 128.0).round().clamp_(-128, 127)
     else:
         x = (x - 128.0) / 128.0
-    return x
+    return x if out_dtype is None else x.to(out_dtype)
+
+
+def medoid_of(x: torch.Tensor) -> int:
+    """The point nearest the dataset mean (block-wise: x may be a 25 GB bfloat16 tensor)."""
+    N = x.shape[0]
+    mean = torch.zeros(x.shape[1], dtype=torch.float64, device=x.device)
+    for a in range(0, N, 1 << 22):
+        mean += x[a:a + (1 << 22)].double().sum(0)
+    mean = (mean / N).float()
+    best, arg = float("inf"), 0
+    for a in range(0, N, 1 << 22):
+        d = _sq_norms(x[a:a + (1 << 22)].float() - mean)
+        v, i = torch.min(d, 0)
+        if float(v) < best:
+            best, arg = float(v), a + int(i)
+    return arg
 
 
 def _sq_norms(x: torch.Tensor) -> torch.Tensor:
@@ -69,14 +106,15 @@ def knn(base: torch.Tensor, queries: torch.Tensor, k: int, exclude_self: bool = 
     """Exact k nearest neighbours (squared L2) of every query row among ``base`` rows.
     Returns (ids int64 [Q,k], dists float32 [Q,k]) sorted ascending by (dist, id)."""
     Nb = base.shape[0]
-    bn = _sq_norms(base)
+    low = base.dtype != torch.float32                     # 8-bit data held as bfloat16: exact values, f32 arithmetic per block
+    bn = torch.cat([_sq_norms(base[a:a + (1 << 22)].float()) for a in range(0, Nb, 1 << 22)]) if low else _sq_norms(base)
     out_i, out_d = [], []
     for r0 in range(0, queries.shape[0], row_block):
-        q = queries[r0:r0 + row_block]
+        q = queries[r0:r0 + row_block].float()
         qn = _sq_norms(q)
         cand_d, cand_i = [], []
         for c0 in range(0, Nb, col_block):
-            b = base[c0:c0 + col_block]
+            b = base[c0:c0 + col_block].float()
             d = qn[:, None] + bn[None, c0:c0 + col_block] - 2.0 * (q @ b.T)
             if exclude_self:
                 rows = torch.arange(r0, r0 + q.shape[0], device=base.device)
@@ -90,7 +128,7 @@ def knn(base: torch.Tensor, queries: torch.Tensor, k: int, exclude_self: bool = 
         ci = torch.cat(cand_i, dim=1)
         # exact re-evaluation of the shortlisted candidates (removes matmul round-off), then a
         # lexicographic (dist, id) order so ties are deterministic
-        diff = q[:, None, :] - base[ci]
+        diff = q[:, None, :] - base[ci].float()
         cd = (diff * diff).sum(dim=2)
         order = torch.argsort(ci, dim=1, stable=True)
         cd, ci = torch.gather(cd, 1, order), torch.gather(ci, 1, order)
@@ -135,15 +173,22 @@ def train_pq(x: torch.Tensor, m: int, iters: int = 8, sample: int = 65536, seed:
     N, D = x.shape
     dev = x.device
     g = _gen(seed + 2, dev)
-    centroid = x.mean(dim=0)
-    xc = x - centroid
+    if x.dtype == torch.float32 and N <= (1 << 24):
+        centroid = x.mean(dim=0)
+    else:                                                  # block-wise (a 25 GB bfloat16 tensor must not be copied to float32 whole)
+        acc = torch.zeros(D, dtype=torch.float64, device=dev)
+        for a in range(0, N, 1 << 22):
+            acc += x[a:a + (1 << 22)].double().sum(0)
+        centroid = (acc / N).float()
     off = chunk_offsets(D, m)
     pivots = torch.zeros(256, D, device=dev)
     codes = torch.empty(N, m, dtype=torch.uint8, device=dev)
     sidx = torch.randperm(N, generator=g, device=dev)[: min(sample, N)]
+    xs = x[sidx].float() - centroid
+    cens = []
     for c in range(m):
         a, b = int(off[c]), int(off[c + 1])
-        sub = xc[sidx, a:b]
+        sub = xs[:, a:b]
         if sub.shape[0] >= 256:
             init = torch.randperm(sub.shape[0], generator=g, device=dev)[:256]
         else:
@@ -157,9 +202,12 @@ def train_pq(x: torch.Tensor, m: int, iters: int = 8, sample: int = 65536, seed:
             nz = cnt > 0
             cen[nz] = sums[nz] / cnt[nz, None]
         pivots[:, a:b] = cen
-        full = xc[:, a:b]
-        for r0 in range(0, N, 1 << 20):
-            codes[r0:r0 + (1 << 20), c] = torch.cdist(full[r0:r0 + (1 << 20)], cen).argmin(dim=1).to(torch.uint8)
+        cens.append(cen)
+    for r0 in range(0, N, 1 << 20):
+        full = x[r0:r0 + (1 << 20)].float() - centroid
+        for c in range(m):
+            a, b = int(off[c]), int(off[c + 1])
+            codes[r0:r0 + (1 << 20), c] = torch.cdist(full[:, a:b], cens[c]).argmin(dim=1).to(torch.uint8)
     return pivots, centroid, off, codes
 
 
@@ -167,7 +215,7 @@ def make_queries(x: torch.Tensor, Q: int, dtype: str, noise: float = 4.5, seed: 
     g = _gen(seed + 3, x.device)
     pick = torch.randint(0, x.shape[0], (Q,), generator=g, device=x.device)
     scale = noise if dtype != "float" else noise / 128.0
-    q = x[pick] + torch.randn(Q, x.shape[1], generator=g, device=x.device) * scale
+    q = x[pick].float() + torch.randn(Q, x.shape[1], generator=g, device=x.device) * scale
     if dtype == "uint8":
         q = q.round().clamp_(0, 255)
     elif dtype == "int8":

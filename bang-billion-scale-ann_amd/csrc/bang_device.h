@@ -158,7 +158,13 @@ struct PqRow {
   uint32_t sh;
 };
 
-template <int NDW, bool ALIGNED>
+// NT: the row is requested with the non-temporal hint (global_load ... nt).  A code row is read once per evaluation from a table of
+// 32 MB .. 70 GB and never again soon: streamed through L2 / Infinity Cache with the default policy it evicts the lines that ARE
+// re-used -- the live queries' visited filters (50 KB each, ~200 MB in all).
+#ifndef BANG_CODES_NT
+#define BANG_CODES_NT 0
+#endif
+template <int NDW, bool ALIGNED, bool NT = (BANG_CODES_NT != 0)>
 __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_t* __restrict__ codes, uint32_t m,
                                             uint32_t id) {
   const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
@@ -166,7 +172,7 @@ __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_
   const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
 #pragma unroll
   for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4; ++i) {
-    const u32x4a v = p[i];
+    const u32x4a v = NT ? __builtin_nontemporal_load(p + i) : p[i];
     r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
   }
   r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
