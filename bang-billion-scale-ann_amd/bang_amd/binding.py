@@ -40,7 +40,7 @@ class IterParams(C.Structure):
         ("d_mark", C.c_void_p), ("d_parents", C.c_void_p), ("d_cand_ids", C.c_void_p), ("d_cand_row", C.c_void_p),
         ("d_cand_cnt", C.c_void_p), ("d_active", C.c_void_p), ("d_qstats", C.c_void_p),
         ("d_done_count", C.c_void_p), ("h_done_flag", C.c_void_p), ("d_ktime", C.c_void_p), ("h_parents", C.c_void_p), ("done_value", C.c_uint32),
-        ("pq_nhi", C.c_uint32),
+        ("pq_nhi", C.c_uint32), ("code_stride", C.c_uint32),
     ]
 
 
@@ -55,14 +55,15 @@ class SearchParams(C.Structure):
         ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
-        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
+        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
     ]
 
 
 class IndexDesc(C.Structure):
     _fields_ = [("medoid", C.c_uint64), ("entry_len", C.c_uint64), ("D", C.c_uint32), ("R", C.c_uint32),
                 ("N", C.c_uint32), ("m", C.c_uint32), ("graph", C.c_void_p), ("codes", C.c_void_p),
-                ("d_codes", C.c_void_p), ("pivots", C.c_void_p), ("centroid", C.c_void_p), ("chunk_off", C.c_void_p)]
+                ("d_codes", C.c_void_p), ("pivots", C.c_void_p), ("centroid", C.c_void_p), ("chunk_off", C.c_void_p),
+                ("code_stride", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -74,7 +75,7 @@ class Stats(C.Structure):
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
                 ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64),
-                ("filter_loads_skipped", C.c_uint64)]
+                ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64)]
 
 
 ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source
@@ -190,8 +191,9 @@ class Engine:
     def load(self, prefix: str):
         _check(lib().bang_load_e(self._h, prefix.encode()), "bang_load")
 
-    def load_index(self, ix, d_codes: int | None = None):
-        """Load from a formats.Index held in memory (graph stays referenced, not copied, in host mode)."""
+    def load_index(self, ix, d_codes: int | None = None, code_stride: int = 0):
+        """Load from a formats.Index held in memory (graph stays referenced, not copied, in host mode).  d_codes: the PQ codes are
+        already on the device, rows `code_stride` bytes apart (0 = m)."""
         graph = np.ascontiguousarray(ix.graph, dtype=np.uint8)
         codes = np.ascontiguousarray(ix.codes, dtype=np.uint8)
         pivots = np.ascontiguousarray(ix.pivots, dtype=np.float32)
@@ -199,10 +201,10 @@ class Engine:
         chunk_off = np.ascontiguousarray(ix.chunk_off, dtype=np.uint32)
         self._keep = [graph, codes, pivots, centroid, chunk_off]
         d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, _vp(graph).value, _vp(codes).value,
-                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value)
+                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride)
         _check(lib().bang_load_mem_e(self._h, C.byref(d)), "bang_load_mem")
 
-    def load_stream(self, ix, source, ctx=None, d_codes: int | None = None):
+    def load_stream(self, ix, source, ctx=None, d_codes: int | None = None, code_stride: int = 0):
         """Streamed load (bang_load_stream_e): `source` is a C function pointer -- or a Python callable
         (first, count, dst_address) -> 0 -- that writes `count` graph entries in the reference layout for the nodes from `first`;
         ix supplies everything but the graph (medoid, entry_len, D, R, N, m, codes, pivots, centroid, chunk_off)."""
@@ -215,7 +217,7 @@ class Engine:
             source = ENTRY_SOURCE(lambda _ctx, first, count, dst: int(py(first, count, dst)))
         self._keep = [codes, pivots, centroid, chunk_off, source]
         d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, None, None if codes is None else _vp(codes).value,
-                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value)
+                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride)
         fn = lib().bang_load_stream_e
         fn.argtypes = [C.c_void_p, C.POINTER(IndexDesc), C.c_void_p, C.c_void_p]
         _check(fn(self._h, C.byref(d), C.cast(source, C.c_void_p), ctx), "bang_load_stream")

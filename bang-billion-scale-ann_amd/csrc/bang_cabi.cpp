@@ -78,7 +78,7 @@ extern "C" int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* d) {
   e->graph = d->graph;
   e->graph_owned = nullptr;
   e->graph_path.clear();
-  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off, d->d_codes ? d->code_stride : 0);
   if (rc != BANG_OK) unload_index(e);
   return rc;
 }
@@ -101,7 +101,7 @@ extern "C" int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* d, ba
     return BANG_ERR_ARG;
   }
   e->entry_fn = src; e->entry_ctx = ctx;
-  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off);
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off, d->d_codes ? d->code_stride : 0);
   e->entry_fn = nullptr; e->entry_ctx = nullptr;
   if (rc != BANG_OK) unload_index(e);
   return rc;
@@ -242,6 +242,7 @@ static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* 
   s.graph_pull = (e->pull && e->search_v2 && e->graph_mode != BANG_GRAPH_DEVICE) ? 1 : 0;
   s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
   s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
+  s.code_stride = e->code_stride;
   return rc;
 }
 

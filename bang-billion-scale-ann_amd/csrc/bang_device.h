@@ -178,6 +178,57 @@ __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_
   r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
 }
 
+// COOPERATIVE fetch of the code rows of a wave's <= 64 survivors.  With per-lane loads (pq_row_load) every one of the NX4 load
+// instructions of a wave touches 64 different lines -- 5 x 64 line look-ups for 64 rows of 70 bytes, each row's two or three lines
+// looked up again by every instruction -- and the memory pipeline retires ~85 G such look-ups a second: 17 G rows/s
+// (tools/dev/row_fetch_bench.hip).  Here P = NX4 ADJACENT lanes ask for the P 16-byte pieces of ONE row in one instruction, so the
+// pieces of a row merge into one request per line: 30 G rows/s for packed 70-byte rows, 47 G rows/s where a row never leaves its
+// 128-byte line (code_stride = 128) -- the random-access rate of the memory system itself.  A wave instruction covers RPI = 64 / P
+// rows; NI of them cover 64.  The pieces then change hands through 1 KB of the wave's LDS (RPI rows at a time: the lanes that loaded
+// a row store their pieces, the lane that evaluates the row reads all P back), so the reduce below sees the same PqRow as before.
+template <int NDW, bool ALIGNED>
+struct CoopFetch {
+  typedef PqRow<NDW, ALIGNED> Row;
+  static constexpr int P = Row::NX4;                   // 16-byte pieces per row
+  static constexpr int RPI = 64 / P;                   // rows per wave instruction
+  static constexpr int NI = (64 + RPI - 1) / RPI;      // wave instructions for 64 rows
+  static constexpr int LDS_WORDS = RPI * P * 4;        // staging: one instruction's worth of pieces (<= 256 words)
+  u32x4a v[NI];
+  // id: the row this lane will evaluate (valid for lane < n); every lane of the wave must be executing
+  __device__ __forceinline__ void issue(const uint8_t* __restrict__ codes, uint32_t stride, uint32_t id, uint32_t n, int lane) {
+    const uint32_t slot = (uint32_t)lane / (uint32_t)P, piece = (uint32_t)lane % (uint32_t)P;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint32_t rr = (uint32_t)j * RPI + slot;                                       // the row (= lane number of its evaluator)
+      const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr & 63u) << 2), (int)id);
+      const bool ok = slot < (uint32_t)RPI && rr < n;
+      const uint64_t a = (uint64_t)rid * stride;
+      const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + piece;
+      v[j] = ok ? *p : u32x4a{0u, 0u, 0u, 0u};
+    }
+  }
+  __device__ __forceinline__ void collect(Row& r, uint32_t* buf /* LDS_WORDS words of the wave's LDS, 16-byte aligned */, uint32_t stride,
+                                          uint32_t id, int lane) {
+    r.sh = ((uint32_t)id * stride) & 3u;                // (low two bits of the 64-bit row offset)
+    const uint32_t slot = (uint32_t)lane / (uint32_t)P;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (slot < (uint32_t)RPI) *(u32x4a*)(buf + 4 * lane) = v[j];                         // (lane = slot * P + piece: contiguous)
+      wave_sync();
+      const uint32_t k = (uint32_t)lane - (uint32_t)j * RPI;                             // my row within this instruction's batch
+      if (k < (uint32_t)RPI) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const u32x4a t = *(const u32x4a*)(buf + (k * P + q) * 4);
+          r.w[4 * q + 0] = t.x; r.w[4 * q + 1] = t.y; r.w[4 * q + 2] = t.z; r.w[4 * q + 3] = t.w;
+        }
+      }
+      wave_sync();
+    }
+    r.w[Row::NX4 * 4] = 0;
+  }
+};
+
 // SB > 0: the row is consumed in segments of SB code dwords; a dependency fence between segments keeps the compiler from hoisting
 // the LDS reads of the whole row (72 chunks of the 70/74-chunk layouts) in front of the first add -- that is what pushed those
 // instances past 128 VGPRs.

@@ -145,6 +145,8 @@ struct bang_engine {
   uint32_t* d_seed = nullptr;       // {count, MEDOID, adj(MEDOID)...}
   uint8_t* d_medoid_vec = nullptr;
   uint32_t psz = 0, mp = 0;
+  int code_stride_opt = -1;            // option "code_stride": -1 auto (pad rows to a power of two when HBM allows), 0 packed (m), > 0 bytes
+  uint32_t code_stride = 0;            // resolved at load: bytes between code rows in d_codes
   // search params
   int k = 0, L = 0, distfn = BANG_DIST_L2;
   bool params_set = false;
@@ -295,7 +297,7 @@ const char* env_str(const char* name);
 int usable_cpus();                       // CPUs this process may really use (affinity mask capped by the cgroup quota)
 size_t host_bytes_available();           // host memory this process may still take (MemAvailable capped by the cgroup)
 int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext, const float* pivots, const float* centroid,
-                 const uint32_t* chunk_off);
+                 const uint32_t* chunk_off, uint32_t desc_code_stride);
 void unload_index(bang_engine* e);
 int load_files(bang_engine* e, const char* prefix);
 int map_graph_file(bang_engine* e);

@@ -26,9 +26,9 @@
 #include "bang_device.h"
 
 // LUT path (PSZ == 0): LUT[m][256] gathered from global memory as the reference does (:1236); any m.
-__device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ codes, uint32_t m, uint32_t id,
+__device__ __forceinline__ float pq_distance_lut(const uint8_t* __restrict__ codes, uint32_t m, uint32_t stride, uint32_t id,
                                                  const float* __restrict__ lut) {
-  const uint8_t* row = codes + (uint64_t)id * m;
+  const uint8_t* row = codes + (uint64_t)id * stride;
   float s[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) s[l] = 0.0f;
@@ -438,14 +438,15 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
 #pragma unroll
     for (int u = 0; u < NQW; ++u) { d0[u] = BIG_DIST; d1[u] = BIG_DIST; }
     if (do_dist) {
+      const uint32_t cstride = p.code_stride ? p.code_stride : p.m;      // bytes between code rows
       if constexpr (PSZ > 0) {
         // ---- round trip C: the code rows, software pipelined over the NQW queries
         PqRow<NDW, ALIGNED> rows[2];
-        if ((uint32_t)lane < n[0]) pq_row_load(rows[0], p.d_codes, p.m, sid0[0]);
+        if ((uint32_t)lane < n[0]) pq_row_load(rows[0], p.d_codes, cstride, sid0[0]);
 #pragma unroll
         for (int u = 0; u < NQW; ++u) {
           if (u + 1 < NQW) {
-            if ((uint32_t)lane < n[u + 1]) pq_row_load(rows[(u + 1) & 1], p.d_codes, p.m, sid0[u + 1]);
+            if ((uint32_t)lane < n[u + 1]) pq_row_load(rows[(u + 1) & 1], p.d_codes, cstride, sid0[u + 1]);
           }
           cfloat_p qc = (cfloat_p)(uintptr_t)(p.d_qc + (size_t)q[u] * (NDW * 4 * PSZ));
           if ((uint32_t)lane < n[u]) {
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
           if (n[u] > 64) {                                  // survivor 64 (seed list only), lane 0
             if (lane == 0) {
               PqRow<NDW, ALIGNED> r1;
-              pq_row_load(r1, p.d_codes, p.m, sid1[u]);
+              pq_row_load(r1, p.d_codes, cstride, sid1[u]);
               d1[u] = pq_row_reduce<PSZ, NDW, ALIGNED, NHI>(r1, piv_lds, qc);
             }
           }
@@ -465,8 +466,8 @@ __global__ __launch_bounds__(MAXT) void front_kernel(const FrontArgs a) {
 #pragma unroll
         for (int u = 0; u < NQW; ++u) {
           const float* lut = p.d_lut + (size_t)q[u] * p.m * 256;
-          if ((uint32_t)lane < n[u]) d0[u] = pq_distance_lut(p.d_codes, p.m, sid0[u], lut);
-          if (n[u] > 64 && lane == 0) d1[u] = pq_distance_lut(p.d_codes, p.m, sid1[u], lut);
+          if ((uint32_t)lane < n[u]) d0[u] = pq_distance_lut(p.d_codes, p.m, cstride, sid0[u], lut);
+          if (n[u] > 64 && lane == 0) d1[u] = pq_distance_lut(p.d_codes, p.m, cstride, sid1[u], lut);
         }
       }
 #pragma unroll
@@ -1023,7 +1024,7 @@ static int launch_front(const bang_iter_params* p, uint32_t stages, void* stream
   int grid_n = (int)((p->Q + (uint32_t)(waves * nqw) - 1) / (uint32_t)(waves * nqw));
   if (grid_n > wgs) grid_n = wgs;
   const dim3 grid(grid_n), block(waves * WAVE);
-  const bool al = (p->m % 4u) == 0;
+  const bool al = ((p->code_stride ? p->code_stride : p->m) % 4u) == 0;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + (p->psz ? p->mp / 4u : 0u);
   switch (key) {

@@ -15,6 +15,7 @@ void fill_params(bang_engine* e, const Lane& ln, bang_iter_params& p) {
                                         : (e->d_stage ? e->d_stage + q0 * BANG_STAGE_STRIDE : nullptr);
   p.d_seed = e->d_seed;
   p.d_codes = e->d_codes;
+  p.code_stride = e->code_stride;
   p.d_pivots_packed = e->pq_nhi ? e->d_pivots_ragged : e->d_pivots_packed;
   p.d_qc = e->d_qc ? e->d_qc + q0 * e->mp * e->psz : nullptr;
   p.d_lut = e->d_lut ? e->d_lut + q0 * e->m * 256 : nullptr;
@@ -143,7 +144,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     memset(&sp, 0, sizeof(sp));
     sp.Q = ln.nq; sp.R = e->R; sp.m = e->m; sp.L = (uint32_t)e->L; sp.medoid = (uint32_t)e->medoid; sp.cap_iter = cap_iter;
     sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
-    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
+    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.code_stride = e->code_stride; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
     sp.d_graph = e->d_graph; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
     if (!dev_graph) { sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1; }   // pull mode
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
@@ -194,7 +195,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.Q = ln.nq; sp.R = e->R; sp.m = e->m; sp.L = (uint32_t)e->L; sp.medoid = (uint32_t)e->medoid; sp.cap_iter = cap_iter;
     sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
     sp.max_wgs = G; sp.max_waves = W; sp.nctx = e->sv_C; sp.group_waves = e->sv_GS;
-    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
+    sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.code_stride = e->code_stride; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
     sp.d_graph = nullptr; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1;

@@ -477,7 +477,7 @@ int map_graph_file(bang_engine* e) {
 }
 
 int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext, const float* pivots,
-                 const float* centroid, const uint32_t* chunk_off) {
+                 const float* centroid, const uint32_t* chunk_off, uint32_t desc_code_stride) {
   const uint32_t D = e->D, m = e->m;
   if (e->R == 0 || e->R > BANG_MAX_R) {             // assert(R == MAX_R), bang_search.cu:190 (relaxed to R <= 64)
     bang_set_error("graph degree bound R=%u unsupported (max %d)", e->R, BANG_MAX_R);
@@ -488,23 +488,65 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
     return BANG_ERR_IO;
   }
   if (e->medoid >= e->N) { bang_set_error("medoid out of range"); return BANG_ERR_IO; }
-  // PQ codes (+256 B slack: the distance kernel over-reads up to 19 B past a row)
-  const size_t code_bytes = (size_t)e->N * m;
+  // PQ layout first: it decides how the code rows are laid out in HBM
+  uint32_t psz = 0, mp = m;
+  BANG_TRY(bang_pq_layout(chunk_off, D, m, &psz, &mp));
+  if (e->pq_mode == 1) { psz = 0; mp = m; }
+  e->psz = psz;
+  e->mp = mp;
+  // PQ codes (+256 B slack: the distance kernel over-reads up to 19 B past a row).
+  // Row stride.  <p>_pq_compressed.bin packs the rows m bytes apart, so a 70-byte row straddles two or three 64-byte lines.  The
+  // search kernel fetches a row with one request per LINE it touches (CoopFetch, bang_device.h): rows that never leave their
+  // 128-byte line are fetched at 47 G rows/s against 30 G rows/s packed (tools/dev/row_fetch_bench.hip).  "code_stride" = -1 (auto)
+  // pads the rows to the next power of two (64 < m <= 128 -> 128, 32 < m <= 64 -> 64) when HBM holds the padded table next to what
+  // the placement needs; 0 keeps them packed; a caller's own device table (desc->d_codes) is used as it is laid out.
+  const size_t hbm_reserve = (size_t)16 << 30;
+  uint32_t stride = m;
+  if (d_codes_ext) {
+    stride = desc_code_stride ? desc_code_stride : m;
+    if (stride < m) { bang_set_error("code_stride %u is smaller than a row (m = %u)", stride, m); return BANG_ERR_ARG; }
+  } else if (e->code_stride_opt > 0) {
+    stride = (uint32_t)e->code_stride_opt;
+    if (stride < m) { bang_set_error("option code_stride = %u is smaller than a row (m = %u)", stride, m); return BANG_ERR_ARG; }
+  } else if (e->code_stride_opt < 0 && psz != 0 && m > 32 && m <= 128) {
+    uint32_t pad = 64;
+    while (pad < m) pad <<= 1;
+    if (pad != m) {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const size_t N_ = e->N, gbytes = N_ * e->entry_len + 256, vbytes = N_ * (size_t)D * e->tsize;
+      const bool dev_packed = N_ * m + gbytes + hbm_reserve <= free_b;
+      bool ok;
+      if (e->graph_mode == BANG_GRAPH_DEVICE || (e->graph_mode == BANG_GRAPH_AUTO && dev_packed)) ok = N_ * pad + gbytes + hbm_reserve <= free_b;   // (never flips auto to host)
+      else ok = N_ * pad + (e->vectors_opt != 0 ? vbytes : 0) + hbm_reserve + ((size_t)8 << 30) <= free_b;
+      if (ok) stride = pad;
+    }
+  }
+  e->code_stride = stride;
+  const size_t code_bytes = (size_t)e->N * stride;
   if (d_codes_ext) {
     e->d_codes = (uint8_t*)d_codes_ext;
     e->codes_owned = false;
   } else {
     HIP_TRY(hipMalloc((void**)&e->d_codes, code_bytes + 256));
     e->codes_owned = true;
-    HIP_TRY(hipMemset(e->d_codes + code_bytes, 0, 256));
-    const size_t step = (size_t)1 << 30;
-    for (size_t off = 0; off < code_bytes; off += step)
-      HIP_TRY(hipMemcpy(e->d_codes + off, h_codes + off, std::min(step, code_bytes - off), hipMemcpyHostToDevice));
+    if (stride == m) {
+      HIP_TRY(hipMemset(e->d_codes + code_bytes, 0, 256));
+      const size_t step = (size_t)1 << 30;
+      for (size_t off = 0; off < code_bytes; off += step)
+        HIP_TRY(hipMemcpy(e->d_codes + off, h_codes + off, std::min(step, code_bytes - off), hipMemcpyHostToDevice));
+    } else {
+      HIP_TRY(hipMemset(e->d_codes, 0, code_bytes + 256));
+      const size_t rows_per = std::max<size_t>(1, ((size_t)1 << 30) / m);
+      for (size_t r0 = 0; r0 < e->N; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, (size_t)e->N - r0);
+        HIP_TRY(hipMemcpy2D(e->d_codes + r0 * stride, stride, h_codes + r0 * m, m, m, nr, hipMemcpyHostToDevice));
+      }
+    }
   }
   // Placement.  HBM left after the PQ codes decides: the whole graph (adjacency + vectors) if it fits with 16 GB to spare for
   // the per-batch state -> no host in the loop at all; else the graph stays in host RAM (C++ walker) and, if THEY fit, a packed
   // copy of the full-precision vectors goes to HBM for the re-rank (128 GB for 1e9 x 128 uint8 next to 70 GB of codes).
-  const size_t hbm_reserve = (size_t)16 << 30;
   if (e->graph_mode == BANG_GRAPH_AUTO) {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -523,11 +565,6 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   HIP_TRY(hipMemcpy(e->d_centroid, centroid, (size_t)D * 4, hipMemcpyHostToDevice));
   BANG_TRY(dmalloc(&e->d_chunk_off, m + 1));
   HIP_TRY(hipMemcpy(e->d_chunk_off, chunk_off, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
-  uint32_t psz = 0, mp = m;
-  BANG_TRY(bang_pq_layout(chunk_off, D, m, &psz, &mp));
-  if (e->pq_mode == 1) { psz = 0; mp = m; }
-  e->psz = psz;
-  e->mp = mp;
   // 2-float layouts whose chunks are 2,..,2,1,..,1 dims wide also get the exact-size table (if a kernel instance exists for it);
   // bang_alloc picks it when only it leaves room for the persistent kernel's merge scratch at the requested L
   e->pq_nhi = 0; e->pq_nhi_avail = 0;
@@ -780,7 +817,7 @@ int load_files(bang_engine* e, const char* prefix) {
     e->graph = nullptr;
     return rc;
   }
-  rc = upload_index(e, codes.data(), nullptr, pivots.data(), centroid.data(), chunk_off.data());
+  rc = upload_index(e, codes.data(), nullptr, pivots.data(), centroid.data(), chunk_off.data(), 0);
   if (dsrc.fd >= 0) close(dsrc.fd);
   e->entry_fn = nullptr; e->entry_ctx = nullptr; e->entry_src_rereadable = false;
   if (rc != BANG_OK) unload_index(e);

@@ -32,6 +32,9 @@ static const OptionDef kOptions[] = {
     {"device", "BANG_DEVICE", &bang_engine::device, 0, 1 << 20, INT, BEFORE_LOAD, "HIP device ordinal"},
     {"pq", "BANG_PQ", &bang_engine::pq_mode, 0, 1, INT, BEFORE_LOAD, "0 = pivot table resident in LDS (default when it fits), 1 = LUT path (K1 + K2)"},
     {"pq_ragged", "BANG_PQ_RAGGED", &bang_engine::pq_ragged, 0, 1, FLAG, BEFORE_LOAD, "2-dim/1-dim PQ layouts: exact-size pivot table where a kernel instance exists (default 1)"},
+    {"code_stride", "BANG_CODE_STRIDE", &bang_engine::code_stride_opt, -1, 4096, INT, BEFORE_LOAD,
+     "bytes between PQ code rows in HBM: 0 = packed as in <p>_pq_compressed.bin (m), -1 = auto: padded to the next power of two (m = 70 -> 128) "
+     "when HBM holds the padded table, so that a row never leaves its 128-byte line (one request per row instead of two or three)"},
     {"vectors", "BANG_VECTORS", &bang_engine::vectors_opt, -1, 1, INT, BEFORE_LOAD,
      "host graph: 1 = packed copy of the full-precision vectors in HBM for the re-rank, 0 = the walker ships every expanded node's vector "
      "(the reference's data flow), -1 = auto (1 when the copy fits with 16 GB to spare)"},

@@ -45,11 +45,19 @@ struct SearchArgs {
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
 };
 
-#define SRCH_SCRATCH_WORDS 144u     // sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both
+#ifndef BANG_SEARCH_COOP
+#define BANG_SEARCH_COOP 1          // self-paced form: code rows fetched cooperatively (CoopFetch, bang_device.h)
+#endif
+// The cooperative fetch pays from three 16-byte pieces per row on (rows of 12+ code dwords, m > 44): two-piece rows (m = 32) gain
+// nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging area.
+__host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return !host_paced && BANG_SEARCH_COOP && ndw >= 12; }
+// per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both, and so does the staging area
+// of the cooperative code-row fetch (256 words: one wave instruction's worth of 16-byte pieces)
+__host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) { return search_coop(ndw, host_paced) ? 256u : 144u; }
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
-__host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx) {
-  return nctx * search_wl_words(L) + SRCH_SCRATCH_WORDS + (nctx == 2 ? 32u : 0u);
+__host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx, int ndw, bool host_paced) {
+  return nctx * search_wl_words(L) + search_scratch_words(ndw, host_paced) + (nctx == 2 ? 32u : 0u);
 }
 
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
@@ -114,8 +122,8 @@ __device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint
       if (own_b) vb = tbl[sb];
       wave_sync();
     }
-    if (own_a) bloom[ia] = wa | va;
-    if (own_b) bloom[ib] = wb | vb;
+    if (own_a && (wa | va) != wa) bloom[ia] = wa | va;      // (a survivor has at most one of its two bits set already: that store is moot)
+    if (own_b && (wb | vb) != wb) bloom[ib] = wb | vb;
     pa = pa && !(own_a || same_a);
     pb = pb && !(own_b || same_b);
   }
@@ -406,8 +414,13 @@ __device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lan
 #define SRCH_FIN 0xFFFFFFFFu        // h_done value: this context group of the workgroup has no queries left
 #define SRCH_CTX_WORDS 16u          // parked per-context state of a wave, in LDS
 
+// MAXT: threads per workgroup the instance is compiled for -- 1024 (16 waves, 128 VGPRs each) or, for the self-paced instances of
+// the long code rows (>= 64 chunks: the cooperative fetch holds a row's pieces and the row itself for a moment), 768 (12 waves, 168
+// VGPRs each; 12 waves run the request-bound layouts as fast as 15 or 16: DESIGN 4.6)
+__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? 768 : 1024; }
+
 template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST>
-__global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
+__global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_search_params& p = a.p;
   float* piv_lds = lds;
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
   // a wave's LDS region: [worklist of context 0]([worklist of context 1])[scratch 144]([parked context state 2 x 16]: nctx == 2 only)
   uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
   uint32_t* scratch = wbase + (size_t)nctx * a.wl_words;
-  uint32_t* park = scratch + SRCH_SCRATCH_WORDS;
+  uint32_t* park = scratch + search_scratch_words(NDW, HOST);
   // pacing group of this wave
   const uint32_t gs = HOST ? a.gs : nwaves;
   const uint32_t grp_in_wg = HOST ? wave / gs : 0u;
@@ -470,6 +483,8 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 #define BANG_HOST_EARLY_ROWS 0     // host-paced instances: 60-100 B of scratch per lane with it, SIFT1B-shape 13.5 -> 16.3 ms
 #endif
   constexpr bool EARLY_ROWS = !HOST || BANG_HOST_EARLY_ROWS;   // code rows requested before the filter update (else: behind it)
+  constexpr bool COOP = search_coop(NDW, HOST);                // ... by P adjacent lanes per row, one 16-byte piece each
+  const uint32_t code_stride = p.code_stride ? p.code_stride : p.m;
 
   // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
   bool active = false, exhausted = false;
@@ -649,7 +664,9 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
 
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
-      if (EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, p.m, sid0);
+      CoopFetch<NDW, ALIGNED> cf;
+      if (COOP) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      else if (EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
@@ -673,14 +690,15 @@ __global__ __launch_bounds__(1024) void search_kernel(const SearchArgs a) {
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
+        if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if ((uint32_t)lane < n) {
-          if (!EARLY_ROWS) pq_row_load(row, p.d_codes, p.m, sid0);
+          if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
           d0 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
         if (n > 64) {                                          // survivor 64 (seed list only), lane 0
           if (lane == 0) {
             PqRow<NDW, ALIGNED> r1;
-            pq_row_load(r1, p.d_codes, p.m, sid1);
+            pq_row_load(r1, p.d_codes, code_stride, sid1);
             d1 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
           }
         }
@@ -853,10 +871,17 @@ __device__ __forceinline__ bool pipe_trip(F& f, std::integer_sequence<int, I...>
 #ifndef BANG_K2_QC_ROW16
 #define BANG_K2_QC_ROW16 0
 #endif
+#ifndef BANG_K2_COOP
+#define BANG_K2_COOP 1              // code rows fetched cooperatively (CoopFetch, bang_device.h); 0 = one row per lane, NX4 loads each
+#endif
 template <int PSZ, int NDW, bool ALIGNED, int NHI, int MAXT>
 __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_params p, uint32_t lds_piv_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* piv_lds = lds;
+  constexpr bool COOP = BANG_K2_COOP != 0;
+  const uint32_t stride = p.code_stride ? p.code_stride : p.m;
+  // staging area of this wave's cooperative row fetch, behind the pivot table
+  uint32_t* coop_buf = (uint32_t*)(lds + lds_piv_floats) + (size_t)(threadIdx.x >> 6) * CoopFetch<NDW, ALIGNED>::LDS_WORDS;
   {
     const float4* src = (const float4*)p.d_pivots_packed;
     float4* dst = (float4*)piv_lds;
@@ -903,7 +928,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
   // (RD (RD + 1) of them per trip of the loop) so that everything stays in registers.
   // (RD = 3 measured the same as 2 for every layout, at 8 and at 16 waves per CU: the memory system is full with two)
   constexpr int RD = 2, SD = RD + 1;
-  PqRow<NDW, ALIGNED> row[RD];
+  PqRow<NDW, ALIGNED> row[COOP ? 1 : RD];
+  CoopFetch<NDW, ALIGNED> raw[COOP ? RD : 1];
   Qc qc[SD];
   uint32_t ids[SD], cnt[SD], qq[SD];
   bool has[SD];
@@ -919,7 +945,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
     qnext += step;
   };
   auto load_rows = [&](int s, int r) {
-    if (has[s] && (uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) pq_row_load(row[r], p.d_codes, p.m, ids[s]);
+    if (COOP) { if (has[s]) raw[r].issue(p.d_codes, stride, ids[s], cnt[s] < 64u ? cnt[s] : 64u, lane); }     // (has[] is uniform)
+    else if (has[s] && (uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) pq_row_load(row[r], p.d_codes, stride, ids[s]);
   };
 #pragma unroll
   for (int i = 0; i < RD; ++i) load_ids(i);
@@ -932,7 +959,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
     if (!has[s]) return false;                        // (queries are handed out in increasing order: nothing behind this one)
     // all lanes, full EXEC (v_readlane / DPP read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
     asm volatile("s_nop 4");
-    const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[r], piv_lds, qc[s]);
+    if (COOP) raw[r].collect(row[0], coop_buf, stride, ids[s], lane);
+    const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[COOP ? 0 : r], piv_lds, qc[s]);
     if ((uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) p.d_dist[(size_t)qq[s] * BANG_NBR_STRIDE + lane] = d;
     return true;
   };
@@ -942,7 +970,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? 512 : 1024;   // two long rows in flight need the 256-VGPR budget
+  // two long rows in flight need the 256-VGPR budget; so do the two cooperative fetches of the 4-float layout (8 waves fetch as fast as 16)
+  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2) || (BANG_K2_COOP && PSZ == 4 && NDW >= 8)) ? 512 : 1024;
   static bool attr_done[BANG_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
@@ -954,18 +983,20 @@ static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hi
   const uint32_t waves = MAXT / WAVE;
   uint32_t grid = (p.Q + waves - 1) / waves;
   if (grid > cus) grid = cus;
-  hipLaunchKernelGGL((pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>), dim3(grid), dim3(MAXT), (size_t)piv_floats * 4, st, p, piv_floats);
+  const size_t lds_bytes = (size_t)piv_floats * 4 + (BANG_K2_COOP ? (size_t)waves * CoopFetch<NDW, ALIGNED>::LDS_WORDS * 4 : 0);
+  if (lds_bytes > 160 * 1024) { bang_set_error("K2 streaming form: pivot table + staging exceed LDS"); return BANG_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>), dim3(grid), dim3(MAXT), lds_bytes, st, p, piv_floats);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
 
 template <int PSZ, int NDW>
 static int launch_pqdist_al(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  const bool al = (p.m % 4u) == 0;
+  const bool al = ((p.code_stride ? p.code_stride : p.m) % 4u) == 0;            // rows start dword-aligned
   if (p.pq_nhi) {
     constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
     if constexpr (NHI != 0) {
-      if ((int)p.pq_nhi == NHI && !al) return launch_pqdist_inst<PSZ, NDW, false, NHI>(p, piv_floats, st);
+      if ((int)p.pq_nhi == NHI) return al ? launch_pqdist_inst<PSZ, NDW, true, NHI>(p, piv_floats, st) : launch_pqdist_inst<PSZ, NDW, false, NHI>(p, piv_floats, st);
     }
     bang_set_error("no K2 instance for the exact-size pivot table psz=%u mp=%u nhi=%u", p.psz, p.mp, p.pq_nhi);
     return BANG_ERR_UNSUPPORTED;
@@ -1023,13 +1054,13 @@ static int launch_hd(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
 
 template <int PSZ, int NDW>
 static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  const bool al = (a.p.m % 4u) == 0;
+  const bool al = ((a.p.code_stride ? a.p.code_stride : a.p.m) % 4u) == 0;          // rows start dword-aligned
   if (a.p.pq_nhi) {
     // exact-size pivot table: compiled for the two layouts of the BASELINE configs (128 dims in 70 chunks: 58 x 2 + 12 x 1;
-    // 96 dims in 74 chunks: 22 x 2 + 52 x 1)
+    // 96 dims in 74 chunks: 22 x 2 + 52 x 1), rows packed (m = 70 / 74 bytes apart) or padded to a dword-aligned stride
     constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
     if constexpr (NHI != 0) {
-      if ((int)a.p.pq_nhi == NHI && !al) return launch_hd<PSZ, NDW, false, NHI>(a, grid, block, lds, st);
+      if ((int)a.p.pq_nhi == NHI) return al ? launch_hd<PSZ, NDW, true, NHI>(a, grid, block, lds, st) : launch_hd<PSZ, NDW, false, NHI>(a, grid, block, lds, st);
     }
     bang_set_error("no search-kernel instance for the exact-size pivot table psz=%u mp=%u nhi=%u", a.p.psz, a.p.mp, a.p.pq_nhi);
     return BANG_ERR_UNSUPPORTED;
@@ -1044,11 +1075,12 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
 // keeps its pacing groups' shared words there
 static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx, bool host_paced) {
   const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
-  const size_t per_wave = (size_t)search_wave_words(L, nctx) * 4u;
+  const size_t per_wave = (size_t)search_wave_words(L, nctx, (int)(mp / 4u), host_paced) * 4u;
   const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u);
   if (piv_bytes + per_wave > cap) return 0;
   const size_t w = (cap - piv_bytes) / per_wave;
-  return (uint32_t)(w > 16 ? 16 : w);
+  const size_t most = (size_t)search_maxt((int)(mp / 4u), host_paced) / WAVE;      // what the instance is compiled for
+  return (uint32_t)(w > most ? most : w);
 }
 
 extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
@@ -1109,7 +1141,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   a.nctx = nctx;
   a.gs = gs;
   a.wl_words = search_wl_words(p->L);
-  a.wave_words = search_wave_words(p->L, nctx);
+  a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;

@@ -182,11 +182,11 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
         src = getattr(wl["ix"], "entry_source", None)
         if src is not None:                      # streamed shape index: the engine pulls the generator's entries through in chunks
             import ctypes as C
-            eng.load_stream(wl["ix"], src[0], C.byref(src[1]), d_codes=wl["d_codes"])
+            eng.load_stream(wl["ix"], src[0], C.byref(src[1]), d_codes=wl["d_codes"], code_stride=getattr(wl["ix"], "code_stride", 0))
         elif wl.get("prefix"):
             eng.load(wl["prefix"])               # bang_load on the shared index files (`_disk.bin` streamed or mapped, never copied)
         else:
-            eng.load_index(wl["ix"], d_codes=wl["d_codes"])
+            eng.load_index(wl["ix"], d_codes=wl["d_codes"], code_stride=(getattr(wl["ix"], "code_stride", 0) if wl["d_codes"] else 0))
     if ctx.world > 1 and wl.get("shared_dir"):
         # one copy of the pull rows per node: rank 0 builds the rows file in the shared directory, the others map it
         os.environ["BANG_PULL_ROWS_DIR"] = wl["shared_dir"]
@@ -269,7 +269,7 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         run_once(eng, my_q, ctx, timed=True)
     step_s, init_s, search_s, gather_s = [], [], [], []
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
-                "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull")
+                "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
                fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0)
     agg.update({kk: 0 for kk in keys_max})
@@ -381,7 +381,7 @@ def leg_summary(res, wl, graph, recall=None, props=None, extra=None):
 
 
 # ---------------------------------------------------------------------------------------------------------- K2 alone
-def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, reps=5):
+def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, reps=5, stride=0):
     """The PQ-distance stage (K2, compute_neighborDist_par, bang_search.cu:1201-1241) ALONE: `bang_k_pqdist` over enough
     (query, neighbour) pairs that one launch takes >= 1 ms, on a random code table far larger than the 256 MB Infinity Cache.
     Timed with HIP events on the launch stream.  Algorithmic bytes = evaluations x (m + 8)."""
@@ -389,16 +389,17 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
     from bang_amd import binding as B
     from bang_amd.synth import chunk_offsets
     dev = ctx.dev
-    N = int(table_bytes // m)
+    rb = stride or m                                    # bytes between rows (stride > m: padded rows, e.g. 128 for m = 70)
+    N = int(table_bytes // rb)
     Qk = rows_per_launch // 64
     g = torch.Generator(device=dev)
     g.manual_seed(11)
-    codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
+    codes = torch.empty(N * rb + 256, dtype=torch.uint8, device=dev)
     step = 1 << 28
-    for a in range(0, N * m, step):
-        b = min(N * m, a + step)
+    for a in range(0, N * rb, step):
+        b = min(N * rb, a + step)
         codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
-    codes[N * m:] = 0
+    codes[N * rb:] = 0
     chunk_off = chunk_offsets(D, m)
     psz, mp = B.pq_layout(chunk_off, D, m)
     if psz == 0:
@@ -418,6 +419,7 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
     p = B.IterParams()
     p.Q, p.R, p.m, p.L, p.medoid, p.iter, p.first = Qk, 64, m, 16, 0, 2, 0
     p.psz, p.mp, p.pq_nhi = psz, mp, nhi
+    p.code_stride = stride
     p.d_codes, p.d_pivots_packed, p.d_qc = codes.data_ptr(), packed.data_ptr(), qc.data_ptr()
     p.d_nbrs, p.d_dist, p.d_cnt, p.d_seed = nbrs.data_ptr(), dist_o.data_ptr(), cnt.data_ptr(), seed.data_ptr()
     stream = torch.cuda.current_stream(dev)
@@ -438,7 +440,7 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
     evals = Qk * 64
     ach = evals * (m + 8) / (avg * 1e-6) / 1e9
     out = {"kernel": "pqdist_stream_kernel (K2 alone) via bang_k_pqdist_stream", "m": m, "D": D, "psz_mp": [psz, mp],
-           "code_table_bytes": N * m, "evals_per_launch": evals, "algorithmic_bytes_per_launch": evals * (m + 8),
+           "code_stride": rb, "code_table_bytes": N * rb, "evals_per_launch": evals, "algorithmic_bytes_per_launch": evals * (m + 8),
            "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "achieved": round(ach, 1), "unit": "GB/s",
            "peak": HBM_PEAK_GBPS, "frac": round(ach / HBM_PEAK_GBPS, 4), "rows_per_s": round(evals / (avg * 1e-6) / 1e9, 2),
            "timer": "HIP events on the launch stream"}
@@ -708,7 +710,7 @@ def main():
                "host_loop": host_loop_name(agg, graph),
                "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                                   "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
-               "vector_dtype": ix.dtype, "batches_per_step": args.batches if weak else 1,
+               "vector_dtype": ix.dtype, "pq_code_row_stride_bytes": agg["code_stride"], "batches_per_step": args.batches if weak else 1,
                "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
                "pcie_pulled_bytes_per_step": int(agg["pulled_bytes"] // args.steps),
                "qps_incl_init": res["qps_incl_init"],

@@ -88,10 +88,12 @@ typedef struct {
   uint32_t D, R, N, m;
   const uint8_t* graph;      /* N * entry_len bytes */
   const uint8_t* codes;      /* N * m bytes (host) -- or NULL when d_codes is given */
-  const void* d_codes;       /* optional: codes already on the device (N*m + 256 bytes) */
+  const void* d_codes;       /* optional: codes already on the device (N*m + 256 bytes; N*code_stride + 256 with code_stride != 0) */
   const float* pivots;       /* [256][D] */
   const float* centroid;     /* [D] */
   const uint32_t* chunk_off; /* [m+1] */
+  uint32_t code_stride;      /* d_codes only: bytes between the rows of consecutive nodes, 0 = m (packed).  Host codes are always packed;
+                                the engine lays them out itself (option "code_stride") */
 } bang_index_desc;
 int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* desc);
 
@@ -161,6 +163,7 @@ typedef struct {
   uint64_t graph_pull;        /* host-graph placement: 1 = PULL mode -- the adjacency lists live as 256-byte rows in pinned host memory
                                  and the self-paced search kernel fetches them over PCIe by itself (no walker thread in the loop) */
   uint64_t pulled_bytes;      /* pull mode: bytes of adjacency rows the kernel fetched over PCIe (256 per expansion) */
+  uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
 } bang_stats;
@@ -269,6 +272,8 @@ typedef struct {
   uint32_t done_value;
   uint32_t pq_nhi;                     /* psz == 2 only: exact-size ("ragged") pivot table -- the first pq_nhi chunks have 2 dims, the rest 1
                                           (bang_pack_pivots_ragged); 0 = every chunk padded to psz floats (bang_pack_pivots) */
+  uint32_t code_stride;                /* bytes between the code rows of consecutive nodes in d_codes; 0 = m (the packed layout of
+                                          <p>_pq_compressed.bin).  128 for 64 < m <= 128: a row never leaves its 128-byte line */
 } bang_iter_params;
 
 /* Fused K5 + K2 + K4: neighbor_filtering_new (bang_search.cu:1140-1165) -> compute_neighborDist_par
@@ -325,6 +330,7 @@ typedef struct {
                                           advance independently; pacing group index = (g * groups_per_workgroup + group) * nctx + c */
   unsigned long long* d_prof;          /* diagnostic, host-paced form: [G][8] 100 MHz ticks thread 0 of each workgroup spent {waiting for
                                           rows, in the front half up to the publish barrier, publishing, in sort/merge}, [4] = half-rounds; or NULL */
+  uint32_t code_stride;                /* bytes between code rows in d_codes; 0 = m (see bang_iter_params) */
   unsigned long long go_timeout_ticks; /* host-paced form: a pacing group that has waited this many 100 MHz ticks for its rows sets *d_abort and
                                           leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the

@@ -98,8 +98,10 @@ def test_search_kernel_lds_budget_arithmetic(libbang):
     f.argtypes = [C.c_uint32] * 4
     assert f(4, 32, 0, 70) == 16 and f(4, 32, 0, 152) == 16 and f(4, 32, 0, 200) == 13 and 4 <= f(4, 32, 0, 512) <= 6   # SIFT1M layout: 128 KB table
     assert f(2, 72, 0, 152) < f(2, 72, 58, 152)                    # 128 dims in 70 chunks: padded 144 KB vs exact-size 128 KB
-    assert f(2, 76, 0, 152) <= 4 and f(2, 76, 22, 152) == 16       # 96 dims in 74 chunks: only the exact-size table (96 KB) leaves room
-    assert f(2, 72, 58, 152) == 15                                  # SIFT1B layout at the reference's L: 130 KB table + 15 worklists
+    # long code rows (>= 64 chunks): the self-paced instances are compiled for 12 waves of 168 VGPRs, and every wave keeps a 1 KB
+    # staging area for the cooperative row fetch beside its worklist
+    assert f(2, 76, 0, 152) <= 4 and f(2, 76, 22, 152) == 12       # 96 dims in 74 chunks: only the exact-size table (96 KB) leaves room
+    assert f(2, 72, 58, 152) == 12 and f(2, 72, 58, 200) == 10     # SIFT1B layout: 130 KB table + 12 x (worklist + 1 KB)
     assert f(0, 5, 0, 100) == 0 and f(4, 32, 0, 513) == 0          # LUT path / L beyond MAX_L: no search kernel
     g = libbang.bang_ragged_supported
     g.restype = C.c_int

@@ -199,9 +199,10 @@ def test_search_kernel_alone(request, libbang, fixture, L, ragged):
     assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
 
 
+@pytest.mark.parametrize("stride", [0, 128])
 @pytest.mark.parametrize("fixture,ragged", [("small_f32", False), ("small_u8", False), ("small_u8", True), ("small_deep", True),
                                             ("small_i8", False)])
-def test_pqdist_streaming_form_matches_oracle(request, libbang, fixture, ragged):
+def test_pqdist_streaming_form_matches_oracle(request, libbang, fixture, ragged, stride):
     """bang_k_pqdist_stream (the launch the K2-alone roofline figure is measured on): same canonical float order, bit for bit,
     with ragged neighbour counts (0..64) and more queries than one sweep of the grid's waves handles (the ping-pong loop)."""
     import ctypes as C
@@ -223,6 +224,12 @@ def test_pqdist_streaming_form_matches_oracle(request, libbang, fixture, ragged)
     st.d_cnt.upload(cnt)
     st.d_dist.zero()
     p = st.params()
+    if stride:               # padded code table: rows 128 bytes apart (a row never leaves its line; rows start dword aligned)
+        padded = np.zeros((ix.N, stride), np.uint8)
+        padded[:, : ix.m] = ix.codes
+        padded[:, ix.m:] = 0xA5                                # (whatever lies behind a row must not matter)
+        d_pad = B.DeviceBuffer.from_numpy(padded, slack=256)
+        p.d_codes, p.code_stride = d_pad.ptr, stride
     B._check(B.lib().bang_k_pqdist_stream(C.byref(p), None), "bang_k_pqdist_stream")
     B.sync()
     _, _, dist = st.nbrs()

@@ -19,6 +19,9 @@ VARIANTS = {
     "rev12k64": dict(reverse=True, n_random=12, K=64, probes=8),
     "rev12a1": dict(reverse=True, n_random=12, alpha=1.0),
     "rev24": dict(reverse=True, n_random=24),
+    "r2m70": dict(reverse=False, n_random=32, m=70),
+    "revm70": dict(reverse=True, n_random=12, m=70),
+    "r2m64": dict(reverse=False, n_random=32, m=64),
 }
 
 
@@ -32,10 +35,11 @@ def main():
     Q, k = 10000, 10
     for name in names:
         kw = dict(VARIANTS[name])
+        m = kw.pop("m", 32)
         if kw.get("cells") == -1:
             kw["cells"] = int(max(16, min(8192, round((N ** 0.5) / 1.5))))
         t0 = time.time()
-        ix, q, gt_i, gt_d = index_build.make_index_large(N, 128, "uint8", 64, 32, Q, K=k, n_clusters=max(256, N // 10000), device="cuda",
+        ix, q, gt_i, gt_d = index_build.make_index_large(N, 128, "uint8", 64, m, Q, K=k, n_clusters=max(256, N // 10000), device="cuda",
                                                          log=lambda *a: print(*a, flush=True), **kw)
         tb = time.time() - t0
         deg = ix.degrees()

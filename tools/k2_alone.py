@@ -77,8 +77,8 @@ def big():
     ctx.dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     out = []
-    for D, m, dt in ((128, 32, "uint8"), (128, 70, "uint8"), (96, 74, "float")):
-        r = bench.k2_alone(D, m, dt, ctx, reps=10)
+    for D, m, dt, stride in ((128, 32, "uint8", 0), (128, 70, "uint8", 0), (128, 70, "uint8", 128), (96, 74, "float", 0), (96, 74, "float", 128)):
+        r = bench.k2_alone(D, m, dt, ctx, reps=10, stride=stride)
         out.append(r)
         print(json.dumps(r), flush=True)
     return out

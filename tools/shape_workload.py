@@ -95,6 +95,14 @@ def usable_host_bytes() -> int:
 PULL_ROW_BYTES = 256       # host-graph placement, pull mode: the engine keeps the adjacency lists a second time as 256-byte rows
 
 
+CODE_STRIDE = {"sift1b_shape": 128, "deep100m_shape": 128}   # device-generated code tables: rows padded to their own 128-byte line
+
+
+def code_stride(name) -> int:
+    s = int(os.environ.get("BANG_SHAPE_CODE_STRIDE", "-1"))
+    return CODE_STRIDE[name] if s < 0 else (s or SHAPES[name]["m"])
+
+
 def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False):
     """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything."""
     import torch
@@ -104,12 +112,12 @@ def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False):
     N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
     if sh["graph"] == "host" and stream:
         free, _ = torch.cuda.mem_get_info(dev)
-        N = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (sh["D"] * isz + sh["m"]))
+        N = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (sh["D"] * isz + code_stride(name)))
     elif sh["graph"] == "host":
         N = min(N, int(usable_host_bytes() * 0.75) // (entry + (PULL_ROW_BYTES if reserve_rows else 0)))
     else:
         free, _ = torch.cuda.mem_get_info(dev)
-        N = min(N, (int(free * 0.85) - (8 << 30)) // (entry + sh["m"]), int(usable_host_bytes() * 0.75) // entry)
+        N = min(N, (int(free * 0.85) - (8 << 30)) // (entry + code_stride(name)), int(usable_host_bytes() * 0.75) // entry)
     return int(N)
 
 
@@ -135,6 +143,7 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     sh = dict(SHAPES[name])
     isz = 4 if sh["dtype"] == "float" else 1
     D, R, m = sh["D"], sh["R"], sh["m"]
+    cs = m if host_codes else code_stride(name)              # bytes between the rows of the device-generated code table
     entry = D * isz + 4 + 4 * R
     N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
     lib = _lib()
@@ -148,7 +157,7 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         # STREAMED: the graph image never exists -- the engine pulls the generator's entries through in chunks (vectors -> HBM,
         # adjacency lists -> 256-byte pull rows in host memory).  Host budget: the rows; HBM budget: codes + vectors + 28 GB.
         free, _total = torch.cuda.mem_get_info(dev)
-        N2 = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (D * isz + m))
+        N2 = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (D * isz + cs))
         if N2 < N:
             note = (f" (N scaled {N} -> {N2}: {PULL_ROW_BYTES}-byte pull rows in 75 % of the host memory of the box, "
                     f"vectors + codes in HBM)")
@@ -164,8 +173,8 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     else:
         free, _total = torch.cuda.mem_get_info(dev)
         budget = int(free * 0.85) - (8 << 30)
-        if N * (entry + m) > budget:
-            N2 = budget // (entry + m)
+        if N * (entry + cs) > budget:
+            N2 = budget // (entry + cs)
             note = f" (N scaled {N} -> {N2}: HBM budget {budget / 2**30:.0f} GiB)"
             N = N2
         host_budget = int(usable_host_bytes() * 0.75)
@@ -212,16 +221,16 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         codes = None
         log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated in host memory in {time.time() - t0:.1f}s")
     else:                               # PQ codes straight on the device
-        codes = torch.empty(N * m + 256, dtype=torch.uint8, device=dev)
+        codes = torch.empty(N * cs + 256, dtype=torch.uint8, device=dev)       # (uniform random bytes: the padding behind a row too)
         step = 1 << 28
         g = torch.Generator(device=dev)
         g.manual_seed(seed + 7)
-        for a in range(0, N * m, step):
-            b = min(N * m, a + step)
+        for a in range(0, N * cs, step):
+            b = min(N * cs, a + step)
             codes[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=dev, generator=g)
-        codes[N * m:] = 0
+        codes[N * cs:] = 0
         torch.cuda.synchronize()
-        log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated on the device in {time.time() - t0:.1f}s")
+        log(f"[shape] {N * cs / 2**30:.1f} GiB of PQ codes (rows {cs} bytes apart) generated on the device in {time.time() - t0:.1f}s")
     rng = np.random.default_rng(seed + 1)
     scale = 40.0 if sh["dtype"] == "uint8" else 0.5
     pivots = (rng.standard_normal((256, D)) * scale).astype(np.float32)
@@ -233,14 +242,14 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
     ix = ShapeIndex(dtype=sh["dtype"], N=N, D=D, R=R, m=m, medoid=int(N // 2), graph=graph,
                     codes=codes_host if host_codes else np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
                     chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib, _cptr=cptr, _cbytes=N * m,
-                    entry_source=((lib.shape_entry_source, source) if stream else None))
+                    entry_source=((lib.shape_entry_source, source) if stream else None), code_stride=(0 if host_codes else cs))
     if stream:
         name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, STREAMED load: adjacency lists "
                   f"{N * PULL_ROW_BYTES / 1e9:.0f} GB as pull rows in host RAM, vectors {N * D * isz / 1e9:.0f} GB + codes "
-                  f"{N * m / 1e9:.0f} GB in HBM{note}")
+                  f"{N * cs / 1e9:.0f} GB ({cs} B per row) in HBM{note}")
     else:
         name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
-                  f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * m / 1e9:.0f} GB in HBM{note}")
+                  f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * cs / 1e9:.0f} GB ({cs} B per row) in HBM{note}")
     return ix, queries, None, None, (codes.data_ptr() if codes is not None else None), name_s, sh["graph"]
 
 
