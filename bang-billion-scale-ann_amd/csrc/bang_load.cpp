@@ -536,12 +536,22 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       for (size_t off = 0; off < code_bytes; off += step)
         HIP_TRY(hipMemcpy(e->d_codes + off, h_codes + off, std::min(step, code_bytes - off), hipMemcpyHostToDevice));
     } else {
+      // packed chunks go up as they are (one contiguous copy each) and are spread to the row stride ON the device (a pitched
+      // host-to-device copy of 70-byte rows moves a row at a time)
       HIP_TRY(hipMemset(e->d_codes, 0, code_bytes + 256));
-      const size_t rows_per = std::max<size_t>(1, ((size_t)1 << 30) / m);
+      const size_t rows_per = std::max<size_t>(1, ((size_t)256 << 20) / m);
+      uint8_t* d_tmp = nullptr;
+      HIP_TRY(hipMalloc((void**)&d_tmp, rows_per * m));
       for (size_t r0 = 0; r0 < e->N; r0 += rows_per) {
         const size_t nr = std::min(rows_per, (size_t)e->N - r0);
-        HIP_TRY(hipMemcpy2D(e->d_codes + r0 * stride, stride, h_codes + r0 * m, m, m, nr, hipMemcpyHostToDevice));
+        if (hipMemcpy(d_tmp, h_codes + r0 * m, nr * m, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy2D(e->d_codes + r0 * stride, stride, d_tmp, m, m, nr, hipMemcpyDeviceToDevice) != hipSuccess) {
+          (void)hipFree(d_tmp);
+          bang_set_error("PQ code upload failed: %s", hipGetErrorString(hipGetLastError()));
+          return BANG_ERR_HIP;
+        }
       }
+      (void)hipFree(d_tmp);
     }
   }
   // Placement.  HBM left after the PQ codes decides: the whole graph (adjacency + vectors) if it fits with 16 GB to spare for

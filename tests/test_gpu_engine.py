@@ -662,3 +662,46 @@ def test_host_paced_hand_shake_failure_is_reported_and_survivable(libbang, small
             e.set_option("kernel_go_timeout_ms", 1)              # out of range
         e.free()
         e.unload()
+
+
+@pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
+def test_code_row_stride_does_not_change_results(request, libbang, fixture):
+    """Option code_stride: the PQ code rows in HBM packed as in the file (0), padded by the engine (auto: 70 / 74 -> 128; 32 stays), or
+    at an explicit stride (dword aligned or not) -- and a caller's own padded device table -- all return the oracle's answer in every
+    loop form."""
+    import bang_amd
+    from bang_amd import binding as B
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q, k, L = q.shape[0], 10, 40
+    ids_o, dists_o = O.Oracle(ix).search(q, k, L)
+    want_auto = 128 if ix.m > 64 else ix.m
+
+    def run(**opts):
+        d_codes = opts.pop("d_codes", None)
+        ext_stride = opts.pop("ext_stride", 0)
+        with bang_amd.Engine(ix.dtype, **opts) as e:
+            e.load_index(ix, d_codes=d_codes, code_stride=ext_stride)
+            e.set_searchparams(k, L)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+            e.free()
+            e.unload()
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), opts
+        return st
+    for graph in (0, 1):
+        assert run(graph=graph)["code_stride"] == want_auto
+        assert run(graph=graph, code_stride=0)["code_stride"] == ix.m
+        assert run(graph=graph, code_stride=ix.m + 3)["code_stride"] == ix.m + 3
+    assert run(graph=0, pull=0, code_stride=128)["code_stride"] == 128                # host-paced search kernel
+    assert run(graph=0, persistent=0, code_stride=128)["code_stride"] == 128          # a launch per iteration
+    assert run(graph=1, search=0, code_stride=128)["code_stride"] == 128
+    padded = np.full((ix.N, 256), 0x5A, np.uint8)
+    padded[:, : ix.m] = ix.codes
+    buf = B.DeviceBuffer.from_numpy(padded, slack=256)
+    assert run(graph=1, d_codes=buf.ptr, ext_stride=256)["code_stride"] == 256         # the caller's layout is taken as it is
+    buf.free()
+    with pytest.raises(bang_amd.BangError):
+        run(graph=1, code_stride=ix.m - 1)
