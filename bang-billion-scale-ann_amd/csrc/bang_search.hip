@@ -50,7 +50,10 @@ struct SearchArgs {
 #endif
 // The cooperative fetch pays from three 16-byte pieces per row on (rows of 12+ code dwords, m > 44): two-piece rows (m = 32) gain
 // nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging area.
-__host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return !host_paced && BANG_SEARCH_COOP && ndw >= 12; }
+#ifndef BANG_HOST_FULL
+#define BANG_HOST_FULL 1            // host-paced instances of the long-row layouts: 12 waves x 168 VGPRs, with filter summary + cooperative fetch
+#endif
+__host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return BANG_SEARCH_COOP && ndw >= 12 && (!host_paced || (BANG_HOST_FULL && ndw >= 16)); }
 // per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both, and so does the staging area
 // of the cooperative code-row fetch (256 words: one wave instruction's worth of 16-byte pieces)
 __host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) { return search_coop(ndw, host_paced) ? 256u : 144u; }
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     }
   };
   // which words of the current query's filter have been stored to (self-paced form; the host-paced instances have no registers to spare)
-  constexpr bool SUMM = !HOST && (BANG_FILTER_SUMMARY != 0);
+  constexpr bool SUMM = (BANG_FILTER_SUMMARY != 0) && (!HOST || search_maxt(NDW, HOST) < 1024);   // (needs 6 VGPRs the 16-wave host-paced instances do not have)
   FilterSummary summ;
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qstats2): filter words not loaded thanks to the summary
@@ -665,8 +668,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      if (COOP) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-      else if (EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
+      if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
+        if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
         if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if ((uint32_t)lane < n) {
           if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
@@ -1100,6 +1104,7 @@ extern "C" int bang_search_geometry(uint32_t psz, uint32_t mp, uint32_t nhi, uin
   if (!host_paced) nctx = 1;
   else if (nctx == 0) nctx = 1;     // two contexts per wave measured slower (more, emptier half-rounds): kept as an experiment knob
   else if (nctx > 2) nctx = 2;
+  if (host_paced && search_maxt((int)(mp / 4u), true) < 1024) nctx = 1;       // (the filter summary lives in registers: one query per wave)
   uint32_t waves = waves_that_fit(psz, mp, nhi, L, nctx, host_paced != 0);
   if (waves == 0) { bang_set_error("pivot table + one wave's worklist do not fit LDS at L=%u", L); return BANG_ERR_UNSUPPORTED; }
   if (max_waves && max_waves < waves) waves = max_waves;

@@ -699,6 +699,7 @@ def main():
     ix = prim["wl"]["ix"]
     ids_primary = res["ids"]
     m_primary, D_primary, dtype_primary = ix.m, ix.D, ix.dtype
+    stride_primary = int(agg["code_stride"]) or ix.m           # the code-row layout the engine searched (K2 alone is measured on the same)
     out, cfg = None, {}
     if rank == 0:
         recall = prim["recall"]
@@ -753,7 +754,7 @@ def main():
     k2 = {}
     if leg_on("k2") and out is not None and out["roofline"] is not None:
         try:
-            k2[f"m{m_primary}"] = k2_alone(D_primary, m_primary, dtype_primary, ctx)
+            k2[f"m{m_primary}"] = k2_alone(D_primary, m_primary, dtype_primary, ctx, reps=10, stride=(stride_primary if stride_primary != m_primary else 0))
             out["roofline"]["k2_alone"] = k2[f"m{m_primary}"]
             cfg["k2_alone_frac"] = k2[f"m{m_primary}"]["frac"]
             cfg["k2_alone_GBps"] = k2[f"m{m_primary}"]["achieved"]
@@ -821,8 +822,9 @@ def main():
             flat(cfg, "deep100m_shape", cfg["at_deep100m_shape"])
             ixd = r["wl"]["ix"]
             mm, DD, dt = ixd.m, ixd.D, ixd.dtype
+            cs_d = int(r["res"]["agg"]["code_stride"]) or mm
             release_config(r)
-            k2[f"m{mm}"] = k2_alone(DD, mm, dt, ctx)
+            k2[f"m{mm}"] = k2_alone(DD, mm, dt, ctx, stride=(cs_d if cs_d != mm else 0))
         guarded("at_deep100m_shape", leg_deep)
 
     if leg_on("sift1b") and args.workload != "sift1b_shape":
