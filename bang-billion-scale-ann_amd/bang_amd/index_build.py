@@ -53,64 +53,112 @@ def _assign(x: torch.Tensor, cen: torch.Tensor, block: int = 1 << 18) -> torch.T
     return out
 
 
-def partition(x: torch.Tensor, cell: int, g: torch.Generator):
-    """Two-level k-means partition into cells of ~`cell` points.  Returns (labels int64 [N], centroids f32 [C, D]).
-    One level of C ~ N / cell centroids would cost an [N x C] distance matrix (N = 1e8: 5e12 entries); two levels cost
+class Partition:
+    """A two-level k-means partition: `order` lists the points cell by cell (cells of one top-level cell are consecutive), cell c
+    owns order[starts[c] : starts[c] + counts[c]], `near` [C, n] are each cell's nearest cells (itself first), cell c belongs to
+    top-level cell top_of[c], top-level cell t owns order[tstarts[t] : tstarts[t] + tcounts[t]], `tnear` its nearest top cells."""
+    pass
+
+
+def partition(x: torch.Tensor, cell: int, g: torch.Generator, n_near: int = 64, cells: int = 0) -> Partition:
+    """One level of C ~ N / cell centroids would cost an [N x C] distance matrix (N = 1e8: 5e12 entries); two levels cost
     N x (C1 + C2) with C1 ~ C2 ~ sqrt(C)."""
     N = x.shape[0]
-    C = max(1, int(round(N / cell)))
+    dev = x.device
+    C = cells or max(1, int(round(N / cell)))
+    P = Partition()
     if C <= 1024:
         cen = _kmeans(x, max(1, min(C, N)), 6, g)
-        return _assign(x, cen), cen
-    C1 = int(max(16, min(1024, round(C ** 0.5))))
-    cen1 = _kmeans(x, C1, 6, g)
-    lab1 = _assign(x, cen1)
-    order = torch.argsort(lab1, stable=True)
-    counts = torch.bincount(lab1, minlength=C1).tolist()
-    labels = torch.empty(N, dtype=torch.int64, device=x.device)
-    cens, base, a = [], 0, 0
-    for c in range(C1):
-        n = counts[c]
-        if n == 0:
-            continue
-        rows = order[a:a + n]
-        a += n
-        k = max(1, min(int(round(n / cell)), n))
-        xs = x[rows]
-        cen = _kmeans(xs, k, 4, g, sample=65536)
-        labels[rows] = _assign(xs, cen) + base
-        cens.append(cen)
-        base += k
-    return labels, torch.cat(cens)
+        lab = _assign(x, cen)
+        top_of = torch.zeros(cen.shape[0], dtype=torch.int64, device=dev)
+        cen1 = cen.mean(0, keepdim=True)
+    else:
+        C1 = int(max(16, min(1024, round(C ** 0.5))))
+        cen1 = _kmeans(x, C1, 6, g)
+        lab1 = _assign(x, cen1)
+        order1 = torch.argsort(lab1, stable=True)
+        counts1 = torch.bincount(lab1, minlength=C1).tolist()
+        lab = torch.empty(N, dtype=torch.int64, device=dev)
+        cens, tops, base, a = [], [], 0, 0
+        for c in range(C1):
+            n = counts1[c]
+            if n == 0:
+                continue
+            rows = order1[a:a + n]
+            a += n
+            k = max(1, min(int(round(n / cell)), n))
+            xs = x[rows]
+            cen_c = _kmeans(xs, k, 4, g, sample=65536)
+            lab[rows] = _assign(xs, cen_c) + base
+            cens.append(cen_c)
+            tops.append(torch.full((k,), c, dtype=torch.int64, device=dev))
+            base += k
+        cen = torch.cat(cens)
+        top_of = torch.cat(tops)
+        del lab1, order1
+    Cn = cen.shape[0]
+    P.C, P.cen, P.lab, P.top_of = Cn, cen, lab, top_of
+    P.order = torch.argsort(lab, stable=True)
+    P.counts = torch.bincount(lab, minlength=Cn)
+    P.starts = torch.cumsum(P.counts, 0) - P.counts
+    nn = min(n_near, Cn)
+    P.near = torch.empty((Cn, nn), dtype=torch.int64, device=dev)
+    for a in range(0, Cn, 4096):                                                   # self first
+        P.near[a:a + 4096] = torch.topk(torch.cdist(cen[a:a + 4096], cen), nn, dim=1, largest=False).indices
+    T = cen1.shape[0]
+    P.T = T
+    P.tcounts = torch.zeros(T, dtype=torch.int64, device=dev).index_add_(0, top_of, P.counts)
+    P.tstarts = torch.cumsum(P.tcounts, 0) - P.tcounts
+    P.tnear = torch.topk(torch.cdist(cen1, cen1), min(16, T), dim=1, largest=False).indices
+    return P
+
+
+def smallworld_links(P: Partition, first: int, count: int, n_links: int, N: int, g: torch.Generator) -> torch.Tensor:
+    """Long-range links for the points [first, first + count): n_links targets per point drawn SCALE-uniformly -- link j picks one of
+    seven nested neighbourhoods of its point (its 4 / 16 / 64 nearest cells, its top-level cell, the 4 / 16 nearest top-level cells,
+    everything) and a uniformly random member of it.  Equal link mass per distance scale is what makes greedy routing short
+    (Kleinberg's small-world construction; Vamana gets such edges from greedy-search paths while it inserts points): uniform random
+    links alone leave a 1e8-point graph with nothing between 'anywhere' and 'the next 48 neighbours'."""
+    dev = P.order.device
+    cells = P.lab[first:first + count]                                            # [B]
+    tops = P.top_of[cells]
+    B = count
+    out = torch.empty((B, n_links), dtype=torch.int64, device=dev)
+    u = torch.rand((B, n_links, 2), generator=g, device=dev)
+    nn, nt = P.near.shape[1], P.tnear.shape[1]
+    for j in range(n_links):
+        sc = j % 7
+        if sc < 3:                                                                 # among the 4 / 16 / 64 nearest cells
+            width = min(nn, 4 ** (sc + 1))
+            tc = P.near[cells, (u[:, j, 0] * width).long().clamp_(max=width - 1)]
+            out[:, j] = P.order[P.starts[tc] + (u[:, j, 1] * P.counts[tc]).long().minimum(P.counts[tc] - 1).clamp_min_(0)]
+        elif sc < 6:                                                               # own top-level cell, 4 / 16 nearest top-level cells
+            width = min(nt, 4 ** (sc - 3))
+            tt = P.tnear[tops, (u[:, j, 0] * width).long().clamp_(max=width - 1)]
+            out[:, j] = P.order[P.tstarts[tt] + (u[:, j, 1] * P.tcounts[tt]).long().minimum(P.tcounts[tt] - 1).clamp_min_(0)]
+        else:
+            out[:, j] = (u[:, j, 1] * N).long().clamp_(max=N - 1)
+    return out
 
 
 def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = synth.SEED, cells: int = 0, log=None, cell: int = 2048,
-                         idx_dtype=torch.int64):
+                         idx_dtype=torch.int64, want_partition: bool = False, select: str = "topk"):
     """Approximate K nearest neighbours of every point (excluding itself) through a coarse partition.
-    Returns (ids [N, K] of idx_dtype, squared distances f32 [N, K]) sorted ascending.  x may be f32 or (exact for 8-bit data) bf16."""
+    Returns (ids [N, K] of idx_dtype, squared distances f32 [N, K]) sorted ascending (+ the Partition if asked for).
+    x may be f32 or (exact for 8-bit data) bf16."""
     N, D = x.shape
     dev = x.device
     g = synth._gen(seed + 11, dev)
     t0 = time.time()
-    if cells:
-        cen = _kmeans(x, cells, 6, g)
-        lab = _assign(x, cen)
-    else:
-        lab, cen = partition(x, cell, g)
-    C = cen.shape[0]
-    order = torch.argsort(lab, stable=True)
-    counts = torch.bincount(lab, minlength=C)
-    del lab
-    starts = torch.cumsum(counts, 0) - counts
-    near = torch.empty((C, min(probes, C)), dtype=torch.int64, device=dev)
-    for a in range(0, C, 4096):                                                   # [C, probes], self first
-        near[a:a + 4096] = torch.topk(torch.cdist(cen[a:a + 4096], cen), min(probes, C), dim=1, largest=False).indices
+    P = partition(x, cell, g, cells=cells)
+    C = P.C
+    order = P.order
     if log:
         log(f"[build] partition: {C} cells of ~{N // max(1, C)} points in {time.time() - t0:.1f}s")
     xn = (x.float() * x.float()).sum(1) if x.dtype == torch.float32 else torch.cat([(x[a:a + (1 << 22)].float() ** 2).sum(1) for a in range(0, N, 1 << 22)])
     out_i = torch.empty((N, K), dtype=idx_dtype, device=dev)
     out_d = torch.empty((N, K), dtype=torch.float32, device=dev)
-    starts_h, counts_h, near_h = starts.tolist(), counts.tolist(), near.tolist()
+    starts_h, counts_h, near_h = P.starts.tolist(), P.counts.tolist(), P.near[:, :probes].tolist()
     t0 = time.time()
     step = max(512, C // 8)
     for c in range(C):
@@ -121,21 +169,37 @@ def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = s
         if cand.shape[0] <= K:                                   # tiny neighbourhood: widen to a random sample
             extra = torch.randint(0, N, (4 * K,), generator=g, device=dev)
             cand = torch.unique(torch.cat([cand, extra]))
-        xc = x[cand]
-        xnc = xn[cand]
+        xc = x[cand].float().T.contiguous()                      # (bfloat16 is the STORAGE type of 8-bit data: a bf16 x bf16 product
+        xnc = xn[cand]                                           # would come back rounded to bf16 -- the arithmetic is f32, exact)
         for a in range(0, rows.shape[0], 8192):                  # bound the distance tile
             r = rows[a:a + 8192]
-            d = xn[r][:, None] + xnc[None, :] - 2.0 * (x[r] @ xc.T).float()
-            d.masked_fill_(r[:, None] == cand[None, :], float("inf"))
-            dd, ii = torch.topk(d, K, dim=1, largest=False)
+            d = torch.addmm(xnc[None, :], x[r].float(), xc, alpha=-2.0).add_(xn[r][:, None])
+            if select == "topk":
+                d.masked_fill_(r[:, None] == cand[None, :], float("inf"))
+                dd, ii = torch.topk(d, K, dim=1, largest=False)
+            else:
+                # "groupmin": the candidates are dealt round-robin into G = 2K groups and every group keeps its nearest member: ONE
+                # pass over the distance tile instead of a top-k selection (3x faster at 12 K candidates).  The K nearest of those
+                # 2K winners are the point's candidates: a true near neighbour is lost only when a nearer one sits in its group
+                # (~5 % of the ten nearest), and the robust prune drops half the list anyway.
+                G = 2 * K
+                nc = d.shape[1]
+                npad = (nc + G - 1) // G * G
+                if npad != nc:
+                    d = torch.cat([d, torch.full((d.shape[0], npad - nc), float("inf"), device=dev)], 1)
+                gv, ga = d.view(d.shape[0], npad // G, G).min(dim=1)                     # [rows, G]
+                gi = (ga * G + torch.arange(G, device=dev)[None, :]).clamp_(max=nc - 1)
+                gv = torch.where(cand[gi] == r[:, None], torch.full_like(gv, float("inf")), gv)   # (the point itself won its group)
+                dd, o = torch.sort(gv, dim=1)
+                dd, ii = dd[:, :K], torch.gather(gi, 1, o[:, :K])
             out_i[r] = cand[ii].to(idx_dtype)
             out_d[r] = dd.clamp_min_(0.0)
         if log and (c + 1) % step == 0:
             log(f"[build] candidate search: cell {c + 1}/{C} ({time.time() - t0:.1f}s)")
-    return out_i, out_d
+    return (out_i, out_d, P) if want_partition else (out_i, out_d)
 
 
-def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, keep: int, alpha: float = 1.2, block: int = 32768):
+def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, keep: int, alpha: float = 1.2, block: int = 65536):
     """DiskANN / Vamana robust prune, batched.  cand_* [N, K] sorted ascending by distance to the point (padding: distance +inf).
     Walks the list in order; a candidate that is still alive is KEPT and kills every later candidate c with
     alpha * d(kept, c) <= d(point, c) (distances, not squares: the comparison is done as alpha^2 * d2 <= d2').
@@ -146,9 +210,9 @@ def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, ke
     for s in range(0, N, block):
         ci = cand_i[s:s + block].long()
         dp = cand_d[s:s + block]                                  # d2(point, c)
-        v = x[ci.clamp_min(0)]                                    # [B, K, D]
-        n2 = (v.float() * v.float()).sum(2)
-        dcc = (n2[:, :, None] + n2[:, None, :] - 2.0 * torch.bmm(v, v.transpose(1, 2)).float()).clamp_min_(0.0)   # [B, K, K] d2(c_i, c_j)
+        v = x[ci.clamp_min(0)].float()                            # [B, K, D]
+        n2 = (v * v).sum(2)
+        dcc = torch.baddbmm(n2[:, None, :], v, v.transpose(1, 2), alpha=-2.0).add_(n2[:, :, None]).clamp_min_(0.0)   # [B, K, K] d2(c_i, c_j)
         del v
         alive = torch.isfinite(dp)
         kept = torch.zeros_like(alive)
@@ -221,14 +285,16 @@ def _compact_kept(ci: torch.Tensor, cd: torch.Tensor, kept: torch.Tensor, width:
 
 
 def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None,
-                      reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64):
+                      reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64,
+                      links: str = "smallworld", select: str = "topk"):
     """(degrees int64 [N], adjacency [N, R] of idx_dtype): robust-pruned near neighbours (two passes with reverse edges in
     between; at most R - n_random of them) + random long-range links up to R, distinct, != self, sorted ascending; the tail of a
     short row is 0.  reverse=False, n_random=R//2: the one-pass builder of round 2."""
     N = x.shape[0]
     dev = x.device
     t0 = time.time()
-    ci, cd = candidate_neighbours(x, K, probes=probes, seed=seed, log=log, cell=cell, cells=cells, idx_dtype=idx_dtype)
+    ci, cd, P = candidate_neighbours(x, K, probes=probes, seed=seed, log=log, cell=cell, cells=cells, idx_dtype=idx_dtype, want_partition=True,
+                                     select=select)
     if log:
         log(f"[build] {K} candidate neighbours per point in {time.time() - t0:.1f}s")
     t0 = time.time()
@@ -255,7 +321,7 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
     for s in range(0, N, 1 << 20):                               # per row: the near neighbours, then random links; R entries in all
         near = near_i[s:s + (1 << 20)].long()
         B = near.shape[0]
-        rnd = torch.randint(0, N, (B, R), generator=g, device=dev)
+        rnd = smallworld_links(P, s, B, R, N, g) if links == "smallworld" else torch.randint(0, N, (B, R), generator=g, device=dev)
         n_n = (near >= 0).sum(1, keepdim=True)
         col = torch.arange(R, device=dev)[None, :]
         pad = torch.full((B, R - W), -1, dtype=torch.int64, device=dev)
@@ -274,14 +340,28 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
     return deg_out, adj_out
 
 
-def pack_graph_device(x: torch.Tensor, dtype: str, deg: torch.Tensor, adj: torch.Tensor, block: int = 1 << 21) -> np.ndarray:
+def pack_graph_device(x: torch.Tensor, dtype: str, deg: torch.Tensor, adj: torch.Tensor, block: int = 1 << 20) -> np.ndarray:
     """formats.pack_graph for a large index: the [T vec[D]][u32 degree][u32 id x R] entries are assembled on the device block by
-    block and land in ONE host array (N x entryLen bytes: 38.8 GB for 1e8 SIFT-like points) -- no [N, R] int64 host copies."""
+    block and land in ONE host array (N x entryLen bytes: 38.8 GB for 1e8 SIFT-like points) -- no [N, R] int64 host copies.  The
+    blocks come down into pinned buffers (asynchronously, two in flight) and a few threads move them into the array."""
+    from concurrent.futures import ThreadPoolExecutor
     N, D = x.shape
     R = adj.shape[1]
     isz = 4 if dtype == "float" else 1
     el = D * isz + 4 + 4 * R
     out = np.empty((N, el), dtype=np.uint8)
+    cuda = x.is_cuda
+    nbuf = 4
+    pins = [torch.empty((block, el), dtype=torch.uint8, pin_memory=True) for _ in range(nbuf)] if cuda else None
+    events = [None] * nbuf
+    pool = ThreadPoolExecutor(max_workers=nbuf)
+    pending = [None] * nbuf
+
+    def drain(i, s, B):
+        events[i].synchronize()
+        np.copyto(out[s:s + B], pins[i][:B].numpy())
+
+    k = 0
     for s in range(0, N, block):
         xb = x[s:s + block]
         B = xb.shape[0]
@@ -293,28 +373,61 @@ def pack_graph_device(x: torch.Tensor, dtype: str, deg: torch.Tensor, adj: torch
             vec = xb.to(torch.int8).view(torch.uint8)
         d32 = deg[s:s + B].to(torch.int32).contiguous().view(torch.uint8).view(B, 4)
         a32 = adj[s:s + B].to(torch.int32).contiguous().view(torch.uint8).view(B, 4 * R)
-        out[s:s + B] = torch.cat([vec, d32, a32], 1).cpu().numpy()
+        ent = torch.cat([vec, d32, a32], 1)
+        if not cuda:
+            out[s:s + B] = ent.numpy()
+            continue
+        i = k % nbuf
+        if pending[i] is not None:
+            pending[i].result()
+        pins[i][:B].copy_(ent, non_blocking=True)
+        events[i] = torch.cuda.Event()
+        events[i].record()
+        pending[i] = pool.submit(drain, i, s, B)
+        k += 1
+    for f in pending:
+        if f is not None:
+            f.result()
+    pool.shutdown()
     return out
 
 
+def graph_coverage(x: torch.Tensor, deg: torch.Tensor, adj: torch.Tensor, k: int = 10, sample: int = 2000, seed: int = 1) -> float:
+    """Diagnostic: the share of the true k nearest neighbours of `sample` random points that their adjacency lists contain."""
+    g = synth._gen(seed, x.device)
+    pick = torch.randint(0, x.shape[0], (sample,), generator=g, device=x.device)
+    ti, _ = synth.knn(x, x[pick].float(), k + 1, row_block=1024)
+    hit = 0
+    for r in range(sample):
+        p = int(pick[r])
+        true = [t for t in ti[r].tolist() if t != p][:k]
+        row = set(adj[p, : int(deg[p])].tolist())
+        hit += sum(1 for t in true if t in row)
+    return hit / (sample * k)
+
+
 def make_index_large(N: int, D: int, dtype: str, R: int, m: int, Q: int, K: int = 10, n_clusters: int = 1024,
-                     seed: int = synth.SEED, device="cuda", pq_iters: int = 6, log=None, **graph_kw):
+                     seed: int = synth.SEED, device="cuda", pq_iters: int = 6, log=None, diag: bool = False, noise: float = 2.0, **graph_kw):
     """A structured index of N >= a few million points with brute-force ground truth for Q queries.
     Returns (Index, queries np [Q, D], gt_ids np u32 [Q, K], gt_dists np f32 [Q, K])."""
     t0 = time.time()
     big = N > 20_000_000
-    x = synth.make_vectors(N, D, dtype, n_clusters=n_clusters, seed=seed, device=device, out_dtype=(torch.bfloat16 if dtype != "float" and str(device).startswith("cuda") else None))
+    x = synth.make_vectors(N, D, dtype, n_clusters=n_clusters, seed=seed, device=device, noise=noise,
+                           out_dtype=(torch.bfloat16 if dtype != "float" and str(device).startswith("cuda") else None))
     if log:
         log(f"[build] {N} vectors generated in {time.time() - t0:.1f}s")
     deg, adj = build_graph_large(x, R, seed=seed, log=log, idx_dtype=(torch.int32 if big else torch.int64), **graph_kw)
     medoid = synth.medoid_of(x)
+    if diag and log:
+        t1 = time.time()
+        log(f"[build] the adjacency lists hold {100 * graph_coverage(x, deg, adj):.1f}% of the true 10-NN of 2000 sampled points ({time.time() - t1:.1f}s)")
     t1 = time.time()
     pivots, centroid, off, codes = synth.train_pq(x, m, iters=pq_iters, seed=seed)
     if log:
         log(f"[build] PQ: {m} chunks trained and {N} points encoded in {time.time() - t1:.1f}s")
     q = synth.make_queries(x, Q, dtype, seed=seed)
     t1 = time.time()
-    gt_i, gt_d = synth.knn(x, q.to(x.dtype), K, row_block=2048)
+    gt_i, gt_d = synth.knn_big(x, q, K) if big else synth.knn(x, q.to(x.dtype), K, row_block=2048)
     if log:
         log(f"[build] brute-force ground truth for {Q} queries in {time.time() - t1:.1f}s")
     t1 = time.time()

@@ -138,6 +138,48 @@ def knn(base: torch.Tensor, queries: torch.Tensor, k: int, exclude_self: bool = 
     return torch.cat(out_i), torch.cat(out_d)
 
 
+def knn_big(base: torch.Tensor, queries: torch.Tensor, k: int, col_block: int = 65536, group: int = 256):
+    """Exact k nearest neighbours of a few thousand queries among up to 1e8+ base rows (ground truth of the 100 M index) without a
+    top-k over every distance tile: a tile [Q, col_block] is viewed as [Q, col_block / group, group]; the k groups with the smallest
+    minima contain the tile's k nearest (a group holding one of them has a minimum <= the k-th smallest value, and at most k groups
+    do), so one min-reduction + a top-k over 256 group minima + a top-k over k x group gathered values replace the big selection.
+    The shortlisted ids are re-evaluated exactly and ordered by (distance, id) like knn()."""
+    Nb, D = base.shape
+    dev = base.device
+    q = queries.float()
+    Q = q.shape[0]
+    qn = _sq_norms(q)
+    ci_all, ar = [], torch.arange(group, device=dev)
+    for c0 in range(0, Nb, col_block):
+        b = base[c0:c0 + col_block].float()
+        nb = b.shape[0]
+        d = torch.addmm(_sq_norms(b)[None, :], q, b.T, alpha=-2.0)              # (+ |q|^2: constant per row, irrelevant for the order)
+        if nb % group:
+            d = torch.cat([d, torch.full((Q, group - nb % group), float("inf"), device=dev)], 1)
+        ng = d.shape[1] // group
+        dv = d.view(Q, ng, group)
+        gsel = torch.topk(dv.amin(dim=2), min(k, ng), dim=1, largest=False).indices          # [Q, k] groups
+        sub = torch.gather(dv, 1, gsel[:, :, None].expand(-1, -1, group)).reshape(Q, -1)      # [Q, k * group]
+        ii = torch.topk(sub, k, dim=1, largest=False).indices
+        ids = torch.gather(gsel, 1, ii // group) * group + ii % group + c0
+        ci_all.append(ids.clamp_(max=Nb - 1))
+    ci = torch.cat(ci_all, 1)
+    out_i, out_d = [], []
+    for r0 in range(0, Q, 256):                                                   # exact re-evaluation of the shortlist
+        c = ci[r0:r0 + 256]
+        diff = q[r0:r0 + 256, None, :] - base[c].float()
+        cd = (diff * diff).sum(2)
+        order = torch.argsort(c, dim=1, stable=True)
+        cd, c = torch.gather(cd, 1, order), torch.gather(c, 1, order)
+        dup = torch.zeros_like(c, dtype=torch.bool)
+        dup[:, 1:] = c[:, 1:] == c[:, :-1]
+        cd = torch.where(dup, torch.full_like(cd, float("inf")), cd)
+        order = torch.argsort(cd, dim=1, stable=True)[:, :k]
+        out_d.append(torch.gather(cd, 1, order))
+        out_i.append(torch.gather(c, 1, order))
+    return torch.cat(out_i), torch.cat(out_d)
+
+
 def build_graph(x: torch.Tensor, R: int, seed: int = SEED, n_knn: int | None = None):
     """kNN + random-long-link graph.  Returns (degrees int64 [N], adjacency int64 [N,R]) with each
     row's first ``degree`` entries distinct, != self and sorted ascending; the tail is 0."""
@@ -203,11 +245,22 @@ def train_pq(x: torch.Tensor, m: int, iters: int = 8, sample: int = 65536, seed:
             cen[nz] = sums[nz] / cnt[nz, None]
         pivots[:, a:b] = cen
         cens.append(cen)
-    for r0 in range(0, N, 1 << 20):
-        full = x[r0:r0 + (1 << 20)].float() - centroid
-        for c in range(m):
-            a, b = int(off[c]), int(off[c + 1])
-            codes[r0:r0 + (1 << 20), c] = torch.cdist(full[:, a:b], cens[c]).argmin(dim=1).to(torch.uint8)
+    # encode: chunks of equal width are handled together ([rows, chunks, 256] distances from one batched product)
+    widths = sorted(set(int(off[c + 1] - off[c]) for c in range(m)))
+    groups = []
+    for w in widths:
+        cs = [c for c in range(m) if int(off[c + 1] - off[c]) == w]
+        cols = torch.tensor([int(off[c]) + j for c in cs for j in range(w)], device=dev)
+        cg = torch.stack([cens[c] for c in cs])                                     # [nc, 256, w]
+        groups.append((torch.tensor(cs, device=dev), cols, cg, (cg * cg).sum(2), w))
+    step = 1 << 20 if N <= (1 << 24) else 1 << 16
+    for r0 in range(0, N, step):
+        full = x[r0:r0 + step].float() - centroid
+        B = full.shape[0]
+        for cs_t, cols, cg, cn, w in groups:
+            sub = full[:, cols].view(B, cs_t.shape[0], w).transpose(0, 1)           # [nc, B, w]
+            d = cn[:, None, :] - 2.0 * torch.bmm(sub, cg.transpose(1, 2))           # [nc, B, 256]  (+ |x|^2: constant per row)
+            codes[r0:r0 + B, cs_t] = d.argmin(dim=2).transpose(0, 1).to(torch.uint8)
     return pivots, centroid, off, codes
 
 

@@ -49,6 +49,8 @@ WORKLOADS = {
     "sift1m": (1_000_000, 128, "uint8", 64, 32, 10_000, 256),   # BASELINE.json configs[1]
     "sift10m": (10_000_000, 128, "uint8", 64, 32, 10_000, 1024),  # structured index beyond the Infinity Cache (320 MB of codes, 3.9 GB graph):
                                                                   # Vamana-style build on the GPU (bang_amd/index_build.py), SURVEY 8 f-3
+    "sift100m": (100_000_000, 128, "uint8", 64, 70, 10_000, 10_000),  # SIFT1B's layout (m = 70) on a recall-verified 1e8-point index: 38.8 GB
+                                                                      # of graph entries, built on the GPU in about a minute
     "small": (100_000, 128, "uint8", 64, 32, 10_000, 64),       # quick functional run
     "tiny": (20_000, 128, "uint8", 64, 32, 1_000, 32),
 }
@@ -137,11 +139,12 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False, h
         def make():
             if N > 2_000_000:                    # exact kNN by brute force stops being practical: partitioned search + robust prune
                 from bang_amd import index_build
-                return index_build.make_index_large(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev, log=log)
+                kw = dict(select="groupmin", probes=12) if N > 20_000_000 else {}
+                return index_build.make_index_large(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev, log=log, **kw)
             return synth.make_index(N, D, dtype, R, m, Q or Qd, K=ctx.k, n_clusters=ncl, device=ctx.dev)
         if N > 2_000_000:
             wl_name = wl_name.replace("SIFT1M-like structured synthetic", "SIFT-like structured synthetic").replace(
-                "kNN+random-link graph", "robust-pruned (alpha 1.2) approximate-kNN + random-link graph")
+                "kNN+random-link graph", "Vamana-style graph: robust-pruned (alpha 1.2) approximate kNN + reverse edges + small-world links")
         if world == 1:
             ix, queries, gt_i, gt_d = make()
             rel = lambda: None   # noqa: E731
@@ -647,7 +650,7 @@ def main():
                          "oracle can check the results -- parity runs of the sharded job at reduced N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
-    ap.add_argument("--legs", default="", help="comma list of legs to run (default: all): k2,sift1m,deep100m,walker,sift10m")
+    ap.add_argument("--legs", default="", help="comma list of legs to run (default: all): k2,sift1m,deep100m,walker,sift100m,sift10m")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--no-events", action="store_true", help="do not stamp the launches of the timed steps")
@@ -851,6 +854,16 @@ def main():
             cfg["walker_step_ms_min"], cfg["walker_step_ms_max"] = min(r["res"]["step_ms"]), max(r["res"]["step_ms"])
             release_config(r)
         guarded("at_sift1b_shape_walker", leg_walker)
+
+    if leg_on("sift100m"):
+        def leg_100m():
+            # SIFT1B's PQ layout and placement (graph in host RAM, rows pulled over PCIe) on a structured, recall-verified 1e8-point index
+            r = run_config("sift100m", ctx, args, O, graph="host", steps=leg_steps, warmup=leg_warm, traffic=False, keep=True)
+            cfg["at_sift100m"] = leg_summary(r["res"], r["wl"], "host", recall=r["recall"], extra={"parity_vs_oracle_first_64": r["ok"]})
+            flat(cfg, "sift100m", cfg["at_sift100m"])
+            cfg["sift100m_hops_max"] = cfg["at_sift100m"]["hops_p50_p99_max"][2]
+            release_config(r)
+        guarded("at_sift100m", leg_100m)
 
     if leg_on("sift10m"):
         def leg_10m():

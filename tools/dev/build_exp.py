@@ -22,6 +22,15 @@ VARIANTS = {
     "r2m70": dict(reverse=False, n_random=32, m=70),
     "revm70": dict(reverse=True, n_random=12, m=70),
     "r2m64": dict(reverse=False, n_random=32, m=64),
+    "revm70p12": dict(reverse=True, n_random=12, m=70, probes=12),
+    "swm70": dict(reverse=True, n_random=16, m=70, links="smallworld"),
+    "swm70r24": dict(reverse=True, n_random=24, m=70, links="smallworld"),
+    "unim70": dict(reverse=True, n_random=16, m=70, links="uniform"),
+    "swgm": dict(reverse=True, n_random=16, m=70, select="groupmin"),
+    "swgmp12": dict(reverse=True, n_random=16, m=70, select="groupmin", probes=12),
+    "swp10": dict(reverse=True, n_random=16, m=70, probes=10),
+    "revm70n1": dict(reverse=True, n_random=12, m=70, noise=1.0),
+    "revm70n05": dict(reverse=True, n_random=12, m=70, noise=0.5),
 }
 
 
@@ -40,7 +49,7 @@ def main():
             kw["cells"] = int(max(16, min(8192, round((N ** 0.5) / 1.5))))
         t0 = time.time()
         ix, q, gt_i, gt_d = index_build.make_index_large(N, 128, "uint8", 64, m, Q, K=k, n_clusters=max(256, N // 10000), device="cuda",
-                                                         log=lambda *a: print(*a, flush=True), **kw)
+                                                         log=lambda *a: print(*a, flush=True), diag=True, **kw)
         tb = time.time() - t0
         deg = ix.degrees()
         print(f"== {name} N={N}: built in {tb:.1f}s, degree mean {deg.mean():.1f} min {deg.min()}", flush=True)
