@@ -651,6 +651,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
     ap.add_argument("--legs", default="", help="comma list of legs to run (default: all): k2,sift1m,deep100m,walker,sift100m,sift10m")
+    ap.add_argument("--leg-budget-s", type=float, default=330.0,
+                    help="a leg is skipped (and listed in config.legs_skipped) once the run has taken this long: the default run stays within minutes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--no-events", action="store_true", help="do not stamp the launches of the timed steps")
@@ -736,8 +738,16 @@ def main():
     want = set(x for x in args.legs.split(",") if x)
     legs = world == 1 and not args.no_legs and not os.environ.get("BANG_BENCH_NO_LEGS")
 
+    t_run0 = time.time()
+    skipped = []
+
     def leg_on(name):
-        return legs and (not want or name in want)
+        if not (legs and (not want or name in want)):
+            return False
+        if time.time() - t_run0 > args.leg_budget_s:
+            skipped.append(name)
+            return False
+        return True
 
     # the CPU baseline of a structured primary needs its index: before the release
     if rank == 0 and world == 1 and not args.no_cpu_baseline and prim["structured"]:
@@ -886,6 +896,8 @@ def main():
             release_config(r)
         guarded("at_sift10m", leg_10m)
 
+    if skipped:
+        cfg["legs_skipped"] = ",".join(skipped)
     if out is not None and out["roofline"] is not None and k2:
         out["roofline"]["k2_alone_other_layouts"] = {kk: v for kk, v in k2.items() if kk != f"m{m_primary}"}
         for kk, v in k2.items():

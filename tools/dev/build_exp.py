@@ -29,6 +29,10 @@ VARIANTS = {
     "swgm": dict(reverse=True, n_random=16, m=70, select="groupmin"),
     "swgmp12": dict(reverse=True, n_random=16, m=70, select="groupmin", probes=12),
     "swp10": dict(reverse=True, n_random=16, m=70, probes=10),
+    "gm6": dict(m=70, select="groupmin", probes=6),
+    "gm8": dict(m=70, select="groupmin", probes=8),
+    "gm6c1k": dict(m=70, select="groupmin", probes=8, cell=1024),
+    "gm6k32": dict(m=70, select="groupmin", probes=6, K=32),
     "revm70n1": dict(reverse=True, n_random=12, m=70, noise=1.0),
     "revm70n05": dict(reverse=True, n_random=12, m=70, noise=0.5),
 }
