@@ -67,6 +67,7 @@ static const OptionDef kOptions[] = {
 struct SwitchDef { const char* env; const char* help; };
 static const SwitchDef kSwitches[] = {
     {"BANG_PULL_ROWS_DIR", "directory (tmpfs) every rank of a node can see: ONE pull-rows file per index there, built by the first rank to load, mapped by the others"},
+    {"BANG_PULL_ROWS_INTERLEAVE", "0 = leave the pages of a shared pull-rows file where first touch puts them (default 1: interleaved over the NUMA nodes)"},
     {"BANG_STREAM_LOAD", "0 = bang_load maps <prefix>_disk.bin up front instead of streaming it through (pull mode)"},
     {"BANG_GRAPH_MMAP", "0 = private copy of the graph file (transparent huge pages) instead of a shared read-only mapping"},
     {"BANG_SEARCH_MAX_WGS", "search kernel: cap on workgroups (experiments / tests)"},

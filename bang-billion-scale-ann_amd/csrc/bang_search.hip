@@ -878,11 +878,18 @@ __device__ __forceinline__ bool pipe_trip(F& f, std::integer_sequence<int, I...>
 #ifndef BANG_K2_COOP
 #define BANG_K2_COOP 1              // code rows fetched cooperatively (CoopFetch, bang_device.h); 0 = one row per lane, NX4 loads each
 #endif
+#ifndef BANG_K2_COOP_MIN_P
+#define BANG_K2_COOP_MIN_P 3        // rows of at least this many 16-byte pieces are fetched cooperatively (two-piece rows, m = 32: measured slower)
+#endif
+#ifndef BANG_K2_M32_MAXT
+#define BANG_K2_M32_MAXT 1024
+#endif
+__host__ __device__ constexpr bool k2_coop(int ndw, bool aligned) { return BANG_K2_COOP && (ndw + (aligned ? 0 : 1) + 3) / 4 >= BANG_K2_COOP_MIN_P; }
 template <int PSZ, int NDW, bool ALIGNED, int NHI, int MAXT>
 __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_params p, uint32_t lds_piv_floats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* piv_lds = lds;
-  constexpr bool COOP = BANG_K2_COOP != 0;
+  constexpr bool COOP = k2_coop(NDW, ALIGNED);
   const uint32_t stride = p.code_stride ? p.code_stride : p.m;
   // staging area of this wave's cooperative row fetch, behind the pivot table
   uint32_t* coop_buf = (uint32_t*)(lds + lds_piv_floats) + (size_t)(threadIdx.x >> 6) * CoopFetch<NDW, ALIGNED>::LDS_WORDS;
@@ -917,8 +924,11 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
 #else
   constexpr int NV = (QW + 63) / 64;
   typedef QcRegs<NV> Qc;                            // the centred query in registers (v_readlane): no scalar-load waits inside the reduce
+  // n_all != 0: the Q neighbour rows belong to n_all distinct queries (row q -> query q mod n_all), as the rows of successive
+  // iterations of a search do; 0: one query per row
+  const uint32_t qc_rows = p.n_all ? p.n_all : p.Q;
   auto load_qc = [&](Qc& dst, uint32_t qq) {
-    const float* src = p.d_qc + (size_t)qq * QW;
+    const float* src = p.d_qc + (size_t)(qq % qc_rows) * QW;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
       const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
@@ -975,7 +985,7 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
   // two long rows in flight need the 256-VGPR budget; so do the two cooperative fetches of the 4-float layout (8 waves fetch as fast as 16)
-  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2) || (BANG_K2_COOP && PSZ == 4 && NDW >= 8)) ? 512 : 1024;
+  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? 512 : (PSZ == 4 && NDW == 8) ? BANG_K2_M32_MAXT : 1024;
   static bool attr_done[BANG_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
@@ -987,7 +997,7 @@ static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hi
   const uint32_t waves = MAXT / WAVE;
   uint32_t grid = (p.Q + waves - 1) / waves;
   if (grid > cus) grid = cus;
-  const size_t lds_bytes = (size_t)piv_floats * 4 + (BANG_K2_COOP ? (size_t)waves * CoopFetch<NDW, ALIGNED>::LDS_WORDS * 4 : 0);
+  const size_t lds_bytes = (size_t)piv_floats * 4 + (k2_coop(NDW, ALIGNED) ? (size_t)waves * CoopFetch<NDW, ALIGNED>::LDS_WORDS * 4 : 0);
   if (lds_bytes > 160 * 1024) { bang_set_error("K2 streaming form: pivot table + staging exceed LDS"); return BANG_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>), dim3(grid), dim3(MAXT), lds_bytes, st, p, piv_floats);
   HIP_TRY(hipGetLastError());

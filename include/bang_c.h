@@ -234,7 +234,7 @@ typedef struct {
   /* straggler compaction: when d_qmap != NULL the kernels iterate over Q SLOTS and slot s works on query d_qmap[s]
    * (all per-query arrays stay indexed by the query); n_all = number of queries behind the arrays (parents copy). */
   const uint32_t* d_qmap;
-  uint32_t n_all;
+  uint32_t n_all;                      /* (bang_k_pqdist_stream: != 0 = the Q neighbour rows belong to n_all distinct queries, row q -> query q mod n_all) */
   /* inputs */
   const uint32_t* d_stage;             /* [Q][BANG_STAGE_STRIDE] staged adjacency {count, ids} (first==0) */
   const uint32_t* d_seed;              /* [1 + R+1] {count, MEDOID, adj(MEDOID)...}  (first==1) */
