@@ -215,7 +215,7 @@ def run_once(eng, my_q, ctx, timed=False, gather=True):
         if ctx.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    collective = ctx.world > 1 and gather and not ctx.weak
+    collective = (ctx.world > 1 or getattr(ctx, "force_gather", False)) and gather and not ctx.weak
     dg = getattr(ctx, "dgather", None) if collective else None
     t_a = time.perf_counter()
     if dg is not None:
@@ -495,7 +495,7 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=pull)
     # N > 1: the shard's ids stay in device memory (bang_query_dev_e) until the collective (BANG_BENCH_HOST_GATHER=1: the r02 host bounce)
     ctx.dgather = None
-    if ctx.world > 1 and not weak and not os.environ.get("BANG_BENCH_HOST_GATHER"):
+    if (ctx.world > 1 or getattr(ctx, "force_gather", False)) and not weak and not os.environ.get("BANG_BENCH_HOST_GATHER"):
         ctx.dgather = shard.DeviceGather(Qt, k, ctx.rank, ctx.world, ctx.dev, coll_device=ctx.cdev)
     recall = float("nan")
     if L == 0 and gt_i is not None:
@@ -532,7 +532,7 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     else:
         ok = check_properties(ix, my_q, res["ids"], res["dists"], k)
     gathered_ok = None
-    if ctx.world > 1 and not weak and ctx.rank == 0 and getattr(ctx, "batch_ids", None) is not None:
+    if (ctx.world > 1 or getattr(ctx, "force_gather", False)) and not weak and ctx.rank == 0 and getattr(ctx, "batch_ids", None) is not None:
         # what the collective delivered, against the oracle over the WHOLE batch (where the oracle can run: host-side PQ codes)
         if orc is None and getattr(ix, "codes", None) is not None and ix.codes.shape[0] == ix.N:
             orc = O.Oracle(ix)
@@ -678,8 +678,14 @@ def main():
     torch.cuda.set_device(ctx.local_rank)
     ctx.dev = dev = torch.device("cuda", ctx.local_rank)
     ctx.cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
-    if world > 1:
+    # BANG_BENCH_FORCE_GATHER=1: run the N > 1 data path (bang_query_dev_e + the RCCL all-gather from device buffers) with ONE rank --
+    # the only way to execute the RCCL call on a 1-GPU box (two ranks on one device are refused)
+    ctx.force_gather = bool(os.environ.get("BANG_BENCH_FORCE_GATHER")) and world == 1
+    if world > 1 or ctx.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -908,7 +914,7 @@ def main():
         for kk, v in k2.items():
             if v:
                 cfg[f"k2_alone_{kk}_frac"] = v["frac"]
-    if world > 1:
+    if world > 1 or ctx.force_gather:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -95,3 +95,26 @@ def test_two_ranks_sift1b_shape_gathered_batch_equals_oracle(libbang):
     assert one["config"]["result_properties_ok"] is True and two["config"]["result_properties_ok"] is True
     assert two["config"]["gathered_ids_equal_oracle_whole_batch"] is True, two["config"]
     assert two["n_gpus"] == 2 and "pulled" in two["config"]["host_loop"]
+
+
+def test_rccl_all_gather_from_device_buffers_single_rank(libbang):
+    """The data path of the N > 1 job with the REAL collective: bang_query_dev_e leaves the ids in a device buffer and RCCL's
+    all_gather_into_tensor reads it in place (one rank: RCCL refuses two ranks on one device, and this pool has one GPU per box);
+    the gathered block equals the oracle's answer for the whole batch."""
+    env = dict(os.environ, BANG_BENCH_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--workload", "tiny", "--L", "46", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-legs", "--backend", "nccl"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=380)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert c["parity_vs_oracle_first_64"] is True and c["gathered_ids_equal_oracle_whole_batch"] is True
+    assert c["gather_ms_per_step_max_over_ranks"] > 0 and c["search_ms_per_step_max_over_ranks"] > 0
+    # the same on the north-star layout (streamed SIFT1B-shape index at reduced N, rows pulled)
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--workload", "sift1b_shape", "--shape-n", "6000000", "--queries", "1024", "--L", "40",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs", "--backend", "nccl"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=380)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["result_properties_ok"] is True and d["config"]["gather_ms_per_step_max_over_ranks"] > 0
