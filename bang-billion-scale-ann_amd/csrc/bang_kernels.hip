@@ -764,6 +764,38 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   uint32_t n = a.cand_cnt[q];
   if (n > RERANK_MAX_CAND) n = RERANK_MAX_CAND;
   __syncthreads();
+  // 8-bit vectors of up to 256 dimensions at id * stride (dword aligned): G = D / 16 ADJACENT lanes fetch one candidate's
+  // vector, 16 bytes each, in one instruction -- one request per line of the vector instead of D / 16 look-ups of it by one lane (the
+  // same effect as in the PQ code rows: DESIGN 4.2).  Every partial sum of squared integer differences is an integer below 2^24
+  // (256 x 255^2), exact in float in ANY order, so the lanes' partial sums add up to the bits the ascending fmaf chain produces.
+  if constexpr (sizeof(T) == 1) {
+    const uint32_t G = a.D >> 4;
+    if (!a.by_query && !a.cand_row && (a.D & 15u) == 0 && a.D <= 256 && (G & (G - 1)) == 0 && G <= 16 && (a.vec_stride & 3u) == 0 &&
+        (((uintptr_t)a.vec_base) & 3u) == 0) {
+      const uint32_t per_pass = blockDim.x / G;
+      const uint32_t sub = threadIdx.x % G, slot = threadIdx.x / G;
+      for (uint32_t i0 = 0; i0 < n; i0 += per_pass) {
+        const uint32_t i = i0 + slot;
+        float acc = 0.0f;
+        uint32_t id = 0;
+        if (i < n) {
+          id = a.cand_ids[(size_t)q * a.cand_stride + i];
+          const u32x4a w = *(const u32x4a*)(a.vec_base + (uint64_t)id * a.vec_stride + 16u * sub);
+          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const float diff = elem_diff<T>(ww[d], b, qv, 16u * sub + 4u * d + b);
+              acc = __builtin_fmaf(diff, diff, acc);
+            }
+        }
+        for (uint32_t off = 1; off < G; off <<= 1) acc += __shfl_xor(acc, (int)off);     // (G lanes of one candidate are adjacent)
+        if (i < n && sub == 0) { e[i] = acc; ids[i] = id; }
+      }
+      goto ranked;
+    }
+  }
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t id = a.cand_ids[(size_t)q * a.cand_stride + i];
     const uint8_t* vec;
@@ -778,6 +810,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     e[i] = exact_dist<T>(vec, qv, a.D);
     ids[i] = id;
   }
+ranked:
   __syncthreads();
   // stable rank by exact distance; ties keep expansion order (:1330-1363)
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
