@@ -76,6 +76,7 @@ static const SwitchDef kSwitches[] = {
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},
     {"BANG_MAILBOX_BYTES", "results up to this size return through the pinned mirror in one copy (default 8 MB)"},
     {"BANG_HELPER_GRACE_US", "walker helpers spin this long for the next batch before parking (default 4000)"},
+    {"BANG_WALK_NT", "0 = walker threads copy staged rows with memcpy instead of 512-bit non-temporal stores"},
     {"BANG_DEBUG", "placement / allocation decisions and lane progress on stderr"},
     {"BANG_TIMELINE", "host time of every stage of a bang_query (a stream sync behind each) on stderr"},
     {"BANG_SEARCH_PROF", "search kernel: phase times on stderr (half-rounds of the host-paced form; per-iteration phases in a -DBANG_SEARCH_PHASE_PROF build)"},

@@ -141,6 +141,13 @@ inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
 // its round number; the thread fetches those parents' graph entries -- adjacency rows into the waves' slots of d_stage through the
 // BAR, full-precision vectors into the vector log if they are not resident in HBM -- and releases the workgroup into its next
 // round by storing the round number into its pacing word.
+// 64-byte lines of a staged row written with ONE 512-bit non-temporal store each (BANG_WALK_NT=0: memcpy).  The destination is the
+// GPU's BAR, mapped write-combining: ordinary stores already gather in the core's WC buffers and leave as whole 64-byte writes, so
+// the gain is small -- 15.5 / 13.8 ms against 15.7 / 15.0 ms per SIFT1B-shape batch in two A/B pairs.
+__attribute__((target("avx512f"))) static void wc_copy_nt(void* dst, const void* src, size_t n) {
+  for (size_t o = 0; o + 64 <= n; o += 64) _mm512_stream_si512((__m512i*)((uint8_t*)dst + o), _mm512_loadu_si512((const uint8_t*)src + o));
+}
+
 void swalk(bang_engine* e, Lane& ln, int t, int T) {
   const uint32_t G = e->sv_NG, W = 16;                     // pacing groups (workgroups x wave groups x contexts), up to 16 slots each
   const uint32_t w0 = (uint32_t)((uint64_t)G * (uint32_t)t / (uint32_t)T), w1 = (uint32_t)((uint64_t)G * (uint32_t)(t + 1) / (uint32_t)T);
@@ -160,7 +167,8 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
   auto t_last = Clock::now();
   uint32_t idle = 0;
   bool served_unfenced = false;
-  const bool prof = env_flag("BANG_WALK_PROF");      // diagnostic: time spent serving vs polling, per thread
+  const bool prof = env_flag("BANG_WALK_PROF");
+  const bool nt_rows = env_long("BANG_WALK_NT", 1) != 0 && __builtin_cpu_supports("avx512f");      // diagnostic: time spent serving vs polling, per thread
   uint64_t prof_serve = 0, prof_n = 0, prof_rows = 0, prof_t0 = prof ? __rdtsc() : 0, prof_ts = 0;
   auto try_serve = [&](uint32_t w) -> bool {
     uint32_t it = expect[w].load(std::memory_order_relaxed);
@@ -201,7 +209,8 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
         memcpy(&deg, ent + vb, 4);                                      // :801
         if (deg > R) deg = R;
         const size_t nbytes = std::min<size_t>(((size_t)deg * 4 + 63) & ~(size_t)63, (size_t)R * 4);   // ids beyond `deg` are never read
-        memcpy(srow, ent + vb + 4, nbytes);                             // :809-810
+        if (nt_rows) wc_copy_nt(srow, ent + vb + 4, nbytes);            // one 512-bit non-temporal store per 64-byte line
+        else memcpy(srow, ent + vb + 4, nbytes);                        // :809-810
         counts[i >> 2] |= deg << (8 * (i & 3u));
         bytes += nbytes;
       }
