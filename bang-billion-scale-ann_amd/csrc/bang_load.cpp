@@ -126,6 +126,15 @@ static int pull_rows_open(bang_engine* e, PullRows& pr, const PullRowsSig* expec
     pr.tmp = pr.path + ".tmp." + std::to_string((long)getpid());
     const int fd = open(pr.tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
     if (fd >= 0) {
+      // (a mapping of a tmpfs file that outgrows its file system dies with SIGBUS on first touch, not with an error: check first)
+      struct statvfs vfs;
+      if (fstatvfs(fd, &vfs) == 0 && (unsigned long long)vfs.f_bavail * vfs.f_frsize < pr.bytes + ((size_t)1 << 30)) {
+        close(fd);
+        (void)unlink(pr.tmp.c_str());
+        pr.tmp.clear();
+        bang_set_error("pull rows: %.1f GB do not fit the file system of %s", pr.bytes / 1e9, pr.path.c_str());
+        return BANG_ERR_NOMEM;
+      }
       if (ftruncate(fd, (off_t)pr.bytes) == 0) pr.m = mmap(nullptr, pr.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
       close(fd);
       if (pr.m == MAP_FAILED) { (void)unlink(pr.tmp.c_str()); pr.tmp.clear(); }

@@ -115,7 +115,9 @@ def build_workload(name, ctx, Q=0, shape_n=0, reserve_rows=True, stream=False, h
         shared = None
         stream = bool(stream and shape_workload.SHAPES[name]["graph"] == "host" and not host_codes)
         if world > 1:
-            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows, stream) if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
+            st = os.statvfs(os.path.dirname(sdir))
+            n_plan = torch.tensor([shape_workload.plan_n(name, ctx.dev, shape_n, reserve_rows, stream, shared_bytes=st.f_bavail * st.f_frsize)
+                                   if rank == 0 else 0], dtype=torch.int64, device=ctx.cdev)
             dist.broadcast(n_plan, 0)
             shape_n = int(n_plan.item())
             if not stream:                       # (a streamed index has no graph image to share: every rank runs the generator)

@@ -103,8 +103,10 @@ def code_stride(name) -> int:
     return CODE_STRIDE[name] if s < 0 else (s or SHAPES[name]["m"])
 
 
-def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False):
-    """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything."""
+def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False, shared_bytes=0):
+    """N a shape workload will get on this box (after scaling to the host / HBM memory budget), without building anything.
+    shared_bytes: free space of the directory the ranks of a node share (tmpfs) -- the ONE pull-rows file (and, not streamed, the
+    graph image) must fit it: a mapping of a tmpfs file that outgrows the file system dies with SIGBUS, not with an error."""
     import torch
     sh = SHAPES[name]
     isz = 4 if sh["dtype"] == "float" else 1
@@ -118,6 +120,10 @@ def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False):
     else:
         free, _ = torch.cuda.mem_get_info(dev)
         N = min(N, (int(free * 0.85) - (8 << 30)) // (entry + code_stride(name)), int(usable_host_bytes() * 0.75) // entry)
+    if shared_bytes and sh["graph"] == "host":
+        per_node = (PULL_ROW_BYTES if (stream or reserve_rows) else 0) + (0 if stream else entry)
+        if per_node:
+            N = min(N, int(shared_bytes * 0.9) // per_node)
     return int(N)
 
 
