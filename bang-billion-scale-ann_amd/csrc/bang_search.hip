@@ -984,8 +984,11 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  // two long rows in flight need the 256-VGPR budget; so do the two cooperative fetches of the 4-float layout (8 waves fetch as fast as 16)
-  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? 512 : (PSZ == 4 && NDW == 8) ? BANG_K2_M32_MAXT : 1024;
+  // long rows: two cooperative fetches in flight + the row being reduced need more than the 128 VGPRs of a 16-wave workgroup
+#ifndef BANG_K2_LONG_MAXT
+#define BANG_K2_LONG_MAXT 768        // 12 waves x 168 VGPRs: rows 128 B apart 30.5 -> 32.3 (m = 70), 30.9 -> 32.9 G rows/s (m = 74) against 8 waves x 256
+#endif
+  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? BANG_K2_LONG_MAXT : (PSZ == 4 && NDW == 8) ? BANG_K2_M32_MAXT : 1024;
   static bool attr_done[BANG_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
