@@ -208,3 +208,14 @@ def test_every_option_lives_in_one_table(libbang):
             assert name in known, (src, name)
         if not src.endswith("bang_options.cpp"):
             assert "getenv(" not in open(src).read(), src
+
+
+def test_integration_md_carries_the_option_table_verbatim(libbang):
+    """INTEGRATION.md section 5 is the text bang_describe_options() prints: the documentation cannot drift from the table."""
+    lib = libbang
+    lib.bang_describe_options.argtypes = [C.c_char_p, C.c_size_t]
+    need = lib.bang_describe_options(None, 0)
+    buf = C.create_string_buffer(need)
+    lib.bang_describe_options(buf, need)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert buf.value.decode().rstrip() in doc
