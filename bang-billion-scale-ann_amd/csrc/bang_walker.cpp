@@ -145,7 +145,9 @@ inline void slice_of(const Lane& ln, int t, int T, uint32_t* i0, uint32_t* i1) {
 // GPU's BAR, mapped write-combining: ordinary stores already gather in the core's WC buffers and leave as whole 64-byte writes, so
 // the gain is small -- 15.5 / 13.8 ms against 15.7 / 15.0 ms per SIFT1B-shape batch in two A/B pairs.
 __attribute__((target("avx512f"))) static void wc_copy_nt(void* dst, const void* src, size_t n) {
-  for (size_t o = 0; o + 64 <= n; o += 64) _mm512_stream_si512((__m512i*)((uint8_t*)dst + o), _mm512_loadu_si512((const uint8_t*)src + o));
+  size_t o = 0;
+  for (; o + 64 <= n; o += 64) _mm512_stream_si512((__m512i*)((uint8_t*)dst + o), _mm512_loadu_si512((const uint8_t*)src + o));
+  if (o < n) memcpy((uint8_t*)dst + o, (const uint8_t*)src + o, n - o);      // (degree bounds below 16 ids: a row shorter than one line)
 }
 
 void swalk(bang_engine* e, Lane& ln, int t, int T) {
