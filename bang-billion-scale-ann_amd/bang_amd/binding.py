@@ -63,7 +63,7 @@ class IndexDesc(C.Structure):
     _fields_ = [("medoid", C.c_uint64), ("entry_len", C.c_uint64), ("D", C.c_uint32), ("R", C.c_uint32),
                 ("N", C.c_uint32), ("m", C.c_uint32), ("graph", C.c_void_p), ("codes", C.c_void_p),
                 ("d_codes", C.c_void_p), ("pivots", C.c_void_p), ("centroid", C.c_void_p), ("chunk_off", C.c_void_p),
-                ("code_stride", C.c_uint32)]
+                ("code_stride", C.c_uint32), ("vectors_ready", C.c_uint32), ("d_vectors", C.c_void_p), ("rows_hash", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -204,7 +204,7 @@ class Engine:
                       d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride)
         _check(lib().bang_load_mem_e(self._h, C.byref(d)), "bang_load_mem")
 
-    def load_stream(self, ix, source, ctx=None, d_codes: int | None = None, code_stride: int = 0):
+    def load_stream(self, ix, source, ctx=None, d_codes: int | None = None, code_stride: int = 0, d_vectors: int | None = None):
         """Streamed load (bang_load_stream_e): `source` is a C function pointer -- or a Python callable
         (first, count, dst_address) -> 0 -- that writes `count` graph entries in the reference layout for the nodes from `first`;
         ix supplies everything but the graph (medoid, entry_len, D, R, N, m, codes, pivots, centroid, chunk_off)."""
@@ -217,10 +217,29 @@ class Engine:
             source = ENTRY_SOURCE(lambda _ctx, first, count, dst: int(py(first, count, dst)))
         self._keep = [codes, pivots, centroid, chunk_off, source]
         d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, None, None if codes is None else _vp(codes).value,
-                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride)
+                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride, 0, d_vectors, 0)
         fn = lib().bang_load_stream_e
         fn.argtypes = [C.c_void_p, C.POINTER(IndexDesc), C.c_void_p, C.c_void_p]
         _check(fn(self._h, C.byref(d), C.cast(source, C.c_void_p), ctx), "bang_load_stream")
+
+    def load_shared(self, ix, d_vectors: int, rows_hash: int, d_codes: int | None = None, code_stride: int = 0):
+        """bang_load_shared_e: this rank did not read the index -- the vectors are already in its device buffer `d_vectors` (received
+        from the loading rank), the adjacency rows in the node's rows file (BANG_PULL_ROWS_DIR) whose hash the loading rank reported."""
+        codes = None if ix.codes is None else np.ascontiguousarray(ix.codes, dtype=np.uint8)
+        pivots = np.ascontiguousarray(ix.pivots, dtype=np.float32)
+        centroid = np.ascontiguousarray(ix.centroid, dtype=np.float32)
+        chunk_off = np.ascontiguousarray(ix.chunk_off, dtype=np.uint32)
+        self._keep = [codes, pivots, centroid, chunk_off]
+        d = IndexDesc(ix.medoid, ix.entry_len, ix.D, ix.R, ix.N, ix.m, None, None if codes is None else _vp(codes).value,
+                      d_codes, _vp(pivots).value, _vp(centroid).value, _vp(chunk_off).value, code_stride, 1, d_vectors, rows_hash)
+        fn = lib().bang_load_shared_e
+        fn.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
+        _check(fn(self._h, C.byref(d)), "bang_load_shared")
+
+    def rows_hash(self) -> int:
+        h = C.c_uint64()
+        _check(lib().bang_get_rows_hash(self._h, C.byref(h)), "bang_get_rows_hash")
+        return int(h.value)
 
     def set_searchparams(self, recall: int, worklist_length: int, distfn: int = DIST_L2):
         _check(lib().bang_set_searchparams_e(self._h, recall, worklist_length, distfn), "bang_set_searchparams")

@@ -101,10 +101,41 @@ extern "C" int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* d, ba
     return BANG_ERR_ARG;
   }
   e->entry_fn = src; e->entry_ctx = ctx;
+  e->ext_vecs = (uint8_t*)d->d_vectors; e->ext_vecs_ready = false;
   const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off, d->d_codes ? d->code_stride : 0);
-  e->entry_fn = nullptr; e->entry_ctx = nullptr;
+  e->entry_fn = nullptr; e->entry_ctx = nullptr; e->ext_vecs = nullptr;
   if (rc != BANG_OK) unload_index(e);
   return rc;
+}
+
+extern "C" int bang_load_shared_e(bang_engine_t* e, const bang_index_desc* d) {
+  if (!e || !d || d->graph || !d->pivots || !d->centroid || !d->chunk_off || (!d->codes && !d->d_codes) || !d->d_vectors || !d->vectors_ready) {
+    bang_set_error("bad index descriptor (a shared load takes the filled vector buffer of the node's loading rank and no graph)");
+    return BANG_ERR_ARG;
+  }
+  if (e->loaded) { bang_set_error("index already loaded"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  e->medoid = d->medoid; e->entry_len = d->entry_len; e->D = d->D; e->R = d->R; e->N = d->N; e->m = d->m;
+  e->graph = nullptr; e->graph_owned = nullptr; e->graph_path.clear();
+  if (e->graph_mode == BANG_GRAPH_DEVICE || e->pull_opt == 0 || e->vectors_opt == 0 || e->persistent == 0 || e->search_opt == 0) {
+    bang_set_error("a shared load runs in pull mode on the host placement only");
+    return BANG_ERR_UNSUPPORTED;
+  }
+  e->graph_mode = BANG_GRAPH_HOST;
+  if (e->entry_len != (uint64_t)e->D * e->tsize + 4 + 4ull * e->R) { bang_set_error("index entry length does not match D / R"); return BANG_ERR_ARG; }
+  e->entry_fn = nullptr; e->entry_ctx = nullptr;
+  e->ext_vecs = (uint8_t*)d->d_vectors; e->ext_vecs_ready = true; e->rows_hash = d->rows_hash;
+  const int rc = upload_index(e, d->codes, d->d_codes, d->pivots, d->centroid, d->chunk_off, d->d_codes ? d->code_stride : 0);
+  e->ext_vecs = nullptr; e->ext_vecs_ready = false;
+  if (rc != BANG_OK) unload_index(e);
+  return rc;
+}
+
+extern "C" int bang_get_rows_hash(bang_engine_t* e, uint64_t* out) {
+  if (!e || !out) return BANG_ERR_ARG;
+  if (!e->loaded || !e->pull) { bang_set_error("bang_get_rows_hash: no index in pull mode is loaded"); return BANG_ERR_ARG; }
+  *out = e->rows_hash;
+  return BANG_OK;
 }
 
 extern "C" int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn) {

@@ -252,6 +252,10 @@ struct bang_engine {
   bool entry_src_rereadable = false;   // the entry source is ours (a file): placements that need the whole graph may read it all
   const uint32_t* d_adj = nullptr;     // device address of h_adj
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
+  bool vecs_owned = true;              // false: d_vecs is the caller's buffer (bang_index_desc.d_vectors), never freed here
+  uint8_t* ext_vecs = nullptr;         // set for the duration of a load: the caller's vector buffer, and whether it is filled already
+  bool ext_vecs_ready = false;
+  uint64_t rows_hash = 0;              // hash over every adjacency list of the loaded index (the pull rows' signature)
   bool fp_direct = false;              // the walker writes the full-precision vectors straight into d_fp (BAR), no staging copy
   int stagger_us = 0;                  // lane i starts i*stagger_us later (de-synchronises the lanes' PCIe phases)
   int fp_batch = 16;                   // vector-log rows are copied to the device every fp_batch iterations
@@ -302,6 +306,7 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
                  const uint32_t* chunk_off, uint32_t desc_code_stride);
 void unload_index(bang_engine* e);
 int load_files(bang_engine* e, const char* prefix);
+int load_shared(bang_engine* e, uint64_t expect_rows_hash);    // vectors already in the caller's device buffer, rows in the node's rows file
 int map_graph_file(bang_engine* e);
 // ---- bang_alloc.cpp
 int alloc_buffers(bang_engine* e, int Q);

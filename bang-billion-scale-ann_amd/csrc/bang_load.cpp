@@ -87,6 +87,7 @@ struct PullRows {
   void* m = MAP_FAILED;
   size_t bytes = 0, sig_off = 0;
   bool fill = true;                    // false: an existing rows file was mapped (its signature is checked in pull_rows_finish)
+  bool keep_stale = false;             // a mapped file with another signature is left alone (shared load: it is another rank's)
   std::string path, tmp;
 };
 static void pull_rows_abandon(PullRows& pr) {
@@ -173,7 +174,7 @@ static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig
     pr.tmp.clear();
   } else if (memcmp((const uint8_t*)pr.m + pr.sig_off, &sig, sizeof(sig)) != 0) {
     pull_rows_abandon(pr);
-    (void)unlink(pr.path.c_str());                        // stale: rows of another graph (the caller rebuilds them)
+    if (!pr.keep_stale) (void)unlink(pr.path.c_str());    // stale: rows of another graph (the caller rebuilds them)
     bang_set_error("pull rows: %s belonged to another index", pr.path.c_str());
     return BANG_ERR_STALE_ROWS;
   }
@@ -192,6 +193,7 @@ static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig
     return BANG_ERR_HIP;
   }
   e->h_adj = (uint32_t*)pr.m; e->adj_bytes = pr.bytes; e->d_adj = (const uint32_t*)dp; e->pull = true;
+  e->rows_hash = sig.adj_hash;
   pr.m = MAP_FAILED;
   return BANG_OK;
 }
@@ -268,7 +270,8 @@ static bool stream_feasible(bang_engine* e, size_t hbm_reserve, std::string* why
 // staging buffer), adjacency lists into the pull rows -- and dropped.  Host memory: the rows (N x 256 B) and one chunk.
 static int stage_entries_streamed(bang_engine* e, bool retried = false) {
   const size_t vb = vec_bytes(e), N = e->N, el = e->entry_len;
-  HIP_TRY(hipMalloc((void**)&e->d_vecs, N * vb + 256));
+  if (e->ext_vecs) { e->d_vecs = e->ext_vecs; e->vecs_owned = false; }      // the caller's buffer: it can hand the vectors on (xGMI broadcast)
+  else { HIP_TRY(hipMalloc((void**)&e->d_vecs, N * vb + 256)); e->vecs_owned = true; }
   PullRows pr;
   BANG_TRY(pull_rows_open(e, pr, nullptr));
   const size_t chunk = std::max<size_t>(1024, std::min<size_t>((size_t)1 << 20, ((size_t)512 << 20) / el));
@@ -327,13 +330,55 @@ static int stage_entries_streamed(bang_engine* e, bool retried = false) {
     const int frc = pull_rows_finish(e, pr, sig_make(e, h));
     if (frc == BANG_ERR_STALE_ROWS && !retried) {
       // a rows file of ANOTHER graph sat under this name (it has been removed): the entries pass through once more to build ours
-      dfree(e->d_vecs);
+      if (e->vecs_owned) dfree(e->d_vecs);
+      e->d_vecs = nullptr;
       return stage_entries_streamed(e, true);
     }
     if (frc != BANG_OK) return frc == BANG_ERR_STALE_ROWS ? BANG_ERR_IO : frc;
   }
   e->vec_on_device = true;
   BANG_TRY(stage_medoid(e, medoid_entry.data()));
+  e->graph_streamed = true;
+  return BANG_OK;
+}
+
+// SHARED load (ranks > 0 of a multi-GPU node): the rank that read the index has written the pull rows file and handed the
+// full-precision vectors on from its HBM (an RCCL broadcast over xGMI into the caller's buffer); nothing is read from the index
+// here -- the rows file is mapped (its signature must carry the hash the loading rank reports), the seed list comes from the
+// medoid's row, the medoid's vector from the vector buffer.
+int load_shared(bang_engine* e, uint64_t expect_rows_hash) {
+  const size_t vb = vec_bytes(e);
+  if (!e->ext_vecs || !e->ext_vecs_ready) { bang_set_error("shared load: no filled vector buffer"); return BANG_ERR_ARG; }
+  if (e->R > 64) { bang_set_error("shared load: the pull rows hold at most 64 ids (R = %u)", e->R); return BANG_ERR_UNSUPPORTED; }
+  const PullRowsSig sig = sig_make(e, expect_rows_hash);
+  PullRows pr;
+  pr.bytes = (size_t)e->N * 256 + 4096;
+  pr.sig_off = (size_t)e->N * 256 + 2048;
+  const char* dir = env_str("BANG_PULL_ROWS_DIR");
+  if (!dir) { bang_set_error("shared load: BANG_PULL_ROWS_DIR is not set"); return BANG_ERR_ARG; }
+  pr.path = std::string(dir) + "/" + (e->rows_key.empty() ? std::string("index") : e->rows_key) + "_pull_rows.bin";
+  const int fd = open(pr.path.c_str(), O_RDWR);
+  if (fd < 0) { bang_set_error("shared load: cannot open %s", pr.path.c_str()); return BANG_ERR_IO; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size != pr.bytes) { close(fd); bang_set_error("shared load: %s has the wrong size", pr.path.c_str()); return BANG_ERR_IO; }
+  pr.m = mmap(nullptr, pr.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (pr.m == MAP_FAILED) { bang_set_error("shared load: cannot map %s", pr.path.c_str()); return BANG_ERR_NOMEM; }
+  pr.fill = false;
+  pr.keep_stale = true;
+  {
+    const int rc = pull_rows_finish(e, pr, sig);       // compares the signature (sizes, medoid, hash of every adjacency list)
+    if (rc != BANG_OK) return rc == BANG_ERR_STALE_ROWS ? BANG_ERR_IO : rc;
+  }
+  e->d_vecs = e->ext_vecs; e->vecs_owned = false; e->vec_on_device = true;
+  std::vector<uint8_t> me(e->entry_len, 0);
+  HIP_TRY(hipMemcpy(me.data(), e->d_vecs + (size_t)e->medoid * vb, vb, hipMemcpyDeviceToHost));
+  const uint32_t* row = e->h_adj + (size_t)e->medoid * 64;
+  uint32_t deg = 0;
+  while (deg < e->R && deg < 64 && row[deg] != 0xFFFFFFFFu) ++deg;
+  memcpy(me.data() + vb, &deg, 4);
+  memcpy(me.data() + vb + 4, row, (size_t)deg * 4);
+  BANG_TRY(stage_medoid(e, me.data()));
   e->graph_streamed = true;
   return BANG_OK;
 }
@@ -625,6 +670,11 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   e->vec_on_device = false;
   e->pull = false;
   e->graph_streamed = false;
+  if (!e->graph && e->entry_fn == nullptr && e->graph_path.empty() && e->ext_vecs_ready) {
+    BANG_TRY(load_shared(e, e->rows_hash));              // (rows_hash: what the caller said the loading rank reported)
+    e->loaded = true;
+    return BANG_OK;
+  }
   if (!e->graph) {
     // no resident graph: a streamed load (the caller's entry source), or a graph FILE that has not been touched yet.  If the pull
     // mode applies the entries only pass through (vectors -> HBM, adjacency -> pull rows); else a file is mapped as before.
@@ -648,7 +698,8 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       if (from_file) { close(fsrc.fd); e->entry_fn = nullptr; e->entry_ctx = nullptr; }
       if (rc == BANG_OK) { e->loaded = true; return BANG_OK; }
       if (!((from_file || e->entry_src_rereadable) && rc == BANG_ERR_NOMEM && e->pull_opt != 1)) return rc;
-      dfree(e->d_vecs);                               // the rows do not fit this host: keep the graph resident, the walker serves it
+      if (e->vecs_owned) dfree(e->d_vecs);           // the rows do not fit this host: keep the graph resident, the walker serves it
+      e->d_vecs = nullptr; e->vecs_owned = true;
       e->vec_on_device = false;
     }
     if (e->entry_fn) BANG_TRY(materialize_graph(e));  // (a DiskANN `_disk.index`: converted into a private resident copy)
@@ -721,7 +772,8 @@ void unload_index(bang_engine* e) {
   dfree(e->d_seed);
   dfree(e->d_medoid_vec);
   dfree(e->d_graph);
-  dfree(e->d_vecs);
+  if (e->vecs_owned) dfree(e->d_vecs);
+  e->d_vecs = nullptr; e->vecs_owned = true; e->ext_vecs = nullptr; e->ext_vecs_ready = false; e->rows_hash = 0;
   e->vec_on_device = false;
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;

@@ -183,8 +183,40 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
     gm = {"host": bang_amd.GRAPH_HOST, "device": bang_amd.GRAPH_DEVICE, "auto": bang_amd.GRAPH_AUTO}[graph]
     eng = bang_amd.Engine(wl["ix"].dtype, graph=gm, device=ctx.local_rank, lanes=lanes, threads=threads, timing=timing, pull=pull)
 
+    src = getattr(wl["ix"], "entry_source", None)
+    if ctx.world > 1 and wl.get("shared_dir") and src is not None and not os.environ.get("BANG_BENCH_NO_VECTOR_BROADCAST"):
+        # N > 1, streamed index: ONE rank reads the index.  Rank 0 streams it -- adjacency lists into the node's rows file, vectors
+        # into a device buffer of its own -- and hands the vectors on from its HBM (a broadcast: RCCL over xGMI); the other ranks
+        # map the rows file (signature = the hash rank 0 reports) and never touch an index entry (bang_load_shared_e).
+        import ctypes as C
+        import torch
+        ix = wl["ix"]
+        vb = ix.D * (4 if ix.dtype == "float" else 1)
+        os.environ["BANG_PULL_ROWS_DIR"] = wl["shared_dir"]
+        vec = torch.empty(ix.N * vb + 256, dtype=torch.uint8, device=ctx.dev)
+        h = torch.zeros(1, dtype=torch.int64, device=ctx.cdev)
+        t0 = time.time()
+        if ctx.rank == 0:
+            eng.load_stream(ix, src[0], C.byref(src[1]), d_codes=wl["d_codes"], code_stride=getattr(ix, "code_stride", 0), d_vectors=vec.data_ptr())
+            hv_ = eng.rows_hash()
+            h[0] = hv_ - (1 << 64) if hv_ >= (1 << 63) else hv_          # (u64 -> the int64 the collective carries)
+        dist.broadcast(h, 0)
+        t1 = time.time()
+        if ctx.cdev == ctx.dev:
+            dist.broadcast(vec, 0)
+        else:                                    # gloo dry runs: through the host
+            hv = vec.cpu() if ctx.rank == 0 else torch.empty(vec.shape, dtype=torch.uint8)
+            dist.broadcast(hv, 0)
+            if ctx.rank != 0:
+                vec.copy_(hv)
+        torch.cuda.synchronize()
+        if ctx.rank != 0:
+            eng.load_shared(ix, vec.data_ptr(), int(h.item()) & ((1 << 64) - 1), d_codes=wl["d_codes"], code_stride=getattr(ix, "code_stride", 0))
+        wl["_vectors"] = vec                     # (the engines read it until bang_unload)
+        log(f"[bench] rank 0 streamed the index in {t1 - t0:.1f}s, vectors broadcast to {ctx.world - 1} rank(s) in {time.time() - t1:.1f}s")
+        return eng
+
     def load():
-        src = getattr(wl["ix"], "entry_source", None)
         if src is not None:                      # streamed shape index: the engine pulls the generator's entries through in chunks
             import ctypes as C
             eng.load_stream(wl["ix"], src[0], C.byref(src[1]), d_codes=wl["d_codes"], code_stride=getattr(wl["ix"], "code_stride", 0))

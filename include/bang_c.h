@@ -94,6 +94,11 @@ typedef struct {
   const uint32_t* chunk_off; /* [m+1] */
   uint32_t code_stride;      /* d_codes only: bytes between the rows of consecutive nodes, 0 = m (packed).  Host codes are always packed;
                                 the engine lays them out itself (option "code_stride") */
+  uint32_t vectors_ready;    /* bang_load_shared_e: 1 = d_vectors already holds the vectors */
+  void* d_vectors;           /* optional, streamed / shared loads: a DEVICE buffer of the caller, N * D * sizeof(T) + 256 bytes, that holds the
+                                full-precision vectors instead of an allocation of the engine (it must outlive the index).
+                                bang_load_stream_e fills it; the caller may then hand it on to the other GPUs of the node */
+  uint64_t rows_hash;        /* bang_load_shared_e: what bang_get_rows_hash reported on the rank that loaded the index */
 } bang_index_desc;
 int bang_load_mem_e(bang_engine_t* e, const bang_index_desc* desc);
 
@@ -113,6 +118,13 @@ int bang_convert_diskann_index(const char* index_path, const char* out_prefix, i
 
 typedef int (*bang_entry_source)(void* ctx, uint64_t first, uint64_t count, uint8_t* dst);
 int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* desc, bang_entry_source src, void* ctx);
+/* SHARED load, for the ranks of a multi-GPU node that did NOT read the index: the rank that did (bang_load_e / bang_load_stream_e with
+ * desc->d_vectors) has built the node's ONE pull-rows file (BANG_PULL_ROWS_DIR) and holds the full-precision vectors in its HBM; the
+ * others receive the vectors from there (RCCL broadcast over xGMI into their own desc->d_vectors, vectors_ready = 1) and the hash of
+ * the adjacency lists (bang_get_rows_hash), map the rows file and are done -- no index entry is read a second time.  PQ codes as in
+ * every load (desc->codes / d_codes). */
+int bang_load_shared_e(bang_engine_t* e, const bang_index_desc* desc);
+int bang_get_rows_hash(bang_engine_t* e, uint64_t* out);
 
 int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn); /* bang.h:60 */
 int bang_alloc_e(bang_engine_t* e, int num_queries);                                        /* bang.h:53 */

@@ -705,3 +705,44 @@ def test_code_row_stride_does_not_change_results(request, libbang, fixture):
     buf.free()
     with pytest.raises(bang_amd.BangError):
         run(graph=1, code_stride=ix.m - 1)
+
+
+def test_shared_load_from_a_sibling_engines_vectors_and_rows_file(libbang, small_u8, tmp_path, monkeypatch):
+    """bang_load_shared_e: a second engine (standing in for another rank of the node) loads WITHOUT reading an index entry -- the
+    vectors are copied device to device out of the buffer the first engine's streamed load filled (desc->d_vectors), the adjacency
+    rows come from the node's rows file, checked against the hash the first engine reports.  Same answers as the oracle; a wrong
+    hash is refused and leaves the rows file alone."""
+    import bang_amd
+    from bang_amd import binding as B
+    from oracle import oracle as O
+    monkeypatch.setenv("BANG_PULL_ROWS_DIR", str(tmp_path))
+    ix, q, _, _ = small_u8
+    Q, k, L = q.shape[0], 10, 40
+    ids_o, dists_o = O.Oracle(ix).search(q, k, L)
+    vb = ix.D
+    v1 = B.DeviceBuffer(ix.N * vb + 256)
+    v2 = B.DeviceBuffer(ix.N * vb + 256)
+
+    def search(e):
+        e.set_searchparams(k, L)
+        e.alloc(Q)
+        e.init(Q)
+        out = e.query(q)
+        assert e.stats()["graph_pull"] == 1
+        return out
+    with bang_amd.Engine("uint8", graph=0) as e1:
+        e1.load_stream(ix, _entry_source(ix), d_vectors=v1.ptr)
+        h = e1.rows_hash()
+        ids, dists = search(e1)
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        v2.upload(v1.download(np.uint8, (ix.N * vb,)))                  # (the xGMI broadcast of the multi-GPU job)
+        with bang_amd.Engine("uint8", graph=0) as e2:
+            with pytest.raises(bang_amd.BangError):
+                e2.load_shared(ix, v2.ptr, h ^ 1)
+            assert (tmp_path / "index_pull_rows.bin").exists()
+            e2.load_shared(ix, v2.ptr, h)
+            ids2, dists2 = search(e2)
+            assert np.array_equal(ids2, ids_o) and np.array_equal(dists2.view(np.uint32), dists_o.view(np.uint32))
+            with pytest.raises(bang_amd.BangError):                     # nothing but the pull mode can run on such an index
+                e2.free(); e2.set_option("persistent", 0); e2.alloc(Q)
+    v1.free(); v2.free()

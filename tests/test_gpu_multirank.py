@@ -83,6 +83,18 @@ def test_two_ranks_streamed_sift1b_shape_share_one_rows_file(libbang):
         assert c["result_properties_ok"] is True and c["graph"] == "host" and "pulled" in c["host_loop"], c
         assert "STREAMED" in c["workload"] and "N=12000000" in c["workload"]
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    # (rank 1 never read an index entry: it received the vectors from rank 0's device buffer and mapped the rows file -- bang_load_shared_e;
+    # the per-rank stream of round 2 is still reachable)
+    env_old = os.environ.get("BANG_BENCH_NO_VECTOR_BROADCAST")
+    os.environ["BANG_BENCH_NO_VECTOR_BROADCAST"] = "1"
+    try:
+        two_b = _bench(2, args, workload="sift1b_shape", L=40)
+    finally:
+        if env_old is None:
+            os.environ.pop("BANG_BENCH_NO_VECTOR_BROADCAST", None)
+        else:
+            os.environ["BANG_BENCH_NO_VECTOR_BROADCAST"] = env_old
+    assert two_b["config"]["result_properties_ok"] is True
 
 
 def test_two_ranks_sift1b_shape_gathered_batch_equals_oracle(libbang):
