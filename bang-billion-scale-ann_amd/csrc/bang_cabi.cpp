@@ -274,6 +274,7 @@ static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* 
   s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
   s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
   s.code_stride = e->code_stride;
+  s.rows_in_hbm = (s.graph_pull ? e->n_rows_hbm : 0);
   return rc;
 }
 
@@ -337,7 +338,19 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     s.hops_p50 = cc[cc.size() / 2];
     s.hops_p99 = cc[std::min(cc.size() - 1, (cc.size() * 99) / 100)];
     s.hops_max = cc.back();
-    if (s.graph_pull) s.pulled_bytes = (s.candidates - (uint64_t)e->Qcur) * 256;      // one row per expansion (the seed list is on the device)
+    if (s.graph_pull) {                                  // one row per expansion (the seed list is on the device) ...
+      uint64_t pulled = s.candidates - (uint64_t)e->Qcur;
+      if (e->n_rows_hbm) {                               // ... unless the expanded node's row sits in HBM: count the candidate log
+        std::vector<uint32_t> ids((size_t)e->Qcur * e->cand_stride);
+        HIP_TRY(hipMemcpy(ids.data(), e->d_cand_ids, ids.size() * 4, hipMemcpyDeviceToHost));
+        pulled = 0;
+        std::vector<uint32_t> cnt((size_t)e->Qcur);
+        HIP_TRY(hipMemcpy(cnt.data(), e->d_cand_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < (size_t)e->Qcur; ++q)
+          for (uint32_t i = 1; i < cnt[q] && i < e->cand_stride; ++i) pulled += ids[q * e->cand_stride + i] >= e->n_rows_hbm;
+      }
+      s.pulled_bytes = pulled * 256;
+    }
   }
   *out = s;
   return BANG_OK;

@@ -146,7 +146,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.psz = e->psz; sp.mp = e->mp; sp.pq_nhi = e->pq_nhi;
     sp.d_seed = e->d_seed; sp.d_codes = e->d_codes; sp.code_stride = e->code_stride; sp.d_pivots_packed = p.d_pivots_packed; sp.d_qc = p.d_qc;
     sp.d_graph = e->d_graph; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
-    if (!dev_graph) { sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1; }   // pull mode
+    if (!dev_graph) {                                                        // pull mode
+      sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1;
+      sp.d_rows_hbm = e->d_rows_hbm; sp.n_rows_hbm = e->n_rows_hbm;
+    }
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
     sp.d_qskip = e->d_qskip + ln.q0;

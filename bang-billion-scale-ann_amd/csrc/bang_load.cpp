@@ -232,6 +232,31 @@ static int build_pull_rows(bang_engine* e) {
   return pull_rows_finish(e, pr, sig);
 }
 
+// Pull mode, after everything else of the index is in place: HBM the index leaves over takes a copy of the first adjacency rows.
+// The link is the next limiter of the pull mode (SIFT1B-shape: 47-49 of 57 GB/s): every row that sits in HBM is a PCIe read less.
+static int cache_rows_in_hbm(bang_engine* e) {
+  e->n_rows_hbm = 0;
+  if (!e->pull || !e->h_adj || e->rows_hbm_opt == 0) return BANG_OK;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t keep = (size_t)24 << 30;                                   // per-batch state (filters: 50 KB per query) + slack
+  size_t budget = free_b > keep ? free_b - keep : 0;
+  if (e->rows_hbm_opt > 0) budget = std::min(budget, (size_t)e->rows_hbm_opt << 20);
+  size_t n = std::min<size_t>(e->N, budget / 256);
+  // auto: only where the rows do NOT all fit -- an index small enough to sit in HBM whole is on the host because the caller put
+  // it there (graph = host), and graph = auto would have placed it in HBM anyway
+  if (e->rows_hbm_opt < 0 && n >= e->N) return BANG_OK;
+  n = std::min<size_t>(n, (size_t)std::max(0L, env_long("BANG_ROWS_HBM_MAX_ROWS", 1L << 40)));      // (test hook: a partial copy of a small index)
+  if (n < 64) return BANG_OK;
+  if (hipMalloc((void**)&e->d_rows_hbm, n * 256) != hipSuccess) { (void)hipGetLastError(); e->d_rows_hbm = nullptr; return BANG_OK; }
+  const size_t step = (size_t)1 << 30;
+  for (size_t off = 0; off < n * 256; off += step)
+    HIP_TRY(hipMemcpy((uint8_t*)e->d_rows_hbm + off, (const uint8_t*)e->h_adj + off, std::min(step, n * 256 - off), hipMemcpyHostToDevice));
+  e->n_rows_hbm = (uint32_t)n;
+  if (env_flag("BANG_DEBUG")) fprintf(stderr, "[bang] %zu of %u adjacency rows (%.1f GB) also in HBM\n", n, e->N, n * 256 / 1e9);
+  return BANG_OK;
+}
+
 // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501), from the medoid's graph entry
 static int stage_medoid(bang_engine* e, const uint8_t* me) {
   uint32_t deg;
@@ -339,7 +364,7 @@ static int stage_entries_streamed(bang_engine* e, bool retried = false) {
   e->vec_on_device = true;
   BANG_TRY(stage_medoid(e, medoid_entry.data()));
   e->graph_streamed = true;
-  return BANG_OK;
+  return cache_rows_in_hbm(e);
 }
 
 // SHARED load (ranks > 0 of a multi-GPU node): the rank that read the index has written the pull rows file and handed the
@@ -380,7 +405,7 @@ int load_shared(bang_engine* e, uint64_t expect_rows_hash) {
   memcpy(me.data() + vb + 4, row, (size_t)deg * 4);
   BANG_TRY(stage_medoid(e, me.data()));
   e->graph_streamed = true;
-  return BANG_OK;
+  return cache_rows_in_hbm(e);
 }
 
 struct FileEntrySource { int fd; uint64_t entry_len; };
@@ -745,6 +770,7 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
       return BANG_ERR_ARG;
     }
   }
+  if (e->pull) BANG_TRY(cache_rows_in_hbm(e));
   if (e->pull && e->graph_map)
     // nothing reads the mapped graph file while the kernel pulls its rows: let the page cache have the pages back (a later
     // change of the loop form -- "persistent" = 0 -- simply faults them in again)
@@ -775,6 +801,8 @@ void unload_index(bang_engine* e) {
   if (e->vecs_owned) dfree(e->d_vecs);
   e->d_vecs = nullptr; e->vecs_owned = true; e->ext_vecs = nullptr; e->ext_vecs_ready = false; e->rows_hash = 0;
   e->vec_on_device = false;
+  dfree(e->d_rows_hbm);
+  e->n_rows_hbm = 0;
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
   e->graph_path.clear(); e->graph_streamed = false; e->entry_fn = nullptr; e->entry_ctx = nullptr;

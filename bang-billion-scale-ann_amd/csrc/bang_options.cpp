@@ -40,6 +40,9 @@ static const OptionDef kOptions[] = {
      "(the reference's data flow), -1 = auto (1 when the copy fits with 16 GB to spare)"},
     {"pull", "BANG_PULL", &bang_engine::pull_opt, -1, 1, INT, BEFORE_LOAD,
      "host graph: 1 = the search kernel pulls 256-byte adjacency rows from pinned host memory over PCIe, 0 = C++ walker threads serve them, -1 = auto"},
+    {"rows_hbm", "BANG_ROWS_HBM", &bang_engine::rows_hbm_opt, -1, 1 << 22, INT, BEFORE_LOAD,
+     "pull mode: MB of HBM for a copy of the first adjacency rows, read from there instead of over PCIe (-1 = auto: what the index leaves beyond 24 GB, "
+     "where the rows do not all fit; 0 = none)"},
     // ---- loop shape: consumed by bang_alloc
     {"lanes", "BANG_LANES", &bang_engine::lanes_opt, 0, BANG_MAX_LANES, INT, BEFORE_ALLOC, "launch-per-iteration loop: independent query groups pipelined against each other (0 = auto)"},
     {"threads", "BANG_THREADS", &bang_engine::threads_opt, 0, 4096, INT, BEFORE_ALLOC, "host walker threads per lane (0 = auto from the CPU quota)"},
@@ -68,6 +71,7 @@ struct SwitchDef { const char* env; const char* help; };
 static const SwitchDef kSwitches[] = {
     {"BANG_PULL_ROWS_DIR", "directory (tmpfs) every rank of a node can see: ONE pull-rows file per index there, built by the first rank to load, mapped by the others"},
     {"BANG_PULL_ROWS_INTERLEAVE", "0 = leave the pages of a shared pull-rows file where first touch puts them (default 1: interleaved over the NUMA nodes)"},
+    {"BANG_ROWS_HBM_MAX_ROWS", "test hook: cap on the adjacency rows copied to HBM (a partial copy of a small index)"},
     {"BANG_STREAM_LOAD", "0 = bang_load maps <prefix>_disk.bin up front instead of streaming it through (pull mode)"},
     {"BANG_GRAPH_MMAP", "0 = private copy of the graph file (transparent huge pages) instead of a shared read-only mapping"},
     {"BANG_SEARCH_MAX_WGS", "search kernel: cap on workgroups (experiments / tests)"},

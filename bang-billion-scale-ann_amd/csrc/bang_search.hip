@@ -754,7 +754,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // graph resident in HBM: the next adjacency row is requested NOW; it travels while the survivors are merged
       if (want_row) {
         if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
-          n_x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
+          // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those
+          if (parent < p.n_rows_hbm) n_x0 = p.d_rows_hbm[(uint64_t)parent * 64u + lane];
+          else n_x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
           n_cnt = 64u;                                       // counted when the row is consumed
         } else {
           const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);

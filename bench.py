@@ -306,7 +306,7 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         run_once(eng, my_q, ctx, timed=True)
     step_s, init_s, search_s, gather_s = [], [], [], []
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
-                "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride")
+                "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride", "rows_in_hbm")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
                fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0)
     agg.update({kk: 0 for kk in keys_max})
@@ -761,7 +761,7 @@ def main():
                "host_loop": host_loop_name(agg, graph),
                "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                                   "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
-               "vector_dtype": ix.dtype, "pq_code_row_stride_bytes": agg["code_stride"], "batches_per_step": args.batches if weak else 1,
+               "vector_dtype": ix.dtype, "pq_code_row_stride_bytes": agg["code_stride"], "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "batches_per_step": args.batches if weak else 1,
                "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
                "pcie_pulled_bytes_per_step": int(agg["pulled_bytes"] // args.steps),
                "qps_incl_init": res["qps_incl_init"],

@@ -175,6 +175,7 @@ typedef struct {
   uint64_t graph_pull;        /* host-graph placement: 1 = PULL mode -- the adjacency lists live as 256-byte rows in pinned host memory
                                  and the self-paced search kernel fetches them over PCIe by itself (no walker thread in the loop) */
   uint64_t pulled_bytes;      /* pull mode: bytes of adjacency rows the kernel fetched over PCIe (256 per expansion) */
+  uint64_t rows_in_hbm;       /* pull mode: nodes whose adjacency row ALSO sits in HBM (no PCIe read for them), option "rows_hbm" */
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
@@ -343,6 +344,8 @@ typedef struct {
   unsigned long long* d_prof;          /* diagnostic, host-paced form: [G][8] 100 MHz ticks thread 0 of each workgroup spent {waiting for
                                           rows, in the front half up to the publish barrier, publishing, in sort/merge}, [4] = half-rounds; or NULL */
   uint32_t code_stride;                /* bytes between code rows in d_codes; 0 = m (see bang_iter_params) */
+  uint32_t n_rows_hbm;                 /* row_layout = 1: the adjacency rows of the nodes [0, n_rows_hbm) are ALSO in device memory at d_rows_hbm */
+  const uint32_t* d_rows_hbm;          /* [n_rows_hbm][64] u32, or NULL */
   unsigned long long go_timeout_ticks; /* host-paced form: a pacing group that has waited this many 100 MHz ticks for its rows sets *d_abort and
                                           leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the

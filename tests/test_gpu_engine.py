@@ -746,3 +746,37 @@ def test_shared_load_from_a_sibling_engines_vectors_and_rows_file(libbang, small
             with pytest.raises(bang_amd.BangError):                     # nothing but the pull mode can run on such an index
                 e2.free(); e2.set_option("persistent", 0); e2.alloc(Q)
     v1.free(); v2.free()
+
+
+@pytest.mark.parametrize("fixture", ["small_u8", "small_f32"])
+def test_rows_partly_in_hbm_do_not_change_results(request, libbang, fixture, monkeypatch):
+    """Option rows_hbm: in pull mode the adjacency rows of the first nodes also sit in HBM and are read from there; the rest is
+    pulled over PCIe.  Same ids / distances / per-query counters as the oracle; pulled_bytes counts the PCIe rows only."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q, k, L = q.shape[0], 10, 40
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, k, L, with_stats=True)
+
+    def run(**opts):
+        with bang_amd.Engine(ix.dtype, graph=0, **opts) as e:
+            e.load_index(ix)
+            e.set_searchparams(k, L)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+            cnt = e.query_counters(Q)
+            e.free()
+            e.unload()
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        assert np.array_equal(cnt, st_o)
+        return st
+    base = run()                                                    # auto: a small index is left on the host as asked
+    assert base["graph_pull"] == 1 and base["rows_in_hbm"] == 0 and base["pulled_bytes"] == (base["candidates"] - Q) * 256
+    monkeypatch.setenv("BANG_ROWS_HBM_MAX_ROWS", str(ix.N // 3))
+    part = run(rows_hbm=64)
+    assert part["rows_in_hbm"] == ix.N // 3 and 0 < part["pulled_bytes"] < base["pulled_bytes"]
+    monkeypatch.delenv("BANG_ROWS_HBM_MAX_ROWS")
+    full = run(rows_hbm=64)
+    assert full["rows_in_hbm"] == ix.N and full["pulled_bytes"] == 0
