@@ -252,7 +252,7 @@ struct bang_engine {
   bool entry_src_rereadable = false;   // the entry source is ours (a file): placements that need the whole graph may read it all
   const uint32_t* d_adj = nullptr;     // device address of h_adj
   int rows_hbm_opt = -1;               // option "rows_hbm": MB of HBM for a copy of the first adjacency rows (-1 = whatever the index leaves beyond
-                                       // 24 GB -- where the rows do not all fit --, 0 = none): read from HBM instead of pulled over PCIe
+                                       // 12 GB -- where the rows do not all fit --, 0 = none): read from HBM instead of pulled over PCIe
   uint32_t* d_rows_hbm = nullptr;      // [n_rows_hbm][64]
   uint32_t n_rows_hbm = 0;
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
