@@ -162,7 +162,15 @@ extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
   e->Qcap = Q;
   e->Qcur = 0;
   e->cand_stride = (uint32_t)e->L + BANG_EXTRA_ITERS;
-  const int rc = alloc_buffers(e, Q);
+  int rc = alloc_buffers(e, Q);
+  if (rc != BANG_OK && e->d_rows_hbm) {
+    // the copy of the first adjacency rows took the HBM a batch of this size needs: the rows are in host memory anyway
+    free_batch(e);
+    dfree(e->d_rows_hbm);
+    e->n_rows_hbm = 0;
+    (void)hipGetLastError();
+    rc = alloc_buffers(e, Q);
+  }
   if (rc != BANG_OK) { free_batch(e); return rc; }
   e->allocated = true;
   e->inited = false;

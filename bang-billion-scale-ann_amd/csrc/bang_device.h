@@ -226,6 +226,11 @@ struct CoopFetch {
       wave_sync();
     }
     r.w[Row::NX4 * 4] = 0;
+    // every piece register is read once more by ALL lanes: the stores above sit behind `slot < RPI`, so on the other path the
+    // compiler still counts these loads as outstanding and would wait for "them" -- and for every store issued since -- wherever
+    // one of the registers is reused
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" : : "v"(v[j]));
   }
 };
 
@@ -264,6 +269,100 @@ __device__ __forceinline__ float pq_row_reduce(const PqRow<NDW, ALIGNED>& r, con
   return x + y;
 }
 
+
+// The same reduce as a two-stage software pipeline over groups of 8 chunks: the pivot entries of group g+1 are requested from LDS
+// before the arithmetic of group g starts.  Left to itself the scheduler keeps four LDS reads in flight and waits for the first right
+// behind the fourth (it schedules for register pressure): 18 exposed LDS round trips per 72-chunk row, ~1.7 us per iteration of a
+// wave that has its SIMD to itself.  A group is 8 chunks so that every partial sum s[l] takes exactly one term per group: the
+// canonical order (s_l = ((t_l + t_{l+8}) + t_{l+16}) ...) is the plain one (groups of 4 or 2 chunks for the wider entries: the
+// partial sums still take their terms in chunk order).
+template <int PSZ, int NHI>
+struct PivEntry {                                       // one LUT entry's pivot floats (PSZ = 1, 2 or 4 per read; PSZ = 8: two halves)
+  float v[PSZ];
+};
+template <int PSZ, int NHI>
+__device__ __forceinline__ void piv_entry_load(PivEntry<PSZ, NHI>& e, const float* __restrict__ piv_lds, uint32_t c, uint32_t code) {
+  if (PSZ == 2 && NHI > 0) {
+    if (c < (uint32_t)NHI) { const float2 p = *(const float2*)(piv_lds + c * 512u + code * 2u); e.v[0] = p.x; e.v[1] = p.y; }
+    else { e.v[0] = piv_lds[(uint32_t)NHI * 256u + c * 256u + code]; e.v[1] = 0.0f; }
+    return;
+  }
+  const float* a = piv_lds + ((size_t)c * 256 + code) * PSZ;
+  if (PSZ == 1) e.v[0] = a[0];
+  else if (PSZ == 2) { const float2 p = *(const float2*)a; e.v[0] = p.x; e.v[1] = p.y; }
+  else {
+#pragma unroll
+    for (int i = 0; i < PSZ; i += 4) { const float4 p = *(const float4*)(a + i); e.v[i] = p.x; e.v[i + 1] = p.y; e.v[i + 2] = p.z; e.v[i + 3] = p.w; }
+  }
+}
+template <int PSZ, int NHI, class QC>
+__device__ __forceinline__ float piv_entry_eval(const PivEntry<PSZ, NHI>& e, const QC& qc, uint32_t c) {     // == lut_entry()
+  float t = 0.0f;
+  constexpr int ND = PSZ;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    if (PSZ == 2 && NHI > 0 && i == 1 && c >= (uint32_t)NHI) break;                   // 1-dim chunk of the exact-size table
+    const float d = qc_sub(qc, e.v[i], c * PSZ + i);
+    t = __builtin_fmaf(d, d, t);
+  }
+  return t;
+}
+template <int N>
+__device__ __forceinline__ void reg_fence(float* v) {   // an empty asm every value passes through: what is computed from them comes after it
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+template <int PSZ, int NDW, bool ALIGNED, int NHI, class QC = cfloat_p>
+__device__ __forceinline__ float pq_row_reduce_pipe(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds, const QC& qc) {
+  constexpr int G = PSZ <= 2 ? 8 : PSZ == 4 ? 4 : 2;    // chunks per group: <= 16 pivot floats per lane and group
+  constexpr int NC = 4 * NDW;
+  constexpr int NG = (NC + G - 1) / G;
+  float s[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) s[l] = 0.0f;
+  PivEntry<PSZ, NHI> e[2][G];
+  uint32_t* w = const_cast<uint32_t*>(r.w);
+  auto load_group = [&](int g, PivEntry<PSZ, NHI>* dst) {
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = g * G + j;
+      if (c < NC) {
+        const int k = c >> 2;
+        const uint32_t dw = ALIGNED ? w[k] : __builtin_amdgcn_alignbyte(w[k + 1], w[k], r.sh);
+        piv_entry_load<PSZ, NHI>(dst[j], piv_lds, (uint32_t)c, (dw >> (8 * (c & 3))) & 0xffu);
+      }
+    }
+  };
+  // the fence in front of group g's arithmetic: the partial sums, the entries of group g (their reads have returned) and the code
+  // dwords group g+1 is addressed with all pass through it -- the reads of group g+1 cannot be issued earlier (two groups of entries
+  // live at a time, not the whole row's) and nothing of group g is computed before its entries are there
+  auto fence = [&](int g) {
+    reg_fence<8>(s);
+    if (g < NG) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) reg_fence<PSZ>(e[g & 1][j].v);
+    }
+#pragma unroll
+    for (int c = (g + 1) * G; c < (g + 2) * G && c < NC; c += 4) {
+      asm volatile("" : "+v"(w[c >> 2]));
+      if (!ALIGNED) asm volatile("" : "+v"(w[(c >> 2) + 1]));
+    }
+  };
+  load_group(0, e[0]);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    fence(g);
+    if (g + 1 < NG) load_group(g + 1, e[(g + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int c = g * G + j;
+      if (c < NC) s[c & 7] = s[c & 7] + piv_entry_eval<PSZ, NHI>(e[g & 1][j], qc, (uint32_t)c);
+    }
+  }
+  const float x = (s[0] + s[1]) + (s[2] + s[3]);
+  const float y = (s[4] + s[5]) + (s[6] + s[7]);
+  return x + y;
+}
 
 __device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732
   uint32_t lo = 0;

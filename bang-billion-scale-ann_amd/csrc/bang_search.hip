@@ -98,8 +98,12 @@ __device__ __forceinline__ void wave_min_key(uint32_t& hi, uint32_t& lo) {
 // under another tag (rare: ~0.3 per iteration) has its bit merged into the owner's store through the same slot.  Nothing needs
 // initialising: whoever reads a slot has just written it, so its content is this round's.  Returns with every item stored,
 // merged into another lane's store, or (pa / pb still set; ~0.03 per iteration) left for the atomic fallback.
-__device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint32_t* tbl, int lane, bool& pa, uint32_t ia,
-                                              uint32_t ba, uint32_t wa, bool& pb, uint32_t ib, uint32_t bb, uint32_t wb) {
+// The stores themselves are left to the caller (st_a / st_b: this lane stores va / vb to word ia / ib): issued here they would sit
+// between the code-row loads already in flight and the wait for those rows, and that wait would then cover their acknowledgements too
+// (one counter for loads and stores on this target).
+__device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa, uint32_t ia, uint32_t ba, uint32_t wa, bool& pb,
+                                              uint32_t ib, uint32_t bb, uint32_t wb, bool& st_a, uint32_t& out_a, bool& st_b,
+                                              uint32_t& out_b) {
   const uint32_t tag_a = (ia << 7) | ((uint32_t)lane << 1), tag_b = (ib << 7) | ((uint32_t)lane << 1) | 1u;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -125,8 +129,8 @@ __device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint
       if (own_b) vb = tbl[sb];
       wave_sync();
     }
-    if (own_a && (wa | va) != wa) bloom[ia] = wa | va;      // (a survivor has at most one of its two bits set already: that store is moot)
-    if (own_b && (wb | vb) != wb) bloom[ib] = wb | vb;
+    if (own_a && (wa | va) != wa) { st_a = true; out_a = wa | va; }      // (a survivor has at most one of its two bits set already: that store is moot)
+    if (own_b && (wb | vb) != wb) { st_b = true; out_b = wb | vb; }
     pa = pa && !(own_a || same_a);
     pb = pb && !(own_b || same_b);
   }
@@ -146,6 +150,17 @@ __device__ __forceinline__ void filter_commit(uint32_t* __restrict__ bloom, uint
 // through 128 words of the wave's LDS scratch, two registers per pass (ds_or_b32), and OR-ed into the registers.
 #ifndef BANG_FILTER_SUMMARY
 #define BANG_FILTER_SUMMARY 1
+#endif
+// the row reduce as a software pipeline over groups of 8 chunks (pq_row_reduce_pipe): search kernel / K2 streaming kernel
+// the filter's stores issued behind the arrival of the code rows instead of in front of the wait for them
+#ifndef BANG_FILTER_STORES_LATE
+#define BANG_FILTER_STORES_LATE 1
+#endif
+#ifndef BANG_REDUCE_PIPE
+#define BANG_REDUCE_PIPE 1
+#endif
+#ifndef BANG_K2_REDUCE_PIPE
+#define BANG_K2_REDUCE_PIPE 0
 #endif
 #define SUMM_REGS 6
 struct FilterSummary {
@@ -673,9 +688,16 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
-      {
-        bool pa = pass0, pb = pass0;
-        filter_commit(bloom, tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b);
+      // The claim rounds run now, on LDS, while the code rows travel; the stores they decide on are issued once the rows are here.
+      bool pa = pass0, pb = pass0, st_a = false, st_b = false;
+      uint32_t sv_a = 0, sv_b = 0;
+      filter_commit(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+      // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
+      if (SUMM) summ.set(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+      auto filter_stores = [&]() {
+        asm volatile("" ::: "memory");
+        if (st_a) bloom[h0a >> 5] = sv_a;
+        if (st_b) bloom[h0b >> 5] = sv_b;
         const uint64_t left = __ballot(pa || pb || pass1);
         if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
@@ -686,18 +708,27 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
             (void)__hip_atomic_fetch_or(&bloom[h1b >> 5], 1u << (h1b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        // the words just stored to are no longer zero (only those the summary did not know yet need marking)
-        if (SUMM) summ.set(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
-      }
+      };
+      if (!BANG_FILTER_STORES_LATE || !EARLY_ROWS) filter_stores();
 
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
         if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
         if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
+        if (BANG_FILTER_STORES_LATE && EARLY_ROWS) {
+          // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
+          // for them): now the filter stores -- their acknowledgements are not waited for until the next row is needed
+          if (!COOP) {
+#pragma unroll
+            for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4 * 4; ++i) asm volatile("" : "+v"(row.w[i]));
+          }
+          filter_stores();
+        }
         if ((uint32_t)lane < n) {
           if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
-          d0 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
+          d0 = (BANG_REDUCE_PIPE && !HOST) ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
+                                           : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
         if (n > 64) {                                          // survivor 64 (seed list only), lane 0
           if (lane == 0) {
@@ -976,7 +1007,8 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
     // all lanes, full EXEC (v_readlane / DPP read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
     asm volatile("s_nop 4");
     if (COOP) raw[r].collect(row[0], coop_buf, stride, ids[s], lane);
-    const float d = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[COOP ? 0 : r], piv_lds, qc[s]);
+    const float d = BANG_K2_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row[COOP ? 0 : r], piv_lds, qc[s])
+                                        : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[COOP ? 0 : r], piv_lds, qc[s]);
     if ((uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) p.d_dist[(size_t)qq[s] * BANG_NBR_STRIDE + lane] = d;
     return true;
   };

@@ -138,6 +138,23 @@ class ShapeIndex:
         return self.D * (4 if self.dtype == "float" else 1) + 4 + 4 * self.R
 
 
+class _RawDev:
+    """a device allocation made with hipExtMallocWithFlags, visible to torch through __cuda_array_interface__ (never freed: experiments)"""
+
+    def __init__(self, nbytes, flags):
+        hip = C.CDLL("libamdhip64.so")
+        p = C.c_void_p()
+        rc = hip.hipExtMallocWithFlags(C.byref(p), C.c_size_t(nbytes), C.c_uint(flags))
+        if rc != 0 or not p.value:
+            raise MemoryError(f"hipExtMallocWithFlags({nbytes}, {flags:#x}) -> {rc}")
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (p.value, False), "version": 2}
+
+
+def _raw_device_bytes(nbytes, flags, dev):
+    import torch
+    return torch.as_tensor(_RawDev(nbytes, flags), device=dev)
+
+
 def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes=False, shared=None, reserve_rows=True,
          stream=False, planned=False):
     """host_codes=True: the PQ codes are generated in HOST memory too (ix.codes, uploaded by bang_load) so that the CPU oracle
@@ -227,7 +244,10 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         codes = None
         log(f"[shape] {N * m / 2**30:.1f} GiB of PQ codes generated in host memory in {time.time() - t0:.1f}s")
     else:                               # PQ codes straight on the device
-        codes = torch.empty(N * cs + 256, dtype=torch.uint8, device=dev)       # (uniform random bytes: the padding behind a row too)
+        if os.environ.get("SHAPE_CODES_MEMFLAGS"):      # experiment (tools/dev): the code table in memory of another type (hipExtMallocWithFlags)
+            codes = _raw_device_bytes(N * cs + 256, int(os.environ["SHAPE_CODES_MEMFLAGS"], 0), dev)
+        else:
+            codes = torch.empty(N * cs + 256, dtype=torch.uint8, device=dev)   # (uniform random bytes: the padding behind a row too)
         step = 1 << 28
         g = torch.Generator(device=dev)
         g.manual_seed(seed + 7)
