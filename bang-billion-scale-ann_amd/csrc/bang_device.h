@@ -202,9 +202,11 @@ struct CoopFetch {
       const uint32_t rr = (uint32_t)j * RPI + slot;                                       // the row (= lane number of its evaluator)
       const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr & 63u) << 2), (int)id);
       const bool ok = slot < (uint32_t)RPI && rr < n;
-      const uint64_t a = (uint64_t)rid * stride;
-      const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + piece;
-      v[j] = ok ? *p : u32x4a{0u, 0u, 0u, 0u};
+      // a lane with no row to fetch reads row 0 instead of sitting the instruction out: a load under a branch makes the compiler's
+      // count of outstanding memory operations inexact, and every later wait for an OLDER load then becomes a wait for everything
+      const uint64_t a = ok ? (uint64_t)rid * stride : 0ull;
+      const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + (ok ? piece : 0u);
+      v[j] = *p;
     }
   }
   __device__ __forceinline__ void collect(Row& r, uint32_t* buf /* LDS_WORDS words of the wave's LDS, 16-byte aligned */, uint32_t stride,

@@ -981,19 +981,22 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
   uint32_t ids[SD], cnt[SD], qq[SD];
   bool has[SD];
   uint32_t qnext = q;
+  // Every load of the pipeline is issued unconditionally -- behind the last row of this wave the slots re-read its FIRST row, a lane
+  // without a neighbour reads code row 0 -- so that the compiler's count of outstanding loads is exact and a step waits for the rows
+  // requested one step earlier, not for the ones it has just requested (one load under a branch and every wait becomes vmcnt(0)).
   auto load_ids = [&](int s) {
     has[s] = qnext < p.Q;
-    if (has[s]) {
-      qq[s] = qnext;
-      cnt[s] = p.d_cnt[qnext];                        // (same address in every lane: no readfirstlane, which would wait for the load here)
-      ids[s] = p.d_nbrs[(size_t)qnext * BANG_NBR_STRIDE + lane];
-      load_qc(qc[s], qnext);
-    }
+    const uint32_t qv = has[s] ? qnext : q;
+    qq[s] = qv;
+    cnt[s] = p.d_cnt[qv];                             // (same address in every lane: no readfirstlane, which would wait for the load here)
+    ids[s] = p.d_nbrs[(size_t)qv * BANG_NBR_STRIDE + lane];
+    load_qc(qc[s], qv);
     qnext += step;
   };
   auto load_rows = [&](int s, int r) {
-    if (COOP) { if (has[s]) raw[r].issue(p.d_codes, stride, ids[s], cnt[s] < 64u ? cnt[s] : 64u, lane); }     // (has[] is uniform)
-    else if (has[s] && (uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) pq_row_load(row[r], p.d_codes, stride, ids[s]);
+    const uint32_t nn = cnt[s] < 64u ? cnt[s] : 64u;
+    if (COOP) raw[r].issue(p.d_codes, stride, ids[s], nn, lane);
+    else pq_row_load(row[r], p.d_codes, stride, (uint32_t)lane < nn ? ids[s] : 0u);
   };
 #pragma unroll
   for (int i = 0; i < RD; ++i) load_ids(i);
