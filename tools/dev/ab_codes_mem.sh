@@ -4,7 +4,7 @@
 cd /root/repo
 mkdir -p gpurun_out/abmem
 for wl in deep100m_shape sift1b_shape; do
-  for fl in "" 0x3 0x1; do
+  for fl in ${FLAGS:-"" 0x3 0x1}; do
     tag=${wl}_${fl:-plain}
     SHAPE_CODES_MEMFLAGS=$fl timeout 900 python3 bench.py --workload $wl --no-legs --steps 6 --warmup 2 > gpurun_out/abmem/$tag.json 2> gpurun_out/abmem/$tag.err
     python3 - $tag <<'PY'
