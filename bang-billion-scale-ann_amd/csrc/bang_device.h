@@ -197,14 +197,18 @@ struct CoopFetch {
   // id: the row this lane will evaluate (valid for lane < n); every lane of the wave must be executing
   __device__ __forceinline__ void issue(const uint8_t* __restrict__ codes, uint32_t stride, uint32_t id, uint32_t n, int lane) {
     const uint32_t slot = (uint32_t)lane / (uint32_t)P, piece = (uint32_t)lane % (uint32_t)P;
+    // all the ids first (NI independent ds_bpermute in flight), then the loads: interleaved, every load waits for its own id's round
+    // trip through the LDS crossbar
+    uint32_t rid[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) rid[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)j * RPI + slot) & 63u) << 2), (int)id);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const uint32_t rr = (uint32_t)j * RPI + slot;                                       // the row (= lane number of its evaluator)
-      const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr & 63u) << 2), (int)id);
       const bool ok = slot < (uint32_t)RPI && rr < n;
       // a lane with no row to fetch reads row 0 instead of sitting the instruction out: a load under a branch makes the compiler's
       // count of outstanding memory operations inexact, and every later wait for an OLDER load then becomes a wait for everything
-      const uint64_t a = ok ? (uint64_t)rid * stride : 0ull;
+      const uint64_t a = ok ? (uint64_t)rid[j] * stride : 0ull;
       const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + (ok ? piece : 0u);
       v[j] = *p;
     }

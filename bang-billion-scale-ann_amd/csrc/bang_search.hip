@@ -101,6 +101,7 @@ __device__ __forceinline__ void wave_min_key(uint32_t& hi, uint32_t& lo) {
 // The stores themselves are left to the caller (st_a / st_b: this lane stores va / vb to word ia / ib): issued here they would sit
 // between the code-row loads already in flight and the wait for those rows, and that wait would then cover their acknowledgements too
 // (one counter for loads and stores on this target).
+template <int SLOTS>                                   // claim table slots (a power of two: 128, or 256 where the wave's scratch has them)
 __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa, uint32_t ia, uint32_t ba, uint32_t wa, bool& pb,
                                               uint32_t ib, uint32_t bb, uint32_t wb, bool& st_a, uint32_t& out_a, bool& st_b,
                                               uint32_t& out_b) {
@@ -109,7 +110,7 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
   for (int r = 0; r < 3; ++r) {
     if (__ballot(pa || pb) == 0) break;                          // uniform
     const uint32_t mul = r == 0 ? 0x9E37u : r == 1 ? 0x85EBu : 0xC2B3u;
-    const uint32_t sa = ((ia * mul) >> 9) & 127u, sb = ((ib * mul) >> 9) & 127u;
+    const uint32_t sa = ((ia * mul) >> 9) & (uint32_t)(SLOTS - 1), sb = ((ib * mul) >> 9) & (uint32_t)(SLOTS - 1);
     if (pa) tbl[sa] = tag_a;
     if (pb) tbl[sb] = tag_b;                                      // a later instruction: wins over this lane's own item a
     wave_sync();
@@ -147,7 +148,7 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 // Layout: 12 288 bits in SIX VGPRs of the owning wave -- word w lives in lane (w & 63), position p = w >> 6 (0..195; the 209 words
 // with p >= 192 share the positions p - 192: a set bit then also covers an alias, which only costs that word its shortcut),
 // register p >> 5, bit p & 31.  Read: six ds_bpermute (no LDS memory touched) + selects.  Set: the survivors' bits are transposed
-// through 128 words of the wave's LDS scratch, two registers per pass (ds_or_b32), and OR-ed into the registers.
+// through 128 (256) words of the wave's LDS scratch, two (four) registers per pass (ds_or_b32), and OR-ed into the registers.
 #ifndef BANG_FILTER_SUMMARY
 #define BANG_FILTER_SUMMARY 1
 #endif
@@ -182,24 +183,34 @@ struct FilterSummary {
     }
     return ((v >> (p & 31u)) & 1u) != 0u;
   }
-  // mark up to three words per lane (a, b: this lane's survivor; c: the 65th id of the seed list, lane 0) as stored to
-  __device__ __forceinline__ void set(uint32_t* tbl /* 128 LDS words of the wave */, int lane, bool ha, uint32_t wa, bool hb, uint32_t wb,
+  // mark up to three words per lane (a, b: this lane's survivor; c: the 65th id of the seed list, lane 0) as stored to.
+  // RP = summary registers transposed per pass = words of LDS scratch / 64: 2 (three passes), or 4 where the wave has 256 words (two)
+  template <int RP>
+  __device__ __forceinline__ void set(uint32_t* tbl /* 64 RP LDS words of the wave */, int lane, bool ha, uint32_t wa, bool hb, uint32_t wb,
                                       bool hc, uint32_t wc0, uint32_t wc1) {
     const uint32_t pa = pos_of(wa), pb = pos_of(wb), pc0 = pos_of(wc0), pc1 = pos_of(wc1);
 #pragma unroll
-    for (int pass = 0; pass < SUMM_REGS / 2; ++pass) {
-      const bool ia = ha && (pa >> 6) == (uint32_t)pass, ib = hb && (pb >> 6) == (uint32_t)pass;
-      const bool ic0 = hc && (pc0 >> 6) == (uint32_t)pass, ic1 = hc && (pc1 >> 6) == (uint32_t)pass;
+    for (int pass = 0; pass < (SUMM_REGS + RP - 1) / RP; ++pass) {
+      const bool ia = ha && (pa >> 5) / RP == (uint32_t)pass, ib = hb && (pb >> 5) / RP == (uint32_t)pass;
+      const bool ic0 = hc && (pc0 >> 5) / RP == (uint32_t)pass, ic1 = hc && (pc1 >> 5) / RP == (uint32_t)pass;
       if (__ballot(ia || ib || ic0 || ic1) == 0) continue;                         // uniform
-      *(uint2*)(tbl + 2 * lane) = make_uint2(0u, 0u);
+      if (RP == 2) *(uint2*)(tbl + 2 * lane) = make_uint2(0u, 0u);
+      else *(uint4*)(tbl + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
       wave_sync();
-      if (ia) (void)__hip_atomic_fetch_or(&tbl[(wa & 63u) * 2u + ((pa >> 5) & 1u)], 1u << (pa & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (ib) (void)__hip_atomic_fetch_or(&tbl[(wb & 63u) * 2u + ((pb >> 5) & 1u)], 1u << (pb & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (ic0) (void)__hip_atomic_fetch_or(&tbl[(wc0 & 63u) * 2u + ((pc0 >> 5) & 1u)], 1u << (pc0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (ic1) (void)__hip_atomic_fetch_or(&tbl[(wc1 & 63u) * 2u + ((pc1 >> 5) & 1u)], 1u << (pc1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ia) (void)__hip_atomic_fetch_or(&tbl[(wa & 63u) * RP + ((pa >> 5) % RP)], 1u << (pa & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ib) (void)__hip_atomic_fetch_or(&tbl[(wb & 63u) * RP + ((pb >> 5) % RP)], 1u << (pb & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ic0) (void)__hip_atomic_fetch_or(&tbl[(wc0 & 63u) * RP + ((pc0 >> 5) % RP)], 1u << (pc0 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (ic1) (void)__hip_atomic_fetch_or(&tbl[(wc1 & 63u) * RP + ((pc1 >> 5) % RP)], 1u << (pc1 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       wave_sync();
-      const uint2 v = *(const uint2*)(tbl + 2 * lane);
-      s[2 * pass] |= v.x; s[2 * pass + 1] |= v.y;
+      if (RP == 2) {
+        const uint2 v = *(const uint2*)(tbl + 2 * lane);
+        s[2 * pass] |= v.x; s[2 * pass + 1] |= v.y;
+      } else {
+        const uint4 v = *(const uint4*)(tbl + 4 * lane);
+        s[4 * pass] |= v.x; s[4 * pass + 1] |= v.y;
+        if (4 * pass + 2 < SUMM_REGS) s[4 * pass + 2] |= v.z;
+        if (4 * pass + 3 < SUMM_REGS) s[4 * pass + 3] |= v.w;
+      }
       wave_sync();
     }
   }
@@ -331,6 +342,7 @@ __device__ __forceinline__ uint32_t sort_and_merge(const WaveLds& s, uint32_t n,
                                                    int lane) {
   if (iter > 1 && w_n == L && n <= 64) {
     const uint64_t m_in = __ballot((uint32_t)lane < n && d0 < worst);
+    if (m_in == 0) return L;                                       // nobody enters: the merge is the identity (a parent taken from the survivors enters)
     if ((uint32_t)__popcll(m_in) <= L) {                           // (more than L entering survivors: only with L < 64; general path)
       const uint32_t wlr = (L + WAVE - 1) / WAVE;
       if (wlr <= 1) merge_few<1>(s, m_in, d0, id0, L, mark, lane);
@@ -691,9 +703,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // The claim rounds run now, on LDS, while the code rows travel; the stores they decide on are issued once the rows are here.
       bool pa = pass0, pb = pass0, st_a = false, st_b = false;
       uint32_t sv_a = 0, sv_b = 0;
-      filter_commit(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+      filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
       // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-      if (SUMM) summ.set(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+      if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
         if (st_a) bloom[h0a >> 5] = sv_a;
