@@ -203,7 +203,9 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
         dist.broadcast(h, 0)
         t1 = time.time()
         if ctx.cdev == ctx.dev:
-            dist.broadcast(vec, 0)
+            step_b = 1 << 32                     # (4 GB per call: a 121 GB count in one collective has never been exercised here)
+            for a in range(0, vec.numel(), step_b):
+                dist.broadcast(vec[a:a + step_b], 0)
         else:                                    # gloo dry runs: through the host
             hv = vec.cpu() if ctx.rank == 0 else torch.empty(vec.shape, dtype=torch.uint8)
             dist.broadcast(hv, 0)

@@ -38,4 +38,10 @@ done
 } > gpurun_out/profiles_out/${R}_shard_sweep_sift1b.md
 cat gpurun_out/profiles_out/${R}_shard_sweep_sift1b.md
 ./tools/dev/row_fetch_bench > gpurun_out/profiles_out/${R}_row_fetch_bench.jsonl 2>/dev/null
+# per-iteration phase times (diagnostic build in lib_prof: make OUT=lib_prof EXTRA_CXXFLAGS=-DBANG_SEARCH_PHASE_PROF)
+if [ -f bang-billion-scale-ann_amd/lib_prof/libbang.so ]; then
+  { echo "# search_kernel: where an iteration's time goes (s_memrealtime stamps of wave 0 of every workgroup, diagnostic build -DBANG_SEARCH_PHASE_PROF, BANG_SEARCH_PROF=1)"; echo;
+    echo '`tools/dev/phase_prof.sh`: bench.py --no-legs --steps 3 per configuration; us per iteration; "Q" = queries in the batch (10 000 = the bench batch, 1 250 = one rank'"'"'s shard of 8).'; echo;
+    bash tools/dev/phase_prof.sh 2>&1 | sed 's/^==/\n##/' ; } > gpurun_out/profiles_out/${R}_phase_profile.md
+fi
 ls gpurun_out/profiles_out | wc -l

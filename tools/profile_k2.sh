@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the PQ-distance stage ALONE (K2, compute_neighborDist_par, bang_search.cu:1201-1241):
-#   tools/k2_alone.py --big = bang_k_pqdist_stream over 40 M (query, neighbour) pairs per launch on a 4 GB code table, m = 32 / 70 / 74.
+#   tools/k2_alone.py --big = bang_k_pqdist_stream over 40 M (query, neighbour) pairs per launch on a 4 GB code table, m = 32 / 70 / 74
+#   (packed and 128-byte rows): 16 launches per layout, the first 6 are warm-up.
 # Pass 1: kernel trace + stats; pass 2: FETCH_SIZE; pass 3: L2 hit / miss / requests; passes 4-5: SQ wait/busy split, instruction mix, LDS conflicts.  Output: gpurun_out/profiles_out/<tag>_k2_alone.md
 set -u
 TAG=${1:-r03}
@@ -15,10 +16,11 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS
 python3 - "$OUT" > gpurun_out/profiles_out/${TAG}_k2_alone.md <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]
+NL, WARM = 16, 6          # launches per layout in tools/k2_alone.py --big (bench.k2_alone: 6 warm-up + reps = 10 timed)
 LAYOUTS = ("32", "70", "70 (rows 128 B apart)", "74", "74 (rows 128 B apart)")
 print("# K2 alone (bang_k_pqdist_stream: pqdist_stream_kernel) under rocprofv3\n")
-print("`tools/k2_alone.py --big`: 40 M (query, neighbour) pairs per launch, random rows of a 4 GB code table, 12 launches per layout and row stride "
-      "(2 warm-up + 10 timed with HIP events).  Algorithmic bytes per evaluation = m + 8 (SURVEY 8(d)).\n")
+print("`tools/k2_alone.py --big`: 40 M (query, neighbour) pairs per launch, random rows of a 4 GB code table, 16 launches per layout and row stride "
+      "(6 warm-up + 10 timed with HIP events).  Algorithmic bytes per evaluation = m + 8 (SURVEY 8(d)).\n")
 print("## the tool's own lines (HIP events), un-profiled pass = the kernel-trace pass\n")
 for l in open(os.path.join(out, "k2_trace.jsonl")):
     if l.startswith("{"):
@@ -30,11 +32,11 @@ f = glob.glob(os.path.join(out, "trace/**/*kernel_trace.csv"), recursive=True)
 if f:
     rows = [r for r in csv.DictReader(open(f[0])) if "pqdist_stream_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    print("## rocprofv3 --kernel-trace: launches of pqdist_stream_kernel, in order (12 per layout: m = 32, 70, 70 at stride 128, 74, 74 at stride 128)\n")
+    print("## rocprofv3 --kernel-trace: launches of pqdist_stream_kernel, in order (16 per layout: m = 32, 70, 70 at stride 128, 74, 74 at stride 128)\n")
     print("| layout | launches | avg us (last 10) | min us | max us | kernel |")
     print("|---|---|---|---|---|---|")
     for i, m in enumerate(LAYOUTS):
-        grp = rows[i * 12:(i + 1) * 12][2:]
+        grp = rows[i * NL:(i + 1) * NL][WARM:]
         if not grp:
             continue
         du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp]
@@ -53,7 +55,7 @@ for name, label in (("pmc_fetch", "FETCH_SIZE (KB; raw -- random 32-74-byte rows
     print("| layout | counter | avg per launch |")
     print("|---|---|---|")
     for i, m in enumerate(LAYOUTS):
-        keep = set(ids[i * 12:(i + 1) * 12][2:])
+        keep = set(ids[i * NL:(i + 1) * NL][WARM:])
         agg = {}
         for r in rows:
             if int(r["Dispatch_Id"]) in keep:
