@@ -28,6 +28,9 @@ One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
 A "step" = one bang_query over the whole batch.  bang_init (visited-filter / worklist reset) is outside the timed bracket,
 exactly as in the reference harness (BANG_Base/test_driver.cpp:432-439); the init-inclusive rate is reported beside it.  Every
 step is bracketed by barrier + cuda.synchronize on both sides and the MAX over ranks is taken.
+
+roofline.traffic (N = 1, default run): HBM bytes per launch of the search kernel, measured by two child runs of the primary
+configuration under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE: separate passes) before this process touches the GPU -- live_traffic().
 """
 import argparse
 import ctypes as C
@@ -354,12 +357,16 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         achieved = evals_per_launch * bpe / (avg_ms * 1e-3) / 1e9
         traffic, traffic_note = None, None
         tf = os.path.join(ROOT, "profiles", f"traffic_{traffic_key}.json") if traffic_key else None
-        if tf and os.path.exists(tf) and ctx.world == 1:
+        live = getattr(ctx, "live_traffic", None) if traffic_key and traffic_key == getattr(ctx, "live_traffic_key", None) else None
+        if live and live.get("bytes") and persistent:
+            traffic, traffic_note = live["bytes"], live["note"]
+        elif tf and os.path.exists(tf) and ctx.world == 1:
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch")
                 traffic_note = (f"HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
-                                f"(profiles/traffic_{traffic_key}.json: FETCH_SIZE + WRITE_SIZE, separate passes) -- NOT re-measured in this run")
+                                f"(profiles/traffic_{traffic_key}.json: FETCH_SIZE + WRITE_SIZE, separate passes) -- NOT re-measured in this run"
+                                + (f" ({live['note']})" if live and not live.get("bytes") else ""))
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -556,6 +563,8 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
         run_once(eng, my_q, ctx)
         graph = "device" if eng.stats()["graph_mode"] == 1 else "host"
         placement_note = f"auto -> {graph} (engine default: graph in HBM when it fits next to the PQ codes with 16 GB to spare)"
+    if getattr(ctx, "live_primary", False):              # the configuration main()'s live PMC passes measured
+        ctx.live_traffic_key, ctx.live_primary = f"{name}_{graph}", False
     res = measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=(f"{name}_{graph}" if traffic else None),
                   batches=batches if weak else 1)
     orc = None
@@ -663,6 +672,62 @@ def cpu_baseline_shape(name, ctx, args, O, L):
             "hip_ids_equal_oracle_on_sample": parity}
 
 
+# ---------------------------------------------------------------------------------------------------------- HBM traffic, live
+def live_traffic(args, log):
+    """roofline.traffic measured in THIS run: two child runs of this very command (primary workload only, 3 timed steps) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes
+    (FETCH_SIZE raw: the launch reads random 4-128-byte pieces as 64-byte requests, the x2 correction for wide coalesced reads
+    does not apply).  The children run and exit BEFORE this process initialises the GPU (they need the HBM the parent would hold).
+    Returns {bytes per launch, note} or {None, why}."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"bytes": None, "note": "rocprofv3 is not on PATH"}
+    steps = 3
+    child = ["python3", os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--steps", str(steps), "--warmup", "1", "--no-legs",
+             "--no-cpu-baseline", "--pull", str(args.pull)]
+    for flag, val in (("--graph", args.graph), ("--L", args.L), ("--queries", args.queries), ("--shape-n", args.shape_n),
+                      ("--lanes", args.lanes), ("--threads", args.threads)):
+        if val:
+            child += [flag, str(val)]
+    if args.resident_graph:
+        child.append("--resident-graph")
+    env = dict(os.environ, BANG_BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
+    got, launch_us = {}, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bang_pmc_", dir="/tmp")
+        t0 = time.time()
+        try:
+            pr = subprocess.Popen(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                                  cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                so, _ = pr.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)            # (the session this call started: nothing else is in it)
+                pr.communicate()
+                return {"bytes": None, "note": f"the {counter} pass did not finish in 240 s"}
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            rows = [r for r in csv.DictReader(open(f[0]))] if f else []
+            sel = [r for r in rows if "search_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            ids = sorted({int(r["Dispatch_Id"]) for r in sel})[-steps:]                # the timed launches
+            if pr.returncode != 0 or len(ids) < steps:
+                return {"bytes": None, "note": f"the {counter} pass failed (rc {pr.returncode}, {len(ids)} launches of the search kernel seen)"}
+            got[counter] = sum(float(r["Counter_Value"]) for r in sel if int(r["Dispatch_Id"]) in ids) * 1024.0 / steps      # KB -> bytes per launch
+            log(f"[bench] live {counter}: {got[counter] / 1e9:.3f} GB per launch of the search kernel ({time.time() - t0:.0f}s)")
+        except Exception as e:                                   # (a profiler problem must not cost the bench line)
+            return {"bytes": None, "note": f"the {counter} pass raised {type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes": int(got["FETCH_SIZE"] + got["WRITE_SIZE"]), "fetch": int(got["FETCH_SIZE"]), "write": int(got["WRITE_SIZE"]),
+            "note": f"HBM-side bytes per launch measured in THIS run: FETCH_SIZE (raw: {got['FETCH_SIZE'] / 1e9:.3f} GB) + WRITE_SIZE "
+                    f"({got['WRITE_SIZE'] / 1e9:.3f} GB) of the {steps} timed launches of the same command under rocprofv3 --pmc, one counter "
+                    f"per pass (MI355X_MICROARCH.md; the x2 correction for wide coalesced reads does not apply to random 64-byte requests)"}
+
+
 # ---------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -697,6 +762,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--no-events", action="store_true", help="do not stamp the launches of the timed steps")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC passes (profiles/) instead of two rocprofv3 passes of this run")
     args = ap.parse_args()
 
     ctx = Ctx()
@@ -705,6 +772,11 @@ def main():
     ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     ctx.k = k = args.k
     ctx.weak = False
+    ctx.live_traffic = None
+    if (world == 1 and not args.no_legs and not args.no_live_traffic and args.batches == 1 and not os.environ.get("BANG_BENCH_NO_TRAFFIC")
+            and not os.environ.get("BANG_BENCH_FORCE_GATHER")):
+        # (before anything here touches the GPU: the profiled children need the HBM and must have exited by then)
+        ctx.live_traffic = live_traffic(args, lambda *a: print(*a, file=sys.stderr, flush=True))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -744,6 +816,7 @@ def main():
 
     # ------------------------------------------------------------------ the primary configuration (value / config / roofline)
     weak = world > 1 and args.batches > 1
+    ctx.live_primary = ctx.live_traffic is not None
     prim = run_config(args.workload, ctx, args, O, graph=args.graph, pull=args.pull, L=args.L, steps=args.steps, warmup=args.warmup,
                       stream=(args.pull != 0 and not args.resident_graph), reserve_rows=(args.pull != 0), Q=args.queries,
                       shape_n=args.shape_n, batches=args.batches, lanes=lanes, threads=threads, keep=True, host_codes=args.host_codes)
