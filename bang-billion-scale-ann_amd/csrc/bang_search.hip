@@ -985,8 +985,11 @@ __global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_par
   // had arrived) and so are the ids, count and centred query of row t+RD -- no step waits for a dependent round trip.  Code-row
   // buffers rotate by RD, the {ids, count, query} slots by RD + 1; the steps are generated with compile-time slot numbers
   // (RD (RD + 1) of them per trip of the loop) so that everything stays in registers.
-  // (RD = 3 measured the same as 2 for every layout, at 8 and at 16 waves per CU: the memory system is full with two)
-  constexpr int RD = 2, SD = RD + 1;
+  // (RD = 3 / 4 with exact waits: m = 32 35.7 -> 34.6 / 28.6 G rows/s, the long-row instances spill and halve -- tools/dev/run_k2rd.sh)
+#ifndef BANG_K2_RD
+#define BANG_K2_RD 2
+#endif
+  constexpr int RD = BANG_K2_RD, SD = RD + 1;
   PqRow<NDW, ALIGNED> row[COOP ? 1 : RD];
   CoopFetch<NDW, ALIGNED> raw[COOP ? RD : 1];
   Qc qc[SD];
