@@ -54,8 +54,9 @@ struct SearchArgs {
 #define BANG_HOST_FULL 1            // host-paced instances of the long-row layouts: 12 waves x 168 VGPRs, with filter summary + cooperative fetch
 #endif
 __host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return BANG_SEARCH_COOP && ndw >= 12 && (!host_paced || (BANG_HOST_FULL && ndw >= 16)); }
-// per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots) aliases both, and so does the staging area
-// of the cooperative code-row fetch (256 words: one wave instruction's worth of 16-byte pieces)
+// per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots; 256 where the scratch has them) and the
+// summary's transposition area alias both, and so does the staging area of the cooperative code-row fetch (256 words: one wave
+// instruction's worth of 16-byte pieces)
 __host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) { return search_coop(ndw, host_paced) ? 256u : 144u; }
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
