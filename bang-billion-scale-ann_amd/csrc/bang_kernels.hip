@@ -756,6 +756,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   __shared__ float e[RERANK_MAX_CAND + 2];
   __shared__ uint32_t ids[RERANK_MAX_CAND + 2];
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[RERANK_MAX_CAND + 2];      // {distance bits, candidate index}
   extern __shared__ __attribute__((aligned(16))) uint8_t qraw[];
   T* qv = (T*)qraw;
   const uint32_t q = a.q0 + blockIdx.x;
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
     if (!a.by_query && !a.cand_row && a.stage_off && a.D <= 256 && (a.vec_stride & 3u) == 0 && (((uintptr_t)a.vec_base) & 3u) == 0) {
       const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
       const uint32_t B = a.D <= 128 ? 16u : 8u, NT = (a.D + 63u) >> 6, Dpad = ((a.D + 3u) & ~3u) + 4u;
-      float* stage = (float*)(qraw + a.stage_off) + (size_t)wave * (16u * 132u);
+      float* stage = (float*)(qraw + a.stage_off) + (size_t)wave * (B * Dpad);
       for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) ids[i] = a.cand_ids[(size_t)q * a.cand_stride + i];
       __syncthreads();
       float val[16][4];
@@ -874,17 +875,22 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankArgs a) {
   }
 ranked:
   __syncthreads();
-  // stable rank by exact distance; ties keep expansion order (:1330-1363)
+  // stable rank by exact distance; ties keep expansion order (:1330-1363): rank = #{(distance, index) pairs below mine}.  Exact
+  // distances are sums of squares -- non-negative floats, which order like their bit patterns -- so the pair is ONE unsigned 64-bit key
+  // {distance bits, index} and the rank one compare per pair (the two-level float rule costs three).
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = ((unsigned long long)__float_as_uint(e[i]) << 32) | i;
+  if (threadIdx.x == 0) keys[n] = ~0ull;                                   // (padding of the last pair: below nobody)
+  __syncthreads();
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const float d = e[i];
+    const unsigned long long mine = keys[i];
     uint32_t r = 0;
-    for (uint32_t j = 0; j < n; ++j) {
-      const float o = e[j];
-      r += (o < d || (o == d && j < i)) ? 1u : 0u;
+    for (uint32_t j = 0; j < n; j += 2) {
+      const ulonglong2 o = *(const ulonglong2*)&keys[j];
+      r += (o.x < mine ? 1u : 0u) + (o.y < mine ? 1u : 0u);
     }
     if (r < a.k) {
       a.ids_out[(size_t)q * a.k + r] = (uint64_t)ids[i];                 // [Q][k] u64 :1366
-      a.dists_out[(size_t)r * a.Q_total + q] = d;                         // [rank][Q] :999,1297
+      a.dists_out[(size_t)r * a.Q_total + q] = e[i];                      // [rank][Q] :999,1297
     }
   }
   for (uint32_t r = n + threadIdx.x; r < a.k; r += blockDim.x) {          // CANON tail
@@ -1207,9 +1213,10 @@ extern "C" int bang_k_rerank_range(const void* d_vec_base, uint64_t vec_stride, 
     using T = decltype(tag);
     size_t lds = ((size_t)D * sizeof(T) + 15) & ~(size_t)15;
     a.stage_off = 0;
-    if (sizeof(T) == 4 && D <= 256 && !a.by_query && !a.cand_row) {      // staging area of the cooperative float fetch: 4 waves x 16 x 132 floats
+    if (sizeof(T) == 4 && D <= 256 && !a.by_query && !a.cand_row) {      // staging area of the cooperative float fetch: 4 waves x B candidates x Dpad floats
+      const size_t B = D <= 128 ? 16 : 8, Dpad = ((D + 3) & ~(size_t)3) + 4;
       a.stage_off = (uint32_t)lds;
-      lds += (size_t)4 * 16 * 132 * sizeof(float);
+      lds += (size_t)4 * B * Dpad * sizeof(float);
     }
     hipLaunchKernelGGL(rerank_kernel<T>, dim3(nq), dim3(256), lds,
                        (hipStream_t)stream, a);

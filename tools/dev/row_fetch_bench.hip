@@ -81,7 +81,10 @@ static void timeit(const char* name, F launch, double rows_per_launch, uint32_t 
 }
 
 int main() {
-  const uint64_t big = (uint64_t)8 << 30;
+  // ROW_FETCH_GB=<n>: table of n GB and only the cooperative fetch of rows in their own 128-byte line -- does the table's size (the
+  // reach of the address translation) bound the random row rate?
+  const char* gb = getenv("ROW_FETCH_GB");
+  const uint64_t big = (uint64_t)(gb ? atoi(gb) : 8) << 30;
   uint8_t* d_t; uint32_t* d_out;
   CHECK(hipMalloc(&d_t, big + 4096));
   CHECK(hipMemset(d_t, 1, big + 4096));
@@ -89,13 +92,15 @@ int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  for (int waves : {16, 8}) {
+  for (int waves : {16, 12, 8}) {
+    if (!gb && waves == 12) continue;
     dim3 grid(cus), block(waves * 64);
     const double lanes = (double)cus * waves * 64;
 #define LANE(NL, INF, RB, ST) { const uint64_t rows = big / ST; \
       timeit("per-lane x" #NL " inflight " #INF, [&](uint32_t it) { hipLaunchKernelGGL((k_lane<NL, INF>), grid, block, 0, 0, d_t, rows, (uint32_t)ST, it, d_out); }, lanes * 64 * INF, RB, ST, waves); }
 #define COOP(G, INF, RB, ST) { const uint64_t rows = big / ST; \
       timeit("coop " #G " lanes/row inflight " #INF, [&](uint32_t it) { hipLaunchKernelGGL((k_coop<G, INF>), grid, block, 0, 0, d_t, rows, (uint32_t)ST, it, d_out); }, lanes / 64 * (64 / G) * 64 * INF, RB, ST, waves); }
+    if (gb) { COOP(5, 4, 70, 128) COOP(5, 8, 70, 128) COOP(8, 8, 128, 128) continue; }
     LANE(2, 2, 32, 32)  LANE(2, 4, 32, 32)  COOP(2, 4, 32, 32)  COOP(2, 8, 32, 32)
     LANE(5, 1, 70, 70)  LANE(5, 2, 70, 70)  COOP(5, 4, 70, 70)  COOP(5, 8, 70, 70)
     LANE(5, 1, 70, 128) LANE(5, 2, 70, 128) COOP(5, 4, 70, 128) COOP(5, 8, 70, 128) COOP(8, 4, 128, 128) COOP(8, 8, 128, 128)
