@@ -10,12 +10,16 @@
 //    traffic of an iteration is what the algorithm needs -- the adjacency row, the filter words, the PQ code rows, one
 //    candidate-log word.
 //  * The visited filter is updated with PLAIN stores.  A query's filter is private to its wave, so atomics are only needed for
-//    two lanes of the SAME wave-instruction that hit the same word.  Those are found with a 64-slot claim table in LDS (three
+//    two lanes of the SAME wave-instruction that hit the same word.  Those are found with a 128 / 256-slot claim table in LDS (three
 //    rounds with different hashes); same-word lanes merge their bits there and one lane stores old | bits.  The rare lanes that
 //    lose all three rounds to other words fall back to an atomic OR after the plain stores have drained.  (Round 1 issued
-//    73 M fully scattered atomic ORs per 10 K batch: ~17x below the rate of plain stores of the same shape on MI355X.)
-//  * Both filter words of an id are probed in one round trip: the second word is needed anyway -- for the test when the first
-//    bit is set, for the update when it is not.
+//    73 M fully scattered atomic ORs per 10 K batch: ~17x below the rate of plain stores of the same shape on MI355X.)  The stores
+//    are issued once the survivors' code rows have arrived: loads and stores share one counter, and a store in front of the wait
+//    for the rows makes that wait cover its acknowledgement.
+//  * Both filter words of an id are probed in one round trip -- except words the wave's FilterSummary (one bit per filter word,
+//    six VGPRs) knows it has never stored to: those are zero without asking.
+//  * Code rows of three or more 16-byte pieces are fetched cooperatively (CoopFetch: adjacent lanes ask for one row, one request
+//    per line) and reduced as a two-stage LDS pipeline (pq_row_reduce_pipe).
 //  * In graph-on-HBM mode the next adjacency row is requested the moment the parent is known, so its latency hides behind the
 //    sort/merge.  In host-graph mode the parents of a workgroup's waves go to the host walker in one coalesced store per round,
 //    and the sort/merge overlaps the walker's round trip.
