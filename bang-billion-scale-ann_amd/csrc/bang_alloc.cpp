@@ -26,7 +26,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
-  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_fp); dfree(e->d_results);
+  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_pool_jobs); dfree(e->d_fp); dfree(e->d_results);
   e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
   if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
   dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
@@ -116,6 +116,7 @@ int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
   BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
   BANG_TRY(dmalloc(&e->d_qskip, nq));
+  BANG_TRY(dmalloc(&e->d_pool_jobs, nq));
   {
     const size_t a64 = 63;
     e->res_off_dists = ((size_t)nq * e->k * 8 + a64) & ~a64;

@@ -181,14 +181,19 @@ extern "C" int bang_init_e(bang_engine_t* e, int Q) {
   if (!e || !e->allocated || Q <= 0 || Q > e->Qcap) { bang_set_error("bang_init: bad state / numQueries"); return BANG_ERR_ARG; }
   BANG_TRY(ensure_device(e));
   const size_t nq = (size_t)Q;
-  HIP_TRY(hipMemsetAsync(e->d_bloom, 0, nq * BANG_BF_WORDS * 4, nullptr));                  // :443
-  HIP_TRY(hipMemsetAsync(e->d_qstats, 0, nq * 8, nullptr));
-  HIP_TRY(hipMemsetAsync(e->d_qskip, 0, nq * 4, nullptr));
-  if (e->d_active) HIP_TRY(hipMemsetAsync(e->d_active, 0, ((size_t)e->cand_stride + 2) * 4, nullptr));
-  BANG_TRY(bang_k_init_state((uint32_t)Q, (uint32_t)e->medoid, e->cand_stride, e->d_cand_ids, e->d_cand_row, e->d_cand_cnt,
-                             e->d_wl_cnt, e->d_mark, e->d_parents_dev, e->d_cnt, nullptr));
-  HIP_TRY(hipDeviceSynchronize());
-  if (e->h_parents) for (size_t i = 0; i < nq; ++i) e->h_parents[i] = BANG_NO_PARENT;
+  // ONE launch (filters :443, state :440-464, counters) on the stream the first lane's bang_query starts on; the call returns when
+  // it is done -- bang_init stays outside the harness's timed region (test_driver.cpp:432-439) -- without a device-wide synchronisation
+  bang_init_params ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.Q = (uint32_t)Q; ia.medoid = (uint32_t)e->medoid; ia.cand_stride = e->cand_stride;
+  ia.d_bloom = e->d_bloom; ia.d_cand_ids = e->d_cand_ids; ia.d_cand_row = e->d_cand_row; ia.d_cand_cnt = e->d_cand_cnt;
+  ia.d_wl_cnt = e->d_wl_cnt; ia.d_mark = e->d_mark; ia.d_parents = e->d_parents_dev; ia.d_cnt = e->d_cnt;
+  ia.d_qstats = e->d_qstats; ia.d_qskip = e->d_qskip; ia.d_pool_jobs = e->d_pool_jobs;
+  ia.d_active = e->d_active; ia.n_active = e->d_active ? e->cand_stride + 2 : 0;
+  hipStream_t st = e->lanes.empty() ? nullptr : e->lanes[0]->s_main;
+  BANG_TRY(bang_k_init_all(&ia, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (e->h_parents && !e->search_v2) for (size_t i = 0; i < nq; ++i) e->h_parents[i] = BANG_NO_PARENT;   // (the walker forms read it)
   e->inited = true;
   return BANG_OK;
 }
@@ -338,6 +343,8 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
       std::vector<uint32_t> sk((size_t)e->Qcur);
       HIP_TRY(hipMemcpy(sk.data(), e->d_qskip, sk.size() * 4, hipMemcpyDeviceToHost));
       for (uint32_t v : sk) s.filter_loads_skipped += v;
+      HIP_TRY(hipMemcpy(sk.data(), e->d_pool_jobs, sk.size() * 4, hipMemcpyDeviceToHost));
+      for (uint32_t v : sk) s.pool_jobs += v;
     }
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));

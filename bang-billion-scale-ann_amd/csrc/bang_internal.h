@@ -30,6 +30,15 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
+// bang_init in one launch: clears the visited filters, resets the per-query state (as bang_k_init_state) and the diagnostic counters
+typedef struct {
+  uint32_t Q, medoid, cand_stride, n_active;
+  uint32_t* d_bloom;                                   /* [Q][BANG_BF_WORDS] */
+  uint32_t *d_cand_ids, *d_cand_row, *d_cand_cnt, *d_wl_cnt, *d_mark, *d_parents, *d_cnt;
+  uint32_t *d_qstats, *d_qskip, *d_pool_jobs, *d_active;   /* may be NULL */
+} bang_init_params;
+int bang_k_init_all(const bang_init_params* a, void* stream);
+
 // Hand-shake timeouts of the host-paced search kernel are run-time options (host_walk_timeout_ms = 20 000, kernel_go_timeout_ms =
 // 30 000: bang_options.cpp).  The HOST gives up first -- it then stores STOP into every pacing word, which ends the kernel at once;
 // a pacing group only gives up on its own (the host process is gone) well after that.  Default of a launch without the field set:

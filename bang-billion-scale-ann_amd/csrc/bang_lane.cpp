@@ -153,6 +153,8 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
     sp.d_qskip = e->d_qskip + ln.q0;
+    sp.d_pool_jobs = e->d_pool_jobs + ln.q0;
+    sp.pool = e->pool_opt != 0 ? 1u : 0u;
     sp.d_ktime = ktime_slot(e, ln);
     sp.max_wgs = (uint32_t)std::max(0L, env_long("BANG_SEARCH_MAX_WGS", 0));          // experiment / test knobs
     sp.max_waves = (uint32_t)std::max(0L, env_long("BANG_SEARCH_MAX_WAVES", 0));

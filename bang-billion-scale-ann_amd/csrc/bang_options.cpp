@@ -53,6 +53,9 @@ static const OptionDef kOptions[] = {
     {"numa", "BANG_NUMA", &bang_engine::numa_opt, -1, 1, INT, BEFORE_ALLOC, "1 = pin walker threads to the GPU's NUMA node, one physical core each; 0 / -1 = leave them to the scheduler"},
     {"timing", "BANG_TIMING", &bang_engine::timing, 0, 1, INT, BEFORE_ALLOC, "1 = stamp every search / front launch in-kernel (s_memrealtime) for bang_get_stats"},
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
+    {"pool", "BANG_POOL", &bang_engine::pool_opt, -1, 1, INT, ANY,
+     "self-paced search kernel, long code rows: waves without a query of their own (a batch smaller than CUs x waves; the drain of any batch) serve the "
+     "distance stage of their workgroup's queries; 0 = off, 1 / -1 (auto) = on.  Same results"},
     // ---- may change between queries
     {"use_flag", "BANG_USE_FLAG", &bang_engine::use_flag, 0, 1, FLAG, BEFORE_ALLOC, "0 = wait for the front kernel with runtime calls instead of its in-kernel completion flag (ablation)"},
     {"compact", "BANG_COMPACT", &bang_engine::compact, 0, 1, FLAG, ANY, "launch-per-iteration loop: straggler compaction on / off"},

@@ -47,6 +47,7 @@ struct SearchArgs {
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
+  uint32_t pool;             // self-paced form: waves without a query of their own serve the distance stage of their workgroup's queries (K2 pool)
 };
 
 #ifndef BANG_SEARCH_COOP
@@ -67,6 +68,26 @@ __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L
 __host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx, int ndw, bool host_paced) {
   return nctx * search_wl_words(L) + search_scratch_words(ndw, host_paced) + (nctx == 2 ? 32u : 0u);
 }
+
+// ---- the K2 POOL (self-paced form): what a wave without a query of its own does.
+// A lightly loaded wave's iteration is bound by its own instruction issue: the row reduce alone is 4 NDW chunk steps of ~10 VALU
+// instructions (1.3 us of the 7.9 us a 1 250-query shard's iteration takes), and the other three SIMDs of its CU idle.  Waves that
+// find the query hand-out exhausted -- at once when Q < CUs x waves (a rank's shard of 8), and in the drain of every batch -- become
+// HELPERS of their workgroup: a wave that owns a query ("leader") posts the <= 64 survivors of an iteration as a job of chunks of
+// 64 / LPR rows in its own LDS scratch, runs the filter update meanwhile, and the helpers fetch the code rows and reduce them with
+// LPR lanes per row (pq_row_reduce_team: a quarter of the chunk steps per row, bit-identical sums).  Leaders never wait for a
+// helper that is not there: a job is only posted while a helper is idle, and whatever is unclaimed when the filter update is done
+// the leader reduces itself.
+#ifndef BANG_SEARCH_POOL
+#define BANG_SEARCH_POOL 1
+#endif
+#ifndef BANG_POOL_LPR
+#define BANG_POOL_LPR 4             // lanes per code row in a helper wave
+#endif
+__host__ __device__ constexpr bool search_pool(int ndw, bool host_paced) { return BANG_SEARCH_POOL && !host_paced && search_coop(ndw, host_paced); }
+#define POOL_CTL_WORDS 80u          // LDS behind the waves' regions: [0] leaders left, [1] helpers, [2] idle helpers; per wave slot s at 4 + 4 s:
+                                    // {state = rows << 8 | chunks handed out, chunks done, query, -}
+#define POOL_RPC (64 / BANG_POOL_LPR)   // rows per chunk
 
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -502,13 +523,22 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   uint32_t* wg_lds = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words + (size_t)grp_in_wg * 128;
   if (HOST && gslot == 0) { wg_lds[lane] = 0u; wg_lds[64 + lane] = 0u; }
   if (HOST && nctx == 2 && lane < (int)(2 * SRCH_CTX_WORDS)) park[lane] = 0u;        // both contexts: inactive
+  // K2 pool (self-paced form): control words behind the waves' regions
+  constexpr bool POOL = search_pool(NDW, HOST);
+  const bool pool_on = POOL && a.pool != 0u;
+  uint32_t* pool_ctl = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words;
+  if (pool_on && wave == 0) {
+    pool_ctl[lane] = (lane == 0) ? nwaves : 0u;
+    if (lane < (int)(POOL_CTL_WORDS - 64u)) pool_ctl[64 + lane] = 0u;
+  }
   __syncthreads();
   if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
   float* sd = (float*)scratch;
   uint32_t* ti = scratch;
   float* td = (float*)(scratch + 72);
-  uint32_t* sc = scratch + 72;                     // compaction scratch (== td: dead before the sort)
+  uint32_t* sc = POOL ? scratch : scratch + 72;    // compaction scratch (== td, or sd where the K2 pool reads the survivors from it: dead before the sort)
+  uint32_t* my_ctl = pool_ctl + 4 + 4 * wave;      // this wave's job words (K2 pool)
   uint32_t* tbl = scratch;                         // filter claim table, 128 words (== sd + td: dead between the stages that use them)
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
@@ -547,7 +577,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   constexpr bool SUMM = (BANG_FILTER_SUMMARY != 0) && (!HOST || search_maxt(NDW, HOST) < 1024);   // (needs 6 VGPRs the 16-wave host-paced instances do not have)
   FilterSummary summ;
   summ.clear();
-  uint32_t probes_skipped = 0;                     // diagnostic counter (d_qstats2): filter words not loaded thanks to the summary
+  uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
+  uint32_t pool_jobs = 0;                          // diagnostic counter (d_pool_jobs): iterations whose distance stage went to the K2 pool
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -624,7 +655,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     // ---------------- a finished context takes its next query: the first one by position, then from the hand-out counter
     if (!active && !exhausted) {
-      if (!((started >> c) & 1u)) q = c * total_waves + gw;
+      if (!((started >> c) & 1u)) q = pool_on ? wave * gridDim.x + blockIdx.x : c * total_waves + gw;   // (pool: every CU gets its share of leaders)
       else {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
@@ -636,8 +667,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
+        pool_jobs = 0;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
+        if (pool_on && lane == 0) my_ctl[2] = q;
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
         cnt_in = p.d_seed[0]; x0 = p.d_seed[1 + lane]; x1 = p.d_seed[65];
         have_row = true;
@@ -700,7 +733,23 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      // K2 pool: with a helper of this workgroup idle, the survivors -- they sit in LDS already (sc) -- go out as a job of
+      // chunks of POOL_RPC rows; the helpers fetch and reduce them while this wave updates the filter
+      bool pooled = false;
+      uint32_t nchunks = 0;
+      if (POOL) {
+        if (pool_on && !first && n > 0u && uni(__hip_atomic_load(&pool_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) {
+          pooled = true;
+          ++pool_jobs;
+          nchunks = (n + (uint32_t)POOL_RPC - 1u) / (uint32_t)POOL_RPC;
+          if (lane == 0) {
+            __hip_atomic_store(&my_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&my_ctl[0], n << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (behind the ids: one wave's LDS operations execute in order)
+          }
+        }
+      }
+      if (POOL && pooled) {}
+      else if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
       else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
@@ -708,9 +757,14 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // The claim rounds run now, on LDS, while the code rows travel; the stores they decide on are issued once the rows are here.
       bool pa = pass0, pb = pass0, st_a = false, st_b = false;
       uint32_t sv_a = 0, sv_b = 0;
-      filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
-      // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-      if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+      if (POOL && pooled) {         // (the first 128 words of the scratch are the job's ids and distances: claim table and transposition area behind them)
+        filter_commit<128>(scratch + 128, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+        if (SUMM) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+      } else {
+        filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+        // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
+        if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+      }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
         if (st_a) bloom[h0a >> 5] = sv_a;
@@ -726,11 +780,39 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           }
         }
       };
-      if (!BANG_FILTER_STORES_LATE || !EARLY_ROWS) filter_stores();
+      if (!BANG_FILTER_STORES_LATE || !EARLY_ROWS || (POOL && pooled)) filter_stores();
 
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
-      {
+      if (POOL && pooled) {
+        // whatever no helper has claimed by now this wave reduces itself (one lane per row, as below) ...
+        uint64_t mine = 0;
+        uint32_t done_self = 0;
+        for (;;) {
+          const uint32_t stw = uni(__hip_atomic_load(&my_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if ((stw & 0xffu) >= nchunks) break;
+          uint32_t old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(&my_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t cidx = uni(old) & 0xffu;
+          if (cidx >= nchunks) break;
+          mine |= (POOL_RPC >= 64 ? ~0ull : ((1ull << POOL_RPC) - 1ull)) << (cidx * (uint32_t)POOL_RPC);
+          ++done_self;
+        }
+        const bool me = ((mine >> lane) & 1ull) != 0ull && (uint32_t)lane < n;
+        if (mine != 0ull) {                                    // uniform
+          if (me) {
+            pq_row_load(row, p.d_codes, code_stride, sid0);
+            d0 = BANG_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc) : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
+          }
+        }
+        // ... and the helpers' chunks are waited for (a claimed chunk is always finished: helpers leave only when no wave of the
+        // workgroup owns a query any more)
+        if (done_self < nchunks)
+          while (uni(__hip_atomic_load(&my_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + done_self < nchunks) __builtin_amdgcn_s_sleep(1);
+        wave_sync();
+        if ((uint32_t)lane < n && !me) d0 = ((const float*)(scratch + 64))[lane];
+        wave_sync();
+      } else {
         if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
         if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if (BANG_FILTER_STORES_LATE && EARLY_ROWS) {
@@ -868,6 +950,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
           if (p.d_qiters) p.d_qiters[q] = iter;
           if (p.d_qskip) p.d_qskip[q] = probes_skipped;
+          if (p.d_pool_jobs) p.d_pool_jobs[q] = pool_jobs;
         }
         active = false;
       } else {
@@ -887,6 +970,57 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       wave_sync();
     }
     PF_STAMP(pf_back);
+  }
+  if (POOL) {
+    if (pool_on) {
+      // ---------------- no query left for this wave: it serves the distance stage of the queries its workgroup still runs (K2 pool)
+      if (lane == 0) {
+        (void)__hip_atomic_fetch_sub(&pool_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(&pool_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      constexpr int LPR = BANG_POOL_LPR;
+      TeamQc<PSZ, NDW, LPR> qq;                         // the served query, centred, in this lane's chunk order
+#pragma unroll
+      for (int i = 0; i < TeamQc<PSZ, NDW, LPR>::NU * PSZ; ++i) qq.v[i] = 0.0f;
+      uint32_t qq_of = 0xFFFFFFFFu;
+      const uint32_t j = (uint32_t)lane & (uint32_t)(LPR - 1), rsub = (uint32_t)lane / (uint32_t)LPR;
+      for (;;) {
+        const uint32_t stw = ((uint32_t)lane < nwaves) ? __hip_atomic_load(&pool_ctl[4 + 4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        const uint64_t mk = __ballot((stw & 0xffu) * (uint32_t)POOL_RPC < ((stw >> 8) & 0xffu));        // waves with unclaimed chunks
+        if (mk == 0ull) {
+          if (uni(__hip_atomic_load(&pool_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;   // nobody owns a query any more
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        // the nearest posting wave at or behind this wave's own slot (spreads the helpers over the jobs)
+        const uint64_t rot = wave ? ((mk >> wave) | (mk << (64u - wave))) : mk;
+        const uint32_t sl = ((uint32_t)__builtin_ctzll(rot) + wave) & 63u;
+        uint32_t* ctl = pool_ctl + 4 + 4 * sl;
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = uni(old);
+        const uint32_t cidx = old & 0xffu, nrows = (old >> 8) & 0xffu;
+        if (cidx * (uint32_t)POOL_RPC >= nrows) continue;                   // another wave was faster
+        if (lane == 0) (void)__hip_atomic_fetch_sub(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t* jids = (const uint32_t*)(lds + a.lds_piv_floats) + (size_t)sl * a.wave_words + (size_t)nctx * a.wl_words;   // that wave's scratch: ids [64], distances [64]
+        float* jdist = (float*)(jids + 64);
+        const uint32_t qs = uni(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const uint32_t rr = cidx * (uint32_t)POOL_RPC + rsub;
+        const bool valid = rr < nrows;
+        const uint32_t id = jids[valid ? rr : cidx * (uint32_t)POOL_RPC];   // (a lane group without a row re-reads the chunk's first: every lane executes the reduce)
+        PqRow<NDW, ALIGNED> hrow;
+        pq_row_load(hrow, p.d_codes, code_stride, id);                      // the LPR lanes of a group ask for the same 16-byte pieces: one request per line
+        if (qs != qq_of) { qq.load(p.d_qc + (size_t)qs * QW, j); qq_of = qs; }
+        const float d = pq_row_reduce_team<PSZ, NDW, ALIGNED, NHI, LPR>(hrow, piv_lds, qq, j);
+        if (valid && j == 0u) jdist[rr] = d;
+        wave_sync();
+        if (lane == 0) {                                                    // (behind the distances: one wave's LDS operations execute in order)
+          (void)__hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
   }
   if (prof && lane == 0) {
     unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
@@ -1150,7 +1284,7 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
 static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx, bool host_paced) {
   const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
   const size_t per_wave = (size_t)search_wave_words(L, nctx, (int)(mp / 4u), host_paced) * 4u;
-  const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u);
+  const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u) - (search_pool((int)(mp / 4u), host_paced) ? POOL_CTL_WORDS * 4u : 0u);
   if (piv_bytes + per_wave > cap) return 0;
   const size_t w = (cap - piv_bytes) / per_wave;
   const size_t most = (size_t)search_maxt((int)(mp / 4u), host_paced) / WAVE;      // what the instance is compiled for
@@ -1217,7 +1351,13 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   a.gs = gs;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
-  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);
+  // K2 pool: every wave slot of a CU is launched whatever the batch size -- the waves beyond the batch are the helpers
+  a.pool = (p->d_graph && p->pool && search_pool((int)(p->mp / 4u), false)) ? 1u : 0u;
+  if (a.pool) {
+    waves = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L, 1, false);
+    if (p->max_waves && p->max_waves < waves) waves = p->max_waves;
+  }
+  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES) + (a.pool ? POOL_CTL_WORDS * 4u : 0u);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + p->mp / 4u;

@@ -179,6 +179,8 @@ typedef struct {
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
+  uint64_t pool_jobs;         /* search kernel, self-paced form: query-iterations whose distance stage was served by waves without a query of
+                                 their own (the K2 pool: a batch smaller than CUs x waves, the drain of any batch) */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -350,6 +352,9 @@ typedef struct {
                                           leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the
                                           word was still zero (self-paced form; 0 in the host-paced form) */
+  uint32_t pool;                       /* self-paced form, long code rows: 1 = waves without a query of their own (a batch smaller than CUs x waves; the drain of
+                                          any batch) serve the distance stage of their workgroup's queries -- the K2 pool, csrc/bang_search.hip; 0 = off.  Same results. */
+  uint32_t* d_pool_jobs;               /* [Q] out, or NULL: iterations of the query whose distance stage went to the pool */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */
