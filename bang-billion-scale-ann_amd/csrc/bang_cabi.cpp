@@ -344,7 +344,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
       HIP_TRY(hipMemcpy(sk.data(), e->d_qskip, sk.size() * 4, hipMemcpyDeviceToHost));
       for (uint32_t v : sk) s.filter_loads_skipped += v;
       HIP_TRY(hipMemcpy(sk.data(), e->d_pool_jobs, sk.size() * 4, hipMemcpyDeviceToHost));
-      for (uint32_t v : sk) s.pool_jobs += v;
+      for (uint32_t v : sk) { s.pool_jobs += v & 0xffffu; s.pool_self_chunks += v >> 16; }
     }
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));

@@ -537,7 +537,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   float* sd = (float*)scratch;
   uint32_t* ti = scratch;
   float* td = (float*)(scratch + 72);
-  uint32_t* sc = POOL ? scratch : scratch + 72;    // compaction scratch (== td, or sd where the K2 pool reads the survivors from it: dead before the sort)
+  uint32_t* sc = POOL ? scratch + 128 : scratch + 72;   // compaction scratch (== td: dead before the sort; K2 pool: behind the job's ids and distances, where the
+                                                        // filter's claim table follows it; [64..128) of it: the survivors' source lanes)
   uint32_t* my_ctl = pool_ctl + 4 + 4 * wave;      // this wave's job words (K2 pool)
   uint32_t* tbl = scratch;                         // filter claim table, 128 words (== sd + td: dead between the stages that use them)
   const uint32_t total_waves = gridDim.x * nwaves;
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
   uint32_t pool_jobs = 0;                          // diagnostic counter (d_pool_jobs): iterations whose distance stage went to the K2 pool
+  unsigned long long pl_self = 0, pl_wait = 0, pl_jobs = 0, pl_selfchunks = 0;   // diagnostic (p.d_prof): 100 MHz ticks of this wave as a leader
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -697,6 +699,23 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       fetched += ci;
       const bool v0 = (uint32_t)lane < ci;
       const bool v1 = ci > 64;                               // the 65th id exists in the seed list only (uniform)
+      // K2 pool: with a helper of this workgroup idle, the row goes out as a job the moment it has arrived -- ALL its ids, in chunks of
+      // POOL_RPC: the helpers fetch the code rows and reduce them while this wave hashes, probes, compacts and updates the filter, and the
+      // distances of the ids that turn out to be visited already are simply not looked at (a distance is a function of the id alone)
+      bool pooled = false;
+      uint32_t nchunks = 0;
+      if (POOL) {
+        if (pool_on && !first && ci > 0u && uni(__hip_atomic_load(&pool_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) {
+          pooled = true;
+          ++pool_jobs;
+          nchunks = (ci + (uint32_t)POOL_RPC - 1u) / (uint32_t)POOL_RPC;
+          if (v0) scratch[lane] = x0;
+          if (lane == 0) {
+            __hip_atomic_store(&my_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&my_ctl[0], ci << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (behind the ids: one wave's LDS operations execute in order)
+          }
+        }
+      }
       const uint32_t h0a = hash1(x0), h0b = hash2(x0);
       uint32_t h1a = 0, h1b = 0, w0a = 0, w0b = 0, w1a = 0, w1b = 0;
       // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip.
@@ -723,9 +742,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // ordered compaction through LDS: survivors keep input order (CANON; the reference emits in atomicAdd order :1161)
       if (pass0) sc[lanes_below(m0)] = x0;
       if (pass1) sc[n0] = x1;
+      if (POOL) { if (pooled && pass0) sc[64 + lanes_below(m0)] = (uint32_t)lane; }
       wave_sync();
       if ((uint32_t)lane < n) sid0 = sc[lane];
       if (lane == 0 && n > 64) sid1 = sc[64];
+      uint32_t src = 0;                                      // K2 pool: where in the row this lane's survivor stood
+      if (POOL) { if (pooled && (uint32_t)lane < n) src = sc[64 + lane]; }
       wave_sync();
       evals += n;
       PH(2);   // compaction
@@ -733,19 +755,19 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      // K2 pool: with a helper of this workgroup idle, the survivors -- they sit in LDS already (sc) -- go out as a job of
-      // chunks of POOL_RPC rows; the helpers fetch and reduce them while this wave updates the filter
-      bool pooled = false;
-      uint32_t nchunks = 0;
+      // K2 pool: chunks no helper has claimed by now are withdrawn and their survivors' rows requested here, as always (one lane per
+      // row); the helpers' chunks are waited for behind the filter update
+      uint32_t claimed = 0;
+      bool me = false;
       if (POOL) {
-        if (pool_on && !first && n > 0u && uni(__hip_atomic_load(&pool_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) {
-          pooled = true;
-          ++pool_jobs;
-          nchunks = (n + (uint32_t)POOL_RPC - 1u) / (uint32_t)POOL_RPC;
-          if (lane == 0) {
-            __hip_atomic_store(&my_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&my_ctl[0], n << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (behind the ids: one wave's LDS operations execute in order)
-          }
+        if (pooled) {
+          uint32_t old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(&my_ctl[0], nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (no claim succeeds behind this)
+          claimed = uni(old) & 0xffu;
+          if (claimed > nchunks) claimed = nchunks;
+          pool_jobs += (nchunks - claimed) << 16;                // (high half: chunks this wave reduced itself)
+          me = (uint32_t)lane < n && src / (uint32_t)POOL_RPC >= claimed;
+          if (__ballot(me) != 0ull) pq_row_load(row, p.d_codes, code_stride, me ? sid0 : 0u);     // (unconditional: the compiler's count of outstanding loads stays exact)
         }
       }
       if (POOL && pooled) {}
@@ -785,32 +807,21 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       if (POOL && pooled) {
-        // whatever no helper has claimed by now this wave reduces itself (one lane per row, as below) ...
-        uint64_t mine = 0;
-        uint32_t done_self = 0;
-        for (;;) {
-          const uint32_t stw = uni(__hip_atomic_load(&my_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          if ((stw & 0xffu) >= nchunks) break;
-          uint32_t old = 0;
-          if (lane == 0) old = __hip_atomic_fetch_add(&my_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const uint32_t cidx = uni(old) & 0xffu;
-          if (cidx >= nchunks) break;
-          mine |= (POOL_RPC >= 64 ? ~0ull : ((1ull << POOL_RPC) - 1ull)) << (cidx * (uint32_t)POOL_RPC);
-          ++done_self;
+        const bool pprof = p.d_prof != nullptr;                  // diagnostic (BANG_SEARCH_PROF=1): where the pool's time goes
+        unsigned long long pt0 = 0, pt1 = 0;
+        if (pprof) pt0 = __builtin_amdgcn_s_memrealtime();
+        if (__ballot(me) != 0ull) {                              // uniform: rows of withdrawn chunks
+          if (me) d0 = BANG_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc) : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
-        const bool me = ((mine >> lane) & 1ull) != 0ull && (uint32_t)lane < n;
-        if (mine != 0ull) {                                    // uniform
-          if (me) {
-            pq_row_load(row, p.d_codes, code_stride, sid0);
-            d0 = BANG_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc) : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
-          }
+        if (pprof) pt1 = __builtin_amdgcn_s_memrealtime();
+        // the helpers' chunks (a claimed chunk is always finished: helpers leave only when no wave of the workgroup owns a query any more)
+        while (uni(__hip_atomic_load(&my_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < claimed) __builtin_amdgcn_s_sleep(1);
+        if (pprof) {
+          const unsigned long long pt2 = __builtin_amdgcn_s_memrealtime();
+          pl_self += pt1 - pt0; pl_wait += pt2 - pt1; ++pl_jobs; pl_selfchunks += nchunks - claimed;
         }
-        // ... and the helpers' chunks are waited for (a claimed chunk is always finished: helpers leave only when no wave of the
-        // workgroup owns a query any more)
-        if (done_self < nchunks)
-          while (uni(__hip_atomic_load(&my_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + done_self < nchunks) __builtin_amdgcn_s_sleep(1);
         wave_sync();
-        if ((uint32_t)lane < n && !me) d0 = ((const float*)(scratch + 64))[lane];
+        if ((uint32_t)lane < n && !me) d0 = ((const float*)(scratch + 64))[src];
         wave_sync();
       } else {
         if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
@@ -980,11 +991,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       constexpr int LPR = BANG_POOL_LPR;
-      TeamQc<PSZ, NDW, LPR> qq;                         // the served query, centred, in this lane's chunk order
-#pragma unroll
-      for (int i = 0; i < TeamQc<PSZ, NDW, LPR>::NU * PSZ; ++i) qq.v[i] = 0.0f;
-      uint32_t qq_of = 0xFFFFFFFFu;
       const uint32_t j = (uint32_t)lane & (uint32_t)(LPR - 1), rsub = (uint32_t)lane / (uint32_t)LPR;
+      const bool hprof = p.d_prof != nullptr;
+      unsigned long long ht_busy = 0, ht_chunks = 0, ht_qq = 0, ht_start = hprof ? __builtin_amdgcn_s_memrealtime() : 0ull, ht_c0 = 0;
       for (;;) {
         const uint32_t stw = ((uint32_t)lane < nwaves) ? __hip_atomic_load(&pool_ctl[4 + 4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         const uint64_t mk = __ballot((stw & 0xffu) * (uint32_t)POOL_RPC < ((stw >> 8) & 0xffu));        // waves with unclaimed chunks
@@ -1003,6 +1012,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         const uint32_t cidx = old & 0xffu, nrows = (old >> 8) & 0xffu;
         if (cidx * (uint32_t)POOL_RPC >= nrows) continue;                   // another wave was faster
         if (lane == 0) (void)__hip_atomic_fetch_sub(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (hprof) ht_c0 = __builtin_amdgcn_s_memrealtime();
         const uint32_t* jids = (const uint32_t*)(lds + a.lds_piv_floats) + (size_t)sl * a.wave_words + (size_t)nctx * a.wl_words;   // that wave's scratch: ids [64], distances [64]
         float* jdist = (float*)(jids + 64);
         const uint32_t qs = uni(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1011,7 +1021,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         const uint32_t id = jids[valid ? rr : cidx * (uint32_t)POOL_RPC];   // (a lane group without a row re-reads the chunk's first: every lane executes the reduce)
         PqRow<NDW, ALIGNED> hrow;
         pq_row_load(hrow, p.d_codes, code_stride, id);                      // the LPR lanes of a group ask for the same 16-byte pieces: one request per line
-        if (qs != qq_of) { qq.load(p.d_qc + (size_t)qs * QW, j); qq_of = qs; }
+        // the served query, centred, in this lane's chunk order: fetched per chunk (L2 hits that travel with the code rows; kept across
+        // chunks "while the query is the same" the 36 registers become loop-carried and the poll loop above fills with copies of them)
+        TeamQc<PSZ, NDW, LPR> qq;
+        qq.load(p.d_qc + (size_t)qs * QW, j);
+        ++ht_qq;
         const float d = pq_row_reduce_team<PSZ, NDW, ALIGNED, NHI, LPR>(hrow, piv_lds, qq, j);
         if (valid && j == 0u) jdist[rr] = d;
         wave_sync();
@@ -1019,6 +1033,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           (void)__hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (hprof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ht_busy += __builtin_amdgcn_s_memrealtime() - ht_c0; ++ht_chunks; }
+      }
+      if (hprof && lane == 0) {
+        unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
+        atomicAdd(&o[0], pl_jobs); atomicAdd(&o[1], pl_self); atomicAdd(&o[2], pl_wait); atomicAdd(&o[3], pl_selfchunks);
+        atomicAdd(&o[4], ht_chunks); atomicAdd(&o[5], ht_busy); atomicAdd(&o[6], __builtin_amdgcn_s_memrealtime() - ht_start); atomicAdd(&o[7], ht_qq);
       }
     }
   }
@@ -1221,6 +1241,12 @@ extern "C" int bang_k_pqdist_stream(const bang_iter_params* p, void* stream) {
   const uint32_t pf = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
   hipStream_t st = (hipStream_t)stream;
   switch (p->psz * 100u + p->mp / 4u) {
+#ifdef BANG_DEV_ONLY_218
+    case 218: return launch_pqdist_al<2, 18>(*p, pf, st);
+    default: bang_set_error("development build: psz=2 mp=72 only"); return BANG_ERR_UNSUPPORTED;
+  }
+  switch (0u) {
+#endif
     case 108: return launch_pqdist_al<1, 8>(*p, pf, st);
     case 116: return launch_pqdist_al<1, 16>(*p, pf, st);
     case 124: return launch_pqdist_al<1, 24>(*p, pf, st);
@@ -1354,26 +1380,32 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // K2 pool: every wave slot of a CU is launched whatever the batch size -- the waves beyond the batch are the helpers
   a.pool = (p->d_graph && p->pool && search_pool((int)(p->mp / 4u), false)) ? 1u : 0u;
   if (a.pool) {
+    const uint32_t leaders = waves;                      // what bang_search_geometry gave the batch: the waves that own a query from the start
     waves = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L, 1, false);
     if (p->max_waves && p->max_waves < waves) waves = p->max_waves;
+    if (p->pool_helpers && leaders + p->pool_helpers < waves) waves = leaders + p->pool_helpers;
   }
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES) + (a.pool ? POOL_CTL_WORDS * 4u : 0u);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + p->mp / 4u;
   switch (key) {
+#ifndef BANG_DEV_ONLY_218          // development builds (ISA dumps, quick A/B libraries): the SIFT1B layout only
     case 108: return launch_al<1, 8>(a, grid, block, lds, st);
     case 116: return launch_al<1, 16>(a, grid, block, lds, st);
     case 124: return launch_al<1, 24>(a, grid, block, lds, st);
     case 132: return launch_al<1, 32>(a, grid, block, lds, st);
     case 208: return launch_al<2, 8>(a, grid, block, lds, st);
     case 216: return launch_al<2, 16>(a, grid, block, lds, st);
-    case 218: return launch_al<2, 18>(a, grid, block, lds, st);
     case 219: return launch_al<2, 19>(a, grid, block, lds, st);
+#endif
+    case 218: return launch_al<2, 18>(a, grid, block, lds, st);
+#ifndef BANG_DEV_ONLY_218
     case 404: return launch_al<4, 4>(a, grid, block, lds, st);
     case 408: return launch_al<4, 8>(a, grid, block, lds, st);
     case 802: return launch_al<8, 2>(a, grid, block, lds, st);
     case 804: return launch_al<8, 4>(a, grid, block, lds, st);
+#endif
     default: bang_set_error("no search-kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
   }
 }

@@ -250,7 +250,9 @@ def run_once(eng, my_q, ctx, timed=False, gather=True):
     import torch
     import torch.distributed as dist
     from bang_amd import shard
+    t_i = time.perf_counter()
     eng.init(my_q.shape[0])
+    ctx.last_init_s = time.perf_counter() - t_i          # bang_init alone (it returns when the device is done with it)
     if timed:
         if ctx.world > 1:
             dist.barrier()
@@ -314,11 +316,11 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
                 "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride", "rows_in_hbm")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
-               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0, pool_jobs=0)
+               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0, pool_jobs=0, pool_self_chunks=0)
     agg.update({kk: 0 for kk in keys_max})
     ids = dists = None
     for _ in range(steps):
-        ti = time.perf_counter()
+        t_init = 0.0
         el = 0.0
         e_s = e_g = 0.0
         for b in range(batches):
@@ -326,10 +328,11 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
             el += e1
             e_s += es1
             e_g += eg1
+            t_init += ctx.last_init_s
             st = eng.stats()
             for key in agg:
                 agg[key] = max(agg[key], st[key]) if key in keys_max else agg[key] + st[key]
-        init_s.append(time.perf_counter() - ti)
+        init_s.append(el + t_init)                       # bang_init + bang_query, nothing else (round 3 also counted the statistics read-back)
         step_s.append(el)
         search_s.append(e_s)
         gather_s.append(e_g)

@@ -181,6 +181,7 @@ typedef struct {
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
   uint64_t pool_jobs;         /* search kernel, self-paced form: query-iterations whose distance stage was served by waves without a query of
                                  their own (the K2 pool: a batch smaller than CUs x waves, the drain of any batch) */
+  uint64_t pool_self_chunks;  /* ... chunks of such jobs (64 / lanes-per-row rows each) that no helper had claimed when the owner was ready for them */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -355,6 +356,7 @@ typedef struct {
   uint32_t pool;                       /* self-paced form, long code rows: 1 = waves without a query of their own (a batch smaller than CUs x waves; the drain of
                                           any batch) serve the distance stage of their workgroup's queries -- the K2 pool, csrc/bang_search.hip; 0 = off.  Same results. */
   uint32_t* d_pool_jobs;               /* [Q] out, or NULL: iterations of the query whose distance stage went to the pool */
+  uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */

@@ -54,7 +54,10 @@ def main():
         for var in a.variants.split(","):
             for kv in var.split("+"):
                 key, val = kv.split("=")
-                eng.set_option(key, int(val))
+                if key.startswith("BANG_"):              # an environment switch (read when used)
+                    os.environ[key] = val
+                else:
+                    eng.set_option(key, int(val))
             eng.set_searchparams(ctx.k, L)
             eng.alloc(q)
             res = bench.measure(eng, wl, my_q, L, a.steps, a.warmup, ctx, graph)
@@ -68,7 +71,7 @@ def main():
             eng.free()
             r = res["roofline"] or {}
             rows.append(dict(queries=q, variant=var, qps=res["queries_per_s"], ms=res["ms_per_step"], launch_us=r.get("avg_launch_us"),
-                             qps_incl_init=res["qps_incl_init"], pool_jobs=int(st.get("pool_jobs", 0) // max(1, a.steps)),
+                             qps_incl_init=res["qps_incl_init"], pool_jobs=int(st.get("pool_jobs", 0) // max(1, a.steps)), pool_self_chunks=int(st.get("pool_self_chunks", 0) // max(1, a.steps)),
                              iters=int(st["iterations"]), step_ms=res["step_ms"], same_as_first=same))
             print(json.dumps(rows[-1]), flush=True)
     eng.unload(); eng.close()
