@@ -44,6 +44,7 @@ void free_batch(bang_engine* e) {
 }
 
 int alloc_buffers(bang_engine* e, int Q) {
+  BANG_TRY(validate_pull_rows(e));
   const size_t L = (size_t)e->L, nq = (size_t)Q;
   const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
   const size_t vb = vec_bytes(e);

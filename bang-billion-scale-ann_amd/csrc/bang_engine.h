@@ -245,6 +245,7 @@ struct bang_engine {
   bool pull = false;                   // resolved at load
   uint32_t* h_adj = nullptr;           // [N][64]
   size_t adj_bytes = 0;
+  std::string rows_path;               // the rows file the mapping h_adj belongs to ("" = anonymous memory): re-checked at bang_alloc
   std::string rows_key;                // names the shared rows file (BANG_PULL_ROWS_DIR): basename of the index prefix
   // STREAMED load: the graph entries pass through in chunks (vectors -> HBM, adjacency -> pull rows) and are not kept
   bang_entry_source entry_fn = nullptr;   // set for the duration of a streamed load
@@ -314,6 +315,7 @@ void unload_index(bang_engine* e);
 int load_files(bang_engine* e, const char* prefix);
 int load_shared(bang_engine* e, uint64_t expect_rows_hash);    // vectors already in the caller's device buffer, rows in the node's rows file
 int map_graph_file(bang_engine* e);
+int validate_pull_rows(bang_engine* e);   // pull mode, at bang_alloc: the rows mapping is still what bang_load registered
 // ---- bang_alloc.cpp
 int alloc_buffers(bang_engine* e, int Q);
 void free_batch(bang_engine* e);

@@ -151,10 +151,10 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       sp.d_rows_hbm = e->d_rows_hbm; sp.n_rows_hbm = e->n_rows_hbm;
     }
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
-    sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt;
+    sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1; sp.n_nodes = e->N;
     sp.d_qskip = e->d_qskip + ln.q0;
     sp.d_pool_jobs = e->d_pool_jobs + ln.q0;
-    sp.pool = e->pool_opt != 0 ? 1u : 0u;
+    sp.pool = e->pool_opt > 0 ? 1u : 0u;                 // (auto = off: measured no faster)
     sp.pool_helpers = (uint32_t)std::max(0L, env_long("BANG_POOL_HELPERS", 0));
     sp.d_ktime = ktime_slot(e, ln);
     sp.max_wgs = (uint32_t)std::max(0L, env_long("BANG_SEARCH_MAX_WGS", 0));          // experiment / test knobs
@@ -375,7 +375,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   const bool mailbox = !to_device && whole && e->res_off_iters <= mailbox_max;
   uint32_t* h_abort = (uint32_t*)(e->h_results + e->res_bytes - BANG_MAX_LANES * 4) + ln.index;   // (one word per lane behind the results)
   *h_abort = 0;
-  if (e->search_host) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
+  if (e->search_host || e->search_v2) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
   const bool iters = e->search_v2 || e->search_host;
   if (to_device) {
     LANE_HIP(hipMemcpyAsync(d_ids_user + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k, (size_t)ln.nq * e->k * sizeof(uint64_t),
@@ -405,6 +405,11 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   }
   tl("results D2H");
   pw_stats[0] = *h_abort;
+  if (pw_stats[0] == 2u) {
+    bang_set_error("search kernel: an adjacency row named a node id out of range (N = %u): the rows were overwritten since bang_load%s%s", e->N,
+                   e->rows_path.empty() ? "" : " -- ", e->rows_path.c_str());
+    return BANG_ERR_HIP;
+  }
   if (pw_stats[0]) { bang_set_error("search kernel gave up waiting for the host walker"); return BANG_ERR_HIP; }
   if (iters) {
     const uint32_t* hq = (const uint32_t*)(e->h_results + e->res_off_iters) + ln.q0;

@@ -194,7 +194,42 @@ static int pull_rows_finish(bang_engine* e, PullRows& pr, const PullRowsSig& sig
   }
   e->h_adj = (uint32_t*)pr.m; e->adj_bytes = pr.bytes; e->d_adj = (const uint32_t*)dp; e->pull = true;
   e->rows_hash = sig.adj_hash;
+  e->rows_path = pr.path;
   pr.m = MAP_FAILED;
+  return BANG_OK;
+}
+
+// Pull mode, at bang_alloc: the self-paced kernel reads the rows by itself, no host thread watches it -- what it is about to read
+// must still be what bang_load registered.  Checked: the mapping's size (N x 256 + trailer), that the address is (still) registered
+// with this device, and -- for a rows FILE, which another process may have truncated or replaced since -- the file's size and the
+// signature behind the last row (the size first: touching a mapping beyond a truncated file's end is a SIGBUS, not an error code).
+int validate_pull_rows(bang_engine* e) {
+  if (!e->pull) return BANG_OK;
+  const size_t want = (size_t)e->N * 256 + 4096;
+  if (!e->h_adj || !e->d_adj || e->adj_bytes != want) {
+    bang_set_error("pull rows: the mapping holds %zu bytes, the index needs %zu (N = %u rows of 256 bytes + trailer)", e->adj_bytes, want, e->N);
+    return BANG_ERR_ARG;
+  }
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, e->h_adj) != hipSuccess || at.devicePointer == nullptr) {
+    (void)hipGetLastError();
+    bang_set_error("pull rows: the host mapping is not registered with the device any more");
+    return BANG_ERR_HIP;
+  }
+  if (!e->rows_path.empty()) {
+    struct stat st;
+    if (stat(e->rows_path.c_str(), &st) == 0 && (size_t)st.st_size != want) {      // (an unlinked file is fine: the mapping keeps its pages)
+      bang_set_error("pull rows: %s has been truncated or replaced since bang_load (%lld bytes, %zu expected): unload and load again",
+                     e->rows_path.c_str(), (long long)st.st_size, want);
+      return BANG_ERR_IO;
+    }
+  }
+  PullRowsSig g;
+  memcpy(&g, (const uint8_t*)e->h_adj + (size_t)e->N * 256 + 2048, sizeof(g));
+  if (memcmp(g.magic, "BANGROW2", 8) != 0 || g.N != e->N || g.medoid != e->medoid || g.adj_hash != e->rows_hash) {
+    bang_set_error("pull rows: the signature behind the last row no longer matches the loaded index (rows overwritten since bang_load)");
+    return BANG_ERR_IO;
+  }
   return BANG_OK;
 }
 
@@ -805,6 +840,7 @@ void unload_index(bang_engine* e) {
   e->n_rows_hbm = 0;
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
+  e->rows_path.clear();
   e->graph_path.clear(); e->graph_streamed = false; e->entry_fn = nullptr; e->entry_ctx = nullptr;
   e->rows_key.clear();
   free(e->graph_owned);

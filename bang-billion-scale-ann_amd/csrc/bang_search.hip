@@ -696,6 +696,14 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         const uint32_t cap = p.R + (first ? 1u : 0u);
         if (ci > cap) ci = cap;
       }
+      // a row that names a node the index does not have (rows overwritten behind the engine's back: the self-paced form has no host
+      // thread that could notice) is not followed: the batch ends with BANG_ERR_HIP instead of a wild read of the code table
+      if (!HOST && p.n_nodes != 0u) {
+        if (__ballot((uint32_t)lane < ci && x0 >= p.n_nodes) != 0ull) {
+          if (lane == 0 && p.d_abort) *p.d_abort = 2u;
+          ci = 0;
+        }
+      }
       fetched += ci;
       const bool v0 = (uint32_t)lane < ci;
       const bool v1 = ci > 64;                               // the 65th id exists in the seed list only (uniform)

@@ -359,30 +359,44 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         evals_per_launch = agg["dist_evals"] / launches
         avg_ms = (agg["front_busy_ms"] if persistent else agg["front_ms"]) / launches
         achieved = evals_per_launch * bpe / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_note = None, None
+        traffic, traffic_note, by_stream = None, None, None
         tf = os.path.join(ROOT, "profiles", f"traffic_{traffic_key}.json") if traffic_key else None
         live = getattr(ctx, "live_traffic", None) if traffic_key and traffic_key == getattr(ctx, "live_traffic_key", None) else None
         if live and live.get("bytes") and persistent:
             traffic, traffic_note = live["bytes"], live["note"]
+            # where the bytes go, from the engine's own counts: one 128-byte line per code row (rows 128 B apart; 1.6 lines of a packed
+            # 70-byte row), 256 B per adjacency row read from the HBM copy, the rest of the reads = filter words (one 128-byte line
+            # each, less what L2 served), the writes = filter stores (32 B each)
+            cs = int(agg.get("code_stride") or m)
+            rows_b = evals_per_launch * (128.0 if cs >= 128 else 128.0 * (1.0 + (m - 1) / 128.0))
+            adj_b = max(0.0, (agg["candidates"] / launches - Qr) * 256.0 - (agg["pulled_bytes"] / launches if graph == "host" else 0.0))
+            by_stream = {"code_rows": int(rows_b), "adjacency_rows_from_hbm": int(adj_b),
+                         "filter_reads": int(max(0.0, live["hbm_read"] - rows_b - adj_b)), "filter_writes": int(live["hbm_write"]),
+                         "pcie_adjacency_rows": int(live.get("pcie_read", 0))}
         elif tf and os.path.exists(tf) and ctx.world == 1:
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("search_kernel_hbm_bytes_per_launch" if persistent else "front_kernel_hbm_bytes_per_launch")
                 traffic_note = (f"HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
-                                f"(profiles/traffic_{traffic_key}.json: FETCH_SIZE + WRITE_SIZE, separate passes) -- NOT re-measured in this run"
+                                f"(profiles/traffic_{traffic_key}.json) -- NOT re-measured in this run"
                                 + (f" ({live['note']})" if live and not live.get("bytes") else ""))
             except Exception:
                 traffic = None
+        # scalars first (the driver's record keeps the leading scalars of an object), prose and nested objects behind them
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                "kernel": ("search kernel, ONE launch per batch (K5 filter + K2 PQ distance + K4 parent + K3a sort + K3b merge for every "
-                           "iteration of every query)") if persistent else "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
+                "traffic_over_algorithmic": (round(traffic / (evals_per_launch * bpe), 3) if traffic else None),
+                "k2_alone_frac": None, "k2_alone_GBps": None,
                 "algorithmic_bytes_per_launch": round(evals_per_launch * bpe, 1),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches, "bytes_per_distance_eval": bpe,
+                "kernel": ("search kernel, ONE launch per batch (K5 filter + K2 PQ distance + K4 parent + K3a sort + K3b merge for every "
+                           "iteration of every query)") if persistent else "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
                 "timer": "in-kernel s_memrealtime stamps (100 MHz) on every launch of the timed steps; cross-checked against "
                          "rocprofv3 --kernel-trace in profiles/"}
         if traffic_note:
             roof["traffic_note"] = traffic_note
+        if by_stream:
+            roof["traffic_by_stream"] = by_stream
         if persistent and graph == "host" and agg.get("graph_pull"):
             pb = agg["pulled_bytes"] / launches
             roof["pcie_pull"] = {"bytes_per_launch": int(pb), "achieved_GBps": round(pb / (avg_ms * 1e-3) / 1e9, 2),
@@ -679,10 +693,15 @@ def cpu_baseline_shape(name, ctx, args, O, L):
 # ---------------------------------------------------------------------------------------------------------- HBM traffic, live
 def live_traffic(args, log):
     """roofline.traffic measured in THIS run: two child runs of this very command (primary workload only, 3 timed steps) under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes
-    (FETCH_SIZE raw: the launch reads random 4-128-byte pieces as 64-byte requests, the x2 correction for wide coalesced reads
-    does not apply).  The children run and exit BEFORE this process initialises the GPU (they need the HBM the parent would hold).
-    Returns {bytes per launch, note} or {None, why}."""
+    `rocprofv3 --pmc` -- separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes:
+        pass A: FETCH_SIZE + TCC_EA0_RDREQ_DRAM_32B_sum      pass B: WRITE_SIZE + TCC_EA0_RDREQ_IO_32B_sum + TCC_EA0_WRREQ_sum
+    Calibration on known byte counts in this path's access shapes (tools/traffic_calib.hip, profiles/r04_traffic_calibration.md):
+    EVERY read request of gfx950's L2 to memory is a 128-byte line -- a 4-byte filter probe as much as a code row or a streamed read --
+    and FETCH_SIZE tallies each at 64 bytes (exactly half, for every shape: the guide's x2 holds throughout), while
+    TCC_EA0_RDREQ_DRAM_32B x 32 and WRITE_SIZE x 1024 (32 bytes per scattered 4-byte store) are byte-exact.  `bytes` = HBM reads
+    (DRAM_32B x 32) + HBM writes (WRITE_SIZE x 1024); reads over PCIe (the pulled adjacency rows, IO_32B x 32) are listed apart.
+    The children run and exit BEFORE this process initialises the GPU (they need the HBM the parent would hold).
+    Returns {bytes per launch, parts, note} or {None, why}."""
     import csv
     import glob
     import shutil
@@ -703,36 +722,43 @@ def live_traffic(args, log):
     if args.resident_graph:
         child.append("--resident-graph")
     env = dict(os.environ, BANG_BENCH_NO_TRAFFIC="1", TMPDIR="/tmp")
-    got, launch_us = {}, None
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    got = {}
+    passes = (("A", ("FETCH_SIZE", "TCC_EA0_RDREQ_DRAM_32B_sum")), ("B", ("WRITE_SIZE", "TCC_EA0_RDREQ_IO_32B_sum", "TCC_EA0_WRREQ_sum")))
+    for tag, counters in passes:
         d = tempfile.mkdtemp(prefix="bang_pmc_", dir="/tmp")
         t0 = time.time()
         try:
-            pr = subprocess.Popen(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+            pr = subprocess.Popen(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
                                   cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 so, _ = pr.communicate(timeout=120)                 # (a pass takes ~30 s; the run must stay within minutes whatever the profiler does)
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, signal.SIGKILL)            # (the session this call started: nothing else is in it)
                 pr.communicate()
-                return {"bytes": None, "note": f"the {counter} pass did not finish in 120 s"}
+                return {"bytes": None, "note": f"PMC pass {tag} did not finish in 120 s"}
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for r in csv.DictReader(open(f[0]))] if f else []
-            sel = [r for r in rows if "search_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            sel = [r for r in rows if "search_kernel" in r["Kernel_Name"]]
             ids = sorted({int(r["Dispatch_Id"]) for r in sel})[-steps:]                # the timed launches
             if pr.returncode != 0 or len(ids) < steps:
-                log(f"[bench] live {counter} pass FAILED: rc {pr.returncode}, {len(ids)} launches of the search kernel seen; child stdout tail: {so[-300:]!r}")
-                return {"bytes": None, "note": f"the {counter} pass failed (rc {pr.returncode}, {len(ids)} launches of the search kernel seen)"}
-            got[counter] = sum(float(r["Counter_Value"]) for r in sel if int(r["Dispatch_Id"]) in ids) * 1024.0 / steps      # KB -> bytes per launch
-            log(f"[bench] live {counter}: {got[counter] / 1e9:.3f} GB per launch of the search kernel ({time.time() - t0:.0f}s)")
+                log(f"[bench] live PMC pass {tag} FAILED: rc {pr.returncode}, {len(ids)} launches of the search kernel seen; child stdout tail: {so[-300:]!r}")
+                return {"bytes": None, "note": f"PMC pass {tag} failed (rc {pr.returncode}, {len(ids)} launches of the search kernel seen)"}
+            for c in counters:
+                got[c] = sum(float(r["Counter_Value"]) for r in sel if int(r["Dispatch_Id"]) in ids and r["Counter_Name"] == c) / steps
+            log(f"[bench] live PMC pass {tag} ({time.time() - t0:.0f}s): " + ", ".join(f"{c} = {got[c]:.4g}" for c in counters) + " per launch of the search kernel")
         except Exception as e:                                   # (a profiler problem must not cost the bench line)
-            return {"bytes": None, "note": f"the {counter} pass raised {type(e).__name__}: {e}"}
+            return {"bytes": None, "note": f"PMC pass {tag} raised {type(e).__name__}: {e}"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"bytes": int(got["FETCH_SIZE"] + got["WRITE_SIZE"]), "fetch": int(got["FETCH_SIZE"]), "write": int(got["WRITE_SIZE"]),
-            "note": f"HBM-side bytes per launch measured in THIS run: FETCH_SIZE (raw: {got['FETCH_SIZE'] / 1e9:.3f} GB) + WRITE_SIZE "
-                    f"({got['WRITE_SIZE'] / 1e9:.3f} GB) of the {steps} timed launches of the same command under rocprofv3 --pmc, one counter "
-                    f"per pass (MI355X_MICROARCH.md; the x2 correction for wide coalesced reads does not apply to random 64-byte requests)"}
+    rd = int(got["TCC_EA0_RDREQ_DRAM_32B_sum"] * 32)
+    wr = int(got["WRITE_SIZE"] * 1024)
+    io = int(got["TCC_EA0_RDREQ_IO_32B_sum"] * 32)
+    return {"bytes": rd + wr, "hbm_read": rd, "hbm_write": wr, "pcie_read": io, "fetch_size_raw": int(got["FETCH_SIZE"] * 1024),
+            "write_requests": int(got["TCC_EA0_WRREQ_sum"]),
+            "note": f"HBM bytes per launch measured in THIS run (rocprofv3 --pmc, one pass per counter group, the {steps} timed launches of the same "
+                    f"command): reads {rd / 1e9:.3f} GB = TCC_EA0_RDREQ_DRAM_32B x 32 (byte-exact on known byte counts: profiles/r04_traffic_calibration.md; "
+                    f"FETCH_SIZE tallies every 128-byte request at 64: raw {got['FETCH_SIZE'] * 1024 / 1e9:.3f} GB) + writes {wr / 1e9:.3f} GB = WRITE_SIZE "
+                    f"(32 B per scattered 4-byte store); {io / 1e9:.3f} GB more were read over PCIe (pulled adjacency rows)"}
 
 
 # ---------------------------------------------------------------------------------------------------------- build first
@@ -862,19 +888,28 @@ def main():
     out, cfg = None, {}
     if rank == 0:
         recall = prim["recall"]
+        # the first 24 keys are what the driver's record keeps: the workload, the checks and the headline numbers of every leg come first
+        # (filled in as the legs run -- a key keeps the position it was created at), the detail behind them
         cfg = {"workload": prim["wl"]["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
-               "graph": graph, "graph_placement": prim["placement_note"] or f"{graph} (requested)",
+               "graph": graph,
+               "parity_vs_oracle_first_64" if prim["structured"] else "result_properties_ok": prim["ok"],
+               "reduced_n_hip_ids_equal_oracle": None, "k2_alone_frac": None, "k2_alone_GBps": None,
+               "traffic_over_algorithmic": (res["roofline"] or {}).get("traffic_over_algorithmic"),
+               "qps_incl_init": res["qps_incl_init"],
+               "sift400m_qps": None, "sift400m_recall": None, "sift400m_L": None, "sift400m_parity_ok": None,
+               "sift100m_qps": None, "sift100m_recall": None, "sift1m_qps": None, "sift1m_recall": None,
+               "deep100m_shape_qps": None, "deep100m_shape_frac": None, "walker_qps": None,
+               "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "legs_skipped": None,
+               "graph_placement": prim["placement_note"] or f"{graph} (requested)",
                "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
                "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
                "iterations": agg["iterations"], "hops_p50": agg["hops_p50"], "hops_p99": agg["hops_p99"], "hops_max": agg["hops_max"],
                "host_loop": host_loop_name(agg, graph),
                "rerank_vectors": ("graph entries in HBM" if graph == "device" else
                                   "packed copy in HBM" if agg["vectors_on_device"] else "shipped by the walker (PCIe)"),
-               "vector_dtype": ix.dtype, "pq_code_row_stride_bytes": agg["code_stride"], "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "batches_per_step": args.batches if weak else 1,
+               "vector_dtype": ix.dtype, "pq_code_row_stride_bytes": agg["code_stride"], "batches_per_step": args.batches if weak else 1,
                "pcie_h2d_bytes_per_step": int(agg["h2d_bytes"] // args.steps),
                "pcie_pulled_bytes_per_step": int(agg["pulled_bytes"] // args.steps),
-               "qps_incl_init": res["qps_incl_init"],
-               "parity_vs_oracle_first_64" if prim["structured"] else "result_properties_ok": prim["ok"],
                "front_ms_per_step": round(agg["front_ms"] / args.steps, 3),
                "front_busy_ms_per_step": round(agg["front_busy_ms"] / args.steps, 3),
                "walker_ms_per_step": round(agg["walker_ms"] / args.steps, 3),
@@ -923,8 +958,8 @@ def main():
         try:
             k2[f"m{m_primary}"] = k2_alone(D_primary, m_primary, dtype_primary, ctx, reps=10, stride=(stride_primary if stride_primary != m_primary else 0))
             out["roofline"]["k2_alone"] = k2[f"m{m_primary}"]
-            cfg["k2_alone_frac"] = k2[f"m{m_primary}"]["frac"]
-            cfg["k2_alone_GBps"] = k2[f"m{m_primary}"]["achieved"]
+            cfg["k2_alone_frac"] = out["roofline"]["k2_alone_frac"] = k2[f"m{m_primary}"]["frac"]
+            cfg["k2_alone_GBps"] = out["roofline"]["k2_alone_GBps"] = k2[f"m{m_primary}"]["achieved"]
         except Exception as ex:
             out["roofline"]["k2_alone"] = {"error": repr(ex)[:300]}
 

@@ -356,6 +356,8 @@ typedef struct {
   uint32_t pool;                       /* self-paced form, long code rows: 1 = waves without a query of their own (a batch smaller than CUs x waves; the drain of
                                           any batch) serve the distance stage of their workgroup's queries -- the K2 pool, csrc/bang_search.hip; 0 = off.  Same results. */
   uint32_t* d_pool_jobs;               /* [Q] out, or NULL: iterations of the query whose distance stage went to the pool */
+  uint32_t n_nodes;                    /* nodes of the index, or 0: an adjacency id >= n_nodes (and not the pad value) is never expanded nor evaluated -- the row
+                                          counts as empty and *d_abort is set to 2 (a corrupt row must not become a wild read of the code table) */
   uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);

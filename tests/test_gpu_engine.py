@@ -227,6 +227,61 @@ def test_search_kernel_matches_oracle_per_query(request, libbang, fixture, L):
     assert np.array_equal(ids0, ids_o) and np.array_equal(dists0.view(np.uint32), dists_o.view(np.uint32))
 
 
+@pytest.mark.parametrize("fixture", ["small_u8", "small_deep"])
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("L", [10, 64, 152])
+def test_k2_pool_does_not_change_results(request, libbang, fixture, graph, L):
+    """Option "pool" = 1 (self-paced search kernel, long code rows): waves without a query of their own serve the distance stage of
+    their workgroup's queries with four lanes per code row (pq_row_reduce_team).  Ids, distances and the per-query counters
+    equal the oracle's -- and the pool has really served iterations."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=graph, search=1, pool=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, L)
+        e.alloc(q.shape[0])
+        for _ in range(2):
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            st = e.stats()
+            assert st["search_kernel"] == 1 and st["pool_jobs"] > 0
+            assert np.array_equal(ids, ids_o)
+            assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(q.shape[0]), st_o)
+        e.free()
+        e.unload()
+
+
+@pytest.mark.parametrize("Q", [1, 5, 700])
+def test_k2_pool_batch_sizes_and_drain(libbang, small_u8, monkeypatch, Q):
+    """The pool with one query, with fewer queries than waves, and with far more queries than wave slots on a two-workgroup grid:
+    there the waves turn into helpers one by one as the hand-out runs dry (the drain of a batch)."""
+    import bang_amd
+    from bang_amd import synth
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    rng = np.random.default_rng(5)
+    qq = np.ascontiguousarray(np.concatenate([q] * (Q // q.shape[0] + 1))[:Q])
+    qq = np.clip(qq.astype(np.int32) + rng.integers(-3, 4, qq.shape), 0, 255).astype(np.uint8)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 48, with_stats=True)
+    if Q > 100:
+        monkeypatch.setenv("BANG_SEARCH_MAX_WGS", "2")
+    with bang_amd.Engine(ix.dtype, graph=1, search=1, pool=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 48)
+        e.alloc(Q)
+        e.init(Q)
+        ids, dists = e.query(qq)
+        st = e.stats()
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+        assert np.array_equal(e.query_counters(Q), st_o)
+        assert st["pool_jobs"] > 0
+        e.free()
+        e.unload()
+
+
 @pytest.mark.parametrize("Q", [1, 2, 63, 700])
 def test_search_kernel_batch_sizes_and_handout(request, libbang, small_u8, Q):
     """Fewer queries than waves (spread over the CUs), and more queries than resident waves on a small grid (max 2 workgroups
@@ -431,6 +486,52 @@ def test_pull_rows_file_is_shared_and_validated(libbang, small_u8, small_i8, tmp
     assert np.array_equal(ids4, O.Oracle(ix2).search(q, 10, 40)[0])
     rows = np.fromfile(path, np.uint32, ix.N * 64).reshape(ix.N, 64)
     assert repl in rows[node, :deg2].tolist()
+
+
+@pytest.mark.gpu
+def test_pull_form_failures_are_reported_not_faults(libbang, small_u8, tmp_path, monkeypatch):
+    """The self-paced pull form has no host thread in its loop, so what can go wrong with the rows it reads by itself is caught at
+    both ends: (1) rows overwritten behind the engine's back (ids out of range) end the batch with an error naming the cause -- no
+    wild read of the code table, no hang -- and the engine answers correctly again once the rows are back; (2) a rows file
+    truncated between bang_load and bang_alloc is refused at bang_alloc."""
+    import os
+    import bang_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("BANG_PULL_ROWS_DIR", str(tmp_path))
+    ix, q, _, _ = small_u8
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, 40)
+    path = tmp_path / "index_pull_rows.bin"
+    with bang_amd.Engine(ix.dtype, graph=0, pull=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 40)
+        e.alloc(q.shape[0])
+        e.init(q.shape[0])
+        ids, _ = e.query(q)
+        assert np.array_equal(ids, ids_o) and e.stats()["graph_pull"] == 1
+        # (1) another process scribbles over the rows: the mapping is shared, the kernel reads what is there now
+        rows = np.memmap(path, np.uint32, "r+", shape=(ix.N, 64))
+        saved = np.array(rows[:, 0])
+        rows[:, 0] = np.uint32(ix.N + 7)
+        rows.flush()
+        e.init(q.shape[0])
+        with pytest.raises(bang_amd.BangError, match="out of range"):
+            e.query(q)
+        rows[:, 0] = saved
+        rows.flush()
+        e.init(q.shape[0])
+        ids2, dists2 = e.query(q)
+        assert np.array_equal(ids2, ids_o) and np.array_equal(dists2.view(np.uint32), dists_o.view(np.uint32))
+        del rows
+        # (2) the file shrinks between bang_load and the next bang_alloc
+        e.free()
+        size = path.stat().st_size
+        os.truncate(path, size - 4096 - 256 * 10)
+        with pytest.raises(bang_amd.BangError, match="truncated or replaced"):
+            e.alloc(q.shape[0])
+        os.truncate(path, size)                      # (grown back: the pages behind the old end read as zeros, the signature is gone)
+        with pytest.raises(bang_amd.BangError, match="signature"):
+            e.alloc(q.shape[0])
+        e.unload()
 
 
 # -------------------------------------------------------------------------------------------------------------- streamed load
