@@ -143,6 +143,8 @@ def knn_big(base: torch.Tensor, queries: torch.Tensor, k: int, col_block: int = 
     top-k over every distance tile: a tile [Q, col_block] is viewed as [Q, col_block / group, group]; the k groups with the smallest
     minima contain the tile's k nearest (a group holding one of them has a minimum <= the k-th smallest value, and at most k groups
     do), so one min-reduction + a top-k over 256 group minima + a top-k over k x group gathered values replace the big selection.
+    The tile distances are float32 |b|^2 - 2 q.b of magnitude ~1e7 for 8-bit data, i.e. good to a few units: a true neighbour within
+    rounding of a tile's k-th candidate could miss a shortlist of exactly k -- so 2k groups and 2k ids per tile are kept.
     The shortlisted ids are re-evaluated exactly and ordered by (distance, id) like knn()."""
     Nb, D = base.shape
     dev = base.device
@@ -158,16 +160,17 @@ def knn_big(base: torch.Tensor, queries: torch.Tensor, k: int, col_block: int = 
             d = torch.cat([d, torch.full((Q, group - nb % group), float("inf"), device=dev)], 1)
         ng = d.shape[1] // group
         dv = d.view(Q, ng, group)
-        gsel = torch.topk(dv.amin(dim=2), min(k, ng), dim=1, largest=False).indices          # [Q, k] groups
-        sub = torch.gather(dv, 1, gsel[:, :, None].expand(-1, -1, group)).reshape(Q, -1)      # [Q, k * group]
-        ii = torch.topk(sub, k, dim=1, largest=False).indices
+        gsel = torch.topk(dv.amin(dim=2), min(2 * k, ng), dim=1, largest=False).indices      # [Q, 2k] groups
+        sub = torch.gather(dv, 1, gsel[:, :, None].expand(-1, -1, group)).reshape(Q, -1)      # [Q, 2k * group]
+        ii = torch.topk(sub, min(2 * k, sub.shape[1]), dim=1, largest=False).indices
         ids = torch.gather(gsel, 1, ii // group) * group + ii % group + c0
         ci_all.append(ids.clamp_(max=Nb - 1))
     ci = torch.cat(ci_all, 1)
     out_i, out_d = [], []
-    for r0 in range(0, Q, 256):                                                   # exact re-evaluation of the shortlist
-        c = ci[r0:r0 + 256]
-        diff = q[r0:r0 + 256, None, :] - base[c].float()
+    rb = max(8, min(256, (1 << 26) // max(1, ci.shape[1] * D)))                   # rows per block: the gathered candidates stay below ~256 MB
+    for r0 in range(0, Q, rb):                                                    # exact re-evaluation of the shortlist
+        c = ci[r0:r0 + rb]
+        diff = q[r0:r0 + rb, None, :] - base[c].float()
         cd = (diff * diff).sum(2)
         order = torch.argsort(c, dim=1, stable=True)
         cd, c = torch.gather(cd, 1, order), torch.gather(c, 1, order)

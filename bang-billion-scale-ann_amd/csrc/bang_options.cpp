@@ -55,7 +55,7 @@ static const OptionDef kOptions[] = {
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
     {"pool", "BANG_POOL", &bang_engine::pool_opt, -1, 1, INT, ANY,
      "self-paced search kernel, long code rows: waves without a query of their own (a batch smaller than CUs x waves; the drain of any batch) serve the "
-     "distance stage of their workgroup's queries (the K2 pool); 1 = on, 0 / -1 (auto) = off: measured no faster (DESIGN 4.6).  Same results"},
+     "distance stage of their workgroup's queries (the K2 pool); 1 = on, 0 / -1 (auto) = off: measured no faster (DESIGN 4.6) and compiled in only with -DBANG_SEARCH_POOL=1 (lib_pool).  Same results"},
     // ---- may change between queries
     {"use_flag", "BANG_USE_FLAG", &bang_engine::use_flag, 0, 1, FLAG, BEFORE_ALLOC, "0 = wait for the front kernel with runtime calls instead of its in-kernel completion flag (ablation)"},
     {"compact", "BANG_COMPACT", &bang_engine::compact, 0, 1, FLAG, ANY, "launch-per-iteration loop: straggler compaction on / off"},

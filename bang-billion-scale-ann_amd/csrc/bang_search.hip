@@ -78,8 +78,13 @@ __host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx,
 // LPR lanes per row (pq_row_reduce_team: a quarter of the chunk steps per row, bit-identical sums).  Leaders never wait for a
 // helper that is not there: a job is only posted while a helper is idle, and whatever is unclaimed when the filter update is done
 // the leader reduces itself.
+// Compiled OUT of the default build: measured no faster (the helpers' chunk takes 2.8 us, two dependent memory round
+// trips like the owner's own path, and what the owner saves it loses to the hand-over and to twelve waves sharing the LDS), and the
+// extra uniform state costs the 168-VGPR instances their last free registers (SGPRs spill into VGPR lanes: 32-100 B of scratch with
+// reloads inside the row reduce, 8.0 -> 9.8 ms per SIFT1B-shape batch).  `make OUT=lib_pool EXTRA_CXXFLAGS=-DBANG_SEARCH_POOL=1` builds
+// it (option "pool" = 1 then turns it on); tests/test_gpu_pool.py runs that build against the oracle.
 #ifndef BANG_SEARCH_POOL
-#define BANG_SEARCH_POOL 1
+#define BANG_SEARCH_POOL 0
 #endif
 #ifndef BANG_POOL_LPR
 #define BANG_POOL_LPR 4             // lanes per code row in a helper wave

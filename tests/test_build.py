@@ -69,3 +69,17 @@ def test_large_builder_makes_a_searchable_index():
     ids2, _ = O.Oracle(ix2).search(synth.to_numpy(q, "uint8"), 10, 60)
     rec2 = O.recall(gt_i.numpy().astype(np.uint32), gt_d.numpy().astype(np.float32), ids2, 10)
     assert rec >= 80.0 and rec >= rec2 - 5.0, (rec, rec2)
+
+
+def test_knn_big_equals_exact_knn():
+    """synth.knn_big (the ground truth of the 1e8-2.5e8-point legs: shortlists per 65 536-column tile, exact re-evaluation) returns
+    what the plain exact search returns -- ids and distances -- on 8-bit-valued data spanning several tiles, ties included."""
+    import torch
+    from bang_amd import synth
+    g = torch.Generator().manual_seed(3)
+    base = torch.randint(0, 256, (300_000, 64), generator=g).float()
+    base[1000:1040] = base[5]                               # exact duplicates: ties are ordered by id in both
+    q = base[torch.randint(0, base.shape[0], (40,), generator=g)] + torch.randint(-2, 3, (40, 64), generator=g).float()
+    i1, d1 = synth.knn(base, q, 10, row_block=40)
+    i2, d2 = synth.knn_big(base, q, 10)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)

@@ -227,61 +227,6 @@ def test_search_kernel_matches_oracle_per_query(request, libbang, fixture, L):
     assert np.array_equal(ids0, ids_o) and np.array_equal(dists0.view(np.uint32), dists_o.view(np.uint32))
 
 
-@pytest.mark.parametrize("fixture", ["small_u8", "small_deep"])
-@pytest.mark.parametrize("graph", [0, 1])
-@pytest.mark.parametrize("L", [10, 64, 152])
-def test_k2_pool_does_not_change_results(request, libbang, fixture, graph, L):
-    """Option "pool" = 1 (self-paced search kernel, long code rows): waves without a query of their own serve the distance stage of
-    their workgroup's queries with four lanes per code row (pq_row_reduce_team).  Ids, distances and the per-query counters
-    equal the oracle's -- and the pool has really served iterations."""
-    import bang_amd
-    from oracle import oracle as O
-    ix, q, _, _ = request.getfixturevalue(fixture)
-    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, L, with_stats=True)
-    with bang_amd.Engine(ix.dtype, graph=graph, search=1, pool=1) as e:
-        e.load_index(ix)
-        e.set_searchparams(10, L)
-        e.alloc(q.shape[0])
-        for _ in range(2):
-            e.init(q.shape[0])
-            ids, dists = e.query(q)
-            st = e.stats()
-            assert st["search_kernel"] == 1 and st["pool_jobs"] > 0
-            assert np.array_equal(ids, ids_o)
-            assert np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
-            assert np.array_equal(e.query_counters(q.shape[0]), st_o)
-        e.free()
-        e.unload()
-
-
-@pytest.mark.parametrize("Q", [1, 5, 700])
-def test_k2_pool_batch_sizes_and_drain(libbang, small_u8, monkeypatch, Q):
-    """The pool with one query, with fewer queries than waves, and with far more queries than wave slots on a two-workgroup grid:
-    there the waves turn into helpers one by one as the hand-out runs dry (the drain of a batch)."""
-    import bang_amd
-    from bang_amd import synth
-    from oracle import oracle as O
-    ix, q, _, _ = small_u8
-    rng = np.random.default_rng(5)
-    qq = np.ascontiguousarray(np.concatenate([q] * (Q // q.shape[0] + 1))[:Q])
-    qq = np.clip(qq.astype(np.int32) + rng.integers(-3, 4, qq.shape), 0, 255).astype(np.uint8)
-    ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 48, with_stats=True)
-    if Q > 100:
-        monkeypatch.setenv("BANG_SEARCH_MAX_WGS", "2")
-    with bang_amd.Engine(ix.dtype, graph=1, search=1, pool=1) as e:
-        e.load_index(ix)
-        e.set_searchparams(10, 48)
-        e.alloc(Q)
-        e.init(Q)
-        ids, dists = e.query(qq)
-        st = e.stats()
-        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
-        assert np.array_equal(e.query_counters(Q), st_o)
-        assert st["pool_jobs"] > 0
-        e.free()
-        e.unload()
-
-
 @pytest.mark.parametrize("Q", [1, 2, 63, 700])
 def test_search_kernel_batch_sizes_and_handout(request, libbang, small_u8, Q):
     """Fewer queries than waves (spread over the CUs), and more queries than resident waves on a small grid (max 2 workgroups

@@ -1,0 +1,50 @@
+"""The drop-in flow through files (test_driver.cpp:338-557) at 5e6 points: an index built on the GPU, written in the reference's file
+formats, loaded by `bang_load` from the files (streamed pread, graph in host RAM) and searched by BOTH harnesses -- our bin/bang_search
+and the reference's unmodified test_driver.cpp on libbang.so -- whose printed recall column must be what the oracle computes for the
+same files at the same L."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_file_flow_recall_column_equals_the_oracles(libbang, tmp_path):
+    import bang_amd
+    from bang_amd import formats, index_build
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import file_flow
+    N, Q = 5_000_000, 2_000
+    ix, q, gt_i, gt_d = index_build.make_index_large(N, 128, "uint8", 64, 70, Q, K=10, n_clusters=512, device="cuda")
+    prefix = str(tmp_path / "flow")
+    formats.write_index(prefix, ix)
+    formats.write_bin(prefix + "_query.bin", q)
+    formats.write_truthset(prefix + "_gt.bin", gt_i, gt_d)
+    orc = O.Oracle(formats.read_index(prefix, "uint8", mmap_graph=True))            # the oracle reads the FILES too
+    want = {}
+    for L in (10, 22, 34, 46, 58, 70):
+        ids_o, _ = orc.search(q, 10, L, nthreads=min(16, os.cpu_count() or 1))
+        want[L] = O.recall(gt_i, gt_d, ids_o, 10)
+    args = [prefix, prefix + "_query.bin", prefix + "_gt.bin", str(Q), "10", "uint8", "l2", "auto"]
+    env = dict(os.environ, BANG_GRAPH="host")
+    bins = {"ours": os.path.join(os.path.dirname(os.path.dirname(bang_amd.lib_path())), "bin", "bang_search"),
+            "reference": os.path.join(ROOT, "oracle", "_ref", "ref_bang_search")}
+    seen = 0
+    for name, b in bins.items():
+        if not os.path.exists(b):
+            continue
+        r = subprocess.run([b] + args, capture_output=True, text=True, env=env, timeout=1800)
+        assert r.returncode == 0, (name, r.stdout[-1500:], r.stderr[-1500:])
+        rows = file_flow.table(r.stdout)
+        assert len(rows) >= 5 * 6
+        for L, _ms, _qps, rec in rows:
+            if L in want:
+                assert abs(rec - want[L]) < 0.006, (name, L, rec, want[L])      # (the harness prints two decimals)
+        assert max(rec for L, _a, _b, rec in rows if L <= 70) >= 90.0
+        seen += 1
+    assert seen >= 1

@@ -95,6 +95,14 @@ def usable_host_bytes() -> int:
 
 
 PULL_ROW_BYTES = 256       # host-graph placement, pull mode: the engine keeps the adjacency lists a second time as 256-byte rows
+HOST_RESERVE = 40 << 30    # streamed load: host memory left to the process beside the pull rows (the engine itself insists on 8 GB; Python, torch,
+                           # the pinned staging buffers of the load and the CPU-baseline leg's small index take the rest).  Round 3 used 75 % of
+                           # the box -- 0.94e9 rows on a 320 GB box, whose 256 GB for N = 1e9 do fit
+
+
+def stream_rows_budget():
+    """pull rows a streamed load may pin in host memory on this box, and the bytes a 1e9-row index would be short of"""
+    return max(0, usable_host_bytes() - HOST_RESERVE) // PULL_ROW_BYTES
 
 
 CODE_STRIDE = {"sift1b_shape": 128, "deep100m_shape": 128}   # device-generated code tables: rows padded to their own 128-byte line
@@ -116,7 +124,7 @@ def plan_n(name, dev, n_override=0, reserve_rows=True, stream=False, shared_byte
     N = n_override or int(os.environ.get("BANG_SHAPE_N", "0")) or sh["N"]
     if sh["graph"] == "host" and stream:
         free, _ = torch.cuda.mem_get_info(dev)
-        N = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (sh["D"] * isz + code_stride(name)))
+        N = min(N, stream_rows_budget(), (free - (28 << 30)) // (sh["D"] * isz + code_stride(name)))
     elif sh["graph"] == "host":
         N = min(N, int(usable_host_bytes() * 0.75) // (entry + (PULL_ROW_BYTES if reserve_rows else 0)))
     else:
@@ -182,10 +190,13 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
         # STREAMED: the graph image never exists -- the engine pulls the generator's entries through in chunks (vectors -> HBM,
         # adjacency lists -> 256-byte pull rows in host memory).  Host budget: the rows; HBM budget: codes + vectors + 28 GB.
         free, _total = torch.cuda.mem_get_info(dev)
-        N2 = min(N, int(usable_host_bytes() * 0.75) // PULL_ROW_BYTES, (free - (28 << 30)) // (D * isz + cs))
+        n_host, n_hbm = stream_rows_budget(), (free - (28 << 30)) // (D * isz + cs)
+        N2 = min(N, n_host, n_hbm)
         if N2 < N:
-            note = (f" (N scaled {N} -> {N2}: {PULL_ROW_BYTES}-byte pull rows in 75 % of the host memory of the box, "
-                    f"vectors + codes in HBM)")
+            short_host = max(0, N - n_host) * PULL_ROW_BYTES / 1e9
+            short_hbm = max(0, N - n_hbm) * (D * isz + cs) / 1e9
+            note = (f" (N scaled {N} -> {N2}: the box is {short_host:.1f} GB of host memory short of the {N * PULL_ROW_BYTES / 1e9:.0f} GB of pull rows "
+                    f"[{usable_host_bytes() / 1e9:.0f} GB usable, {HOST_RESERVE >> 30} GB kept free] and {short_hbm:.1f} GB of HBM short of vectors + codes + 28 GB)")
             N = N2
     elif sh["graph"] == "host":
         budget = int(usable_host_bytes() * 0.75)
