@@ -237,19 +237,19 @@ def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tens
     distinct, sorted ascending by distance, padding id -1 / distance +inf: (ids [N, K1 + slots] of near_i.dtype, d2 f32)."""
     N, K1 = near_i.shape
     dev = x.device
-    rev = torch.full((N * slots,), -1, dtype=torch.int64, device=dev)
+    rev = torch.full((N * slots,), -1, dtype=(torch.int32 if N < (1 << 31) else torch.int64), device=dev)   # (2e8 points x 24 slots: 19 GB instead of 38)
     for s in range(0, N, block):
         c = near_i[s:s + block].long()
         p = torch.arange(s, s + c.shape[0], device=dev)[:, None].expand_as(c)
         ok = c >= 0
         cc, pp = c[ok], p[ok]
         slot = ((pp * 0x9E3779B1 + cc * 0x85EBCA77) >> 7) % slots
-        rev.scatter_reduce_(0, cc * slots + slot, pp, reduce="amax", include_self=True)
+        rev.scatter_reduce_(0, cc * slots + slot, pp.to(rev.dtype), reduce="amax", include_self=True)
     rev = rev.view(N, slots)
     out_i = torch.empty((N, K1 + slots), dtype=near_i.dtype, device=dev)
     out_d = torch.empty((N, K1 + slots), dtype=torch.float32, device=dev)
     for s in range(0, N, 1 << 18):
-        r = rev[s:s + (1 << 18)]
+        r = rev[s:s + (1 << 18)].long()
         B = r.shape[0]
         xr = x[r.clamp_min(0)].float()                            # [B, slots, D]
         xp = x[s:s + B].float()
@@ -308,15 +308,21 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
         log(f"[build] robust prune (alpha {alpha}): {float(kept.sum(1).float().mean()):.1f} of {K} kept on average, {time.time() - t0:.1f}s")
     near_i, near_d = _compact_kept(ci, cd, kept, keep1)
     del ci, cd, kept
+    if x.is_cuda:
+        torch.cuda.empty_cache()                                 # (the next tables are of other shapes: cached blocks would only fragment the pool)
     if reverse:
         t0 = time.time()
         mi, md = reverse_candidates(x, near_i, near_d, slots=max(8, R // 2 - 8))
         del near_i, near_d
+        if x.is_cuda:
+            torch.cuda.empty_cache()
         kept2 = robust_prune(x, mi, md, keep=n_near, alpha=alpha)
         near_i, near_d = _compact_kept(mi, md, kept2, n_near)
         if log:
             log(f"[build] reverse edges + second prune: {float(kept2.sum(1).float().mean()):.1f} near neighbours per point, {time.time() - t0:.1f}s")
         del mi, md, kept2, near_d
+        if x.is_cuda:
+            torch.cuda.empty_cache()
     g = synth._gen(seed + 1, dev)
     adj_out = torch.zeros((N, R), dtype=idx_dtype, device=dev)
     deg_out = torch.empty(N, dtype=torch.int64, device=dev)
