@@ -282,6 +282,13 @@ class Engine:
         _check(lib().bang_get_query_counters(self._h, _vp(cols[2]), _vp(cols[3]), _vp(cols[1]), _vp(cols[0])), "bang_get_query_counters")
         return np.stack(cols, axis=1).astype(np.int64)
 
+    def candidate_log(self, Q: int, L: int):
+        """(ids [Q][L + 50] u32, counts [Q]): the nodes every query of the last batch expanded, in expansion order."""
+        ids = np.zeros((Q, L + EXTRA_ITERS), np.uint32)
+        cnt = np.zeros(Q, np.uint32)
+        _check(lib().bang_get_candidate_log(self._h, _vp(ids), C.c_uint32(ids.shape[1]), _vp(cnt)), "bang_get_candidate_log")
+        return ids, cnt
+
     def free(self):
         _check(lib().bang_free_e(self._h), "bang_free")
 

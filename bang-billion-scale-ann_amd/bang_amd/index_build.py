@@ -287,6 +287,11 @@ def _compact_kept(ci: torch.Tensor, cd: torch.Tensor, kept: torch.Tensor, width:
     return out_i, out_d
 
 
+def _count_true(mask: torch.Tensor, block: int = 1 << 22) -> int:
+    """number of True entries, block by block (a reduction over a bool tensor first widens ALL of it to int64: 83 GiB for 2e8 x 56)"""
+    return sum(int(torch.count_nonzero(mask[a:a + block])) for a in range(0, mask.shape[0], block))
+
+
 def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None,
                       reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64,
                       links: str = "smallworld", select: str = "topk"):
@@ -305,7 +310,7 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
     keep1 = min(n_near, R // 2)
     kept = robust_prune(x, ci, cd, keep=keep1, alpha=alpha)
     if log:
-        log(f"[build] robust prune (alpha {alpha}): {float(kept.sum(1).float().mean()):.1f} of {K} kept on average, {time.time() - t0:.1f}s")
+        log(f"[build] robust prune (alpha {alpha}): {_count_true(kept) / N:.1f} of {K} kept on average, {time.time() - t0:.1f}s")
     near_i, near_d = _compact_kept(ci, cd, kept, keep1)
     del ci, cd, kept
     if x.is_cuda:
@@ -319,7 +324,7 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
         kept2 = robust_prune(x, mi, md, keep=n_near, alpha=alpha)
         near_i, near_d = _compact_kept(mi, md, kept2, n_near)
         if log:
-            log(f"[build] reverse edges + second prune: {float(kept2.sum(1).float().mean()):.1f} near neighbours per point, {time.time() - t0:.1f}s")
+            log(f"[build] reverse edges + second prune: {_count_true(kept2) / N:.1f} near neighbours per point, {time.time() - t0:.1f}s")
         del mi, md, kept2, near_d
         if x.is_cuda:
             torch.cuda.empty_cache()

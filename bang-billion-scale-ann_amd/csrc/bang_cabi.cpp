@@ -388,6 +388,16 @@ extern "C" int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, u
   return BANG_OK;
 }
 
+extern "C" int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts) {
+  if (!e || !ids || !counts) return BANG_ERR_ARG;
+  if (!e->allocated || e->Qcur <= 0) { bang_set_error("bang_get_candidate_log: no query has run on this allocation"); return BANG_ERR_ARG; }
+  if (stride < e->cand_stride) { bang_set_error("bang_get_candidate_log: stride %u < %u (L + 50)", stride, e->cand_stride); return BANG_ERR_ARG; }
+  const size_t Q = (size_t)e->Qcur;
+  HIP_TRY(hipMemcpy(counts, e->d_cand_cnt, Q * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(ids, (size_t)stride * 4, e->d_cand_ids, (size_t)e->cand_stride * 4, (size_t)e->cand_stride * 4, Q, hipMemcpyDeviceToHost));
+  return BANG_OK;
+}
+
 extern "C" int bang_free_e(bang_engine_t* e) {
   if (!e) return BANG_ERR_ARG;
   if (e->allocated) { (void)hipSetDevice(e->device); free_batch(e); }

@@ -286,7 +286,11 @@ static int cache_rows_in_hbm(bang_engine* e) {
   if (hipMalloc((void**)&e->d_rows_hbm, n * 256) != hipSuccess) { (void)hipGetLastError(); e->d_rows_hbm = nullptr; return BANG_OK; }
   const size_t step = (size_t)1 << 30;
   for (size_t off = 0; off < n * 256; off += step)
-    HIP_TRY(hipMemcpy((uint8_t*)e->d_rows_hbm + off, (const uint8_t*)e->h_adj + off, std::min(step, n * 256 - off), hipMemcpyHostToDevice));
+    if (hipMemcpy((uint8_t*)e->d_rows_hbm + off, (const uint8_t*)e->h_adj + off, std::min(step, n * 256 - off), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();                             // the copy is an optimisation: without it every row is pulled over PCIe, nothing fails
+      dfree(e->d_rows_hbm);
+      return BANG_OK;
+    }
   e->n_rows_hbm = (uint32_t)n;
   if (env_flag("BANG_DEBUG")) fprintf(stderr, "[bang] %zu of %u adjacency rows (%.1f GB) also in HBM\n", n, e->N, n * 256 / 1e9);
   return BANG_OK;

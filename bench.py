@@ -203,10 +203,18 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
         vec = torch.empty(ix.N * vb + 256, dtype=torch.uint8, device=ctx.dev)
         h = torch.zeros(1, dtype=torch.int64, device=ctx.cdev)
         t0 = time.time()
+        status = torch.zeros(1, dtype=torch.int64, device=ctx.cdev)       # rank 0's load may fail (rows file does not fit tmpfs ...): every rank
+        err = None                                                         # learns it from this word and raises, instead of hanging in the broadcast
         if ctx.rank == 0:
-            eng.load_stream(ix, src[0], C.byref(src[1]), d_codes=wl["d_codes"], code_stride=getattr(ix, "code_stride", 0), d_vectors=vec.data_ptr())
-            hv_ = eng.rows_hash()
-            h[0] = hv_ - (1 << 64) if hv_ >= (1 << 63) else hv_          # (u64 -> the int64 the collective carries)
+            try:
+                eng.load_stream(ix, src[0], C.byref(src[1]), d_codes=wl["d_codes"], code_stride=getattr(ix, "code_stride", 0), d_vectors=vec.data_ptr())
+                hv_ = eng.rows_hash()
+                h[0] = hv_ - (1 << 64) if hv_ >= (1 << 63) else hv_      # (u64 -> the int64 the collective carries)
+            except Exception as ex:                                        # noqa: BLE001
+                err, status[0] = ex, 1
+        dist.broadcast(status, 0)
+        if int(status.item()) != 0:
+            raise RuntimeError(f"rank 0 could not load the index: {err}" if err else "rank 0 could not load the index (see its log)")
         dist.broadcast(h, 0)
         t1 = time.time()
         if ctx.cdev == ctx.dev:
@@ -236,9 +244,17 @@ def make_engine(wl, graph, ctx, lanes=0, threads=0, timing=1, pull=-1):
     if ctx.world > 1 and wl.get("shared_dir"):
         # one copy of the pull rows per node: rank 0 builds the rows file in the shared directory, the others map it
         os.environ["BANG_PULL_ROWS_DIR"] = wl["shared_dir"]
+        import torch
+        status = torch.zeros(1, dtype=torch.int64, device=ctx.cdev)
+        err = None
         if ctx.rank == 0:
-            load()
-        dist.barrier()
+            try:
+                load()
+            except Exception as ex:                                        # noqa: BLE001  (the other ranks must not wait for a barrier that never comes)
+                err, status[0] = ex, 1
+        dist.broadcast(status, 0)
+        if int(status.item()) != 0:
+            raise RuntimeError(f"rank 0 could not load the index: {err}" if err else "rank 0 could not load the index (see its log)")
         if ctx.rank != 0:
             load()
     else:
@@ -981,6 +997,8 @@ def main():
         try:
             fn()
         except Exception as ex:                              # a leg must never take the primary line down
+            import traceback
+            log(f"[bench] leg {key} FAILED:\n" + traceback.format_exc())
             cfg[key] = {"error": repr(ex)[:300]}
             cfg[key.replace("at_", "") + "_error"] = repr(ex)[:120]
             torch.cuda.empty_cache()

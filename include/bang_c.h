@@ -189,6 +189,10 @@ int bang_get_stats(bang_engine_t* e, bang_stats* out);
  * of iterations the query ran.  Test hook: the oracle reports the same four numbers per query. */
 int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, uint32_t* fetched, uint32_t* candidates, uint32_t* iterations);
 
+/* The candidate log of the last bang_query_e (bang_search.cu:1451-1458: the nodes a query expanded, in expansion order, [0] = MEDOID): ids
+ * [num_queries][stride] with stride >= L + 50, counts [num_queries].  Analysis hook (which adjacency rows a batch really reads). */
+int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts);
+
 /* The reference's own C mirror (bang.h:91-100), uint8 only, one process-global engine. */
 int bang_load_c(char* indexfile_path_prefix);
 int bang_set_searchparams_c(int recall, int worklist_length, int nDistFunc);

@@ -10,9 +10,12 @@ export BANG_BENCH_NO_L200=1     # keep the timed steps the LAST launches of the 
 OUT=gpurun_out/prof_${TAG}
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/bench_pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/bench_pmc_write.err"
+python3 -c "import __graft_entry__ as g; g.build()" || exit 1     # build BEFORE profiling: no compiler may start under rocprofv3 --pmc
+PY=$(python3 -c "import os,sys; print(os.path.realpath(sys.executable))")
+export BANG_NO_BUILD=1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "$PY" bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- "$PY" bench.py $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/bench_pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- "$PY" bench.py $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/bench_pmc_write.err"
 python3 tools/summarize_profile.py "$OUT" "$TTAG" > "$OUT/summary.md" 2> "$OUT/summary.err"
 mkdir -p gpurun_out/profiles_out
 cp "$OUT/summary.md" gpurun_out/profiles_out/${TAG}_summary.md

@@ -8,11 +8,14 @@ TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_k2
 rm -rf "$OUT"; mkdir -p "$OUT" gpurun_out/profiles_out
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/k2_alone.py --big > "$OUT/k2_trace.jsonl" 2> "$OUT/k2_trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/k2_alone.py --big > "$OUT/k2_fetch.jsonl" 2> "$OUT/k2_fetch.err"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d "$OUT/pmc_l2" -- python3 tools/k2_alone.py --big > "$OUT/k2_l2.jsonl" 2> "$OUT/k2_l2.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d "$OUT/pmc_sq1" -- python3 tools/k2_alone.py --big > "$OUT/k2_sq1.jsonl" 2> "$OUT/k2_sq1.err"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 tools/k2_alone.py --big > "$OUT/k2_sq2.jsonl" 2> "$OUT/k2_sq2.err"
+python3 -c "import __graft_entry__ as g; g.build()" || exit 1     # build BEFORE profiling: no compiler may start under rocprofv3 --pmc
+PY=$(python3 -c "import os,sys; print(os.path.realpath(sys.executable))")
+export BANG_NO_BUILD=1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "$PY" tools/k2_alone.py --big > "$OUT/k2_trace.jsonl" 2> "$OUT/k2_trace.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- "$PY" tools/k2_alone.py --big > "$OUT/k2_fetch.jsonl" 2> "$OUT/k2_fetch.err"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d "$OUT/pmc_l2" -- "$PY" tools/k2_alone.py --big > "$OUT/k2_l2.jsonl" 2> "$OUT/k2_l2.err"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d "$OUT/pmc_sq1" -- "$PY" tools/k2_alone.py --big > "$OUT/k2_sq1.jsonl" 2> "$OUT/k2_sq1.err"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- "$PY" tools/k2_alone.py --big > "$OUT/k2_sq2.jsonl" 2> "$OUT/k2_sq2.err"
 python3 - "$OUT" > gpurun_out/profiles_out/${TAG}_k2_alone.md <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]

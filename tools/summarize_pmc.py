@@ -4,9 +4,10 @@ of the timed launches of the search kernel, and every PMC counter per launch of 
 small JSON with the HBM traffic per launch that bench.py quotes as roofline.traffic.
 
 Units / corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KB (TCC_EA0_RDREQ/WRREQ based).  FETCH_SIZE
-reads exactly half the bytes of a WIDE COALESCED read stream on gfx950 (128-B requests tallied at 64 B); this kernel's reads
-are random 4-74-byte probes (64-B requests), which that correction does not apply to and which the guide calls uncalibrated:
-the raw value and the x2 upper bound are both listed, `traffic` uses the raw value."""
+tallies every read request of gfx950's L2 at 64 bytes although each is a 128-byte line -- for EVERY access shape of this path
+(4-byte probes, 128-byte code rows, streamed reads alike: tools/traffic_calib.hip on known byte counts,
+profiles/r04_traffic_calibration.md) -- so the read bytes are 2 x FETCH_SIZE, and TCC_EA0_RDREQ_DRAM_32B x 32 (pass `dram`) gives them
+byte-exactly; WRITE_SIZE is exact (32 bytes per scattered 4-byte store).  `traffic` = DRAM reads + writes."""
 import csv
 import glob
 import json
@@ -114,9 +115,13 @@ print()
 c = counters
 print("## derived\n")
 if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
-    fetch, write = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
-    print(f"* HBM-side traffic per launch: FETCH_SIZE {fetch/1e9:.3f} GB (raw; x2 upper bound {2*fetch/1e9:.3f} GB) + WRITE_SIZE {write/1e9:.3f} GB "
-          f"= {(fetch+write)/1e9:.3f} GB")
+    fetch_raw, write = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+    dram = c.get("TCC_EA0_RDREQ_DRAM_32B_sum", 0.0) * 32
+    io = c.get("TCC_EA0_RDREQ_IO_32B_sum", 0.0) * 32
+    fetch = dram if dram else 2 * fetch_raw - io                # (every request is a 128-byte line tallied at 64; the PCIe share is not HBM traffic)
+    print(f"* HBM traffic per launch: reads {fetch/1e9:.3f} GB (" + (f"TCC_EA0_RDREQ_DRAM_32B x 32; " if dram else "2 x FETCH_SIZE - PCIe reads; ") +
+          f"FETCH_SIZE raw {fetch_raw/1e9:.3f} GB tallies each 128-byte request at 64) + writes WRITE_SIZE {write/1e9:.3f} GB = {(fetch+write)/1e9:.3f} GB"
+          + (f"; {io/1e9:.3f} GB more read over PCIe (TCC_EA0_RDREQ_IO_32B x 32: pulled adjacency rows)" if io else ""))
     rf = (bench.get("trace") or {}).get("roofline") or {}
     alg = rf.get("algorithmic_bytes_per_launch")
     if alg:
@@ -125,11 +130,11 @@ if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         print(f"* over the {timed_avg_us:.0f} us of a launch: {(fetch+write)/timed_avg_us/1e3:.0f} GB/s of HBM-side traffic")
     if tag:
         js = {"search_kernel_hbm_bytes_per_launch": round(fetch + write), "kernel": dom_name,
-              "fetch_bytes_per_launch_raw": round(fetch), "fetch_bytes_per_launch_x2_upper_bound": round(2 * fetch),
+              "fetch_size_raw_bytes_per_launch": round(fetch_raw), "hbm_read_bytes_per_launch": round(fetch), "pcie_read_bytes_per_launch": round(io),
               "write_bytes_per_launch": round(write), "algorithmic_bytes_per_launch": alg,
               "rocprof_timed_launches_avg_us": timed_avg_us, "bench_in_kernel_timer_avg_us": rf.get("avg_launch_us"),
-              "note": "FETCH_SIZE raw (random 64-B requests: the gfx950 x2 correction for wide coalesced reads does not apply; "
-                      "uncalibrated per the guide) + WRITE_SIZE, separate --pmc passes of the same bench command"}
+              "note": "reads = TCC_EA0_RDREQ_DRAM_32B x 32 where that pass ran, else 2 x FETCH_SIZE (every request a 128-byte line tallied at 64: "
+                      "profiles/r04_traffic_calibration.md) less the PCIe reads; writes = WRITE_SIZE; separate --pmc passes of the same bench command"}
         json.dump(js, open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
 if "TCC_HIT_sum" in c:
     h, m = c["TCC_HIT_sum"], c.get("TCC_MISS_sum", 0.0)
