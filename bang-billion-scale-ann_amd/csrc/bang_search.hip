@@ -180,8 +180,18 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 // with p >= 192 share the positions p - 192: a set bit then also covers an alias, which only costs that word its shortcut),
 // register p >> 5, bit p & 31.  Read: six ds_bpermute (no LDS memory touched) + selects.  Set: the survivors' bits are transposed
 // through 128 (256) words of the wave's LDS scratch, two (four) registers per pass (ds_or_b32), and OR-ed into the registers.
+// HALF-WORD units (-DBANG_SUMMARY_HALFWORDS=1: NR = 12 registers, self-paced 168-VGPR instances): one bit per 16-bit half of a filter
+// word -- 25 024 units, probed with 16-bit loads and updated with 16-bit stores.  A query sets ~22 K of its 400 K slots in 201
+// iterations: at the end a WORD is still untouched with probability e^-1.8, a HALF-WORD with e^-0.9 -- measured 65 % of all probes
+// need no load instead of 46 % (DEEP100M-shape: 147 M of 225 M per batch instead of 103 M), and every probe that does reach memory
+// moves a whole 128-byte line (profiles/r04_traffic_calibration.md).  NOT the default: bit-identical (all GPU tests green with it),
+// but the twelve ds_bpermute per probe and the third transposition pass cost more than the saved requests give back -- SIFT1B-shape
+// 8.31 -> 8.57 ms per 10 K batch, a 1 250-query shard 1.74 -> 1.87 ms, DEEP100M-shape 7.53 -> 7.51 ms.
 #ifndef BANG_FILTER_SUMMARY
 #define BANG_FILTER_SUMMARY 1
+#endif
+#ifndef BANG_SUMMARY_HALFWORDS
+#define BANG_SUMMARY_HALFWORDS 0
 #endif
 // the row reduce as a software pipeline over groups of 8 chunks (pq_row_reduce_pipe): search kernel / K2 streaming kernel
 // the filter's stores issued behind the arrival of the code rows instead of in front of the wait for them
@@ -194,7 +204,7 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 #ifndef BANG_K2_REDUCE_PIPE
 #define BANG_K2_REDUCE_PIPE 0
 #endif
-#define SUMM_REGS 6
+template <int SUMM_REGS>                               // 6: one bit per filter word; 12: one bit per half-word
 struct FilterSummary {
   uint32_t s[SUMM_REGS];
   __device__ __forceinline__ void clear() {
@@ -222,6 +232,7 @@ struct FilterSummary {
     const uint32_t pa = pos_of(wa), pb = pos_of(wb), pc0 = pos_of(wc0), pc1 = pos_of(wc1);
 #pragma unroll
     for (int pass = 0; pass < (SUMM_REGS + RP - 1) / RP; ++pass) {
+      if (RP == 2 ? 2 * pass >= SUMM_REGS : 4 * pass >= SUMM_REGS) break;
       const bool ia = ha && (pa >> 5) / RP == (uint32_t)pass, ib = hb && (pb >> 5) / RP == (uint32_t)pass;
       const bool ic0 = hc && (pc0 >> 5) / RP == (uint32_t)pass, ic1 = hc && (pc1 >> 5) / RP == (uint32_t)pass;
       if (__ballot(ia || ib || ic0 || ic1) == 0) continue;                         // uniform
@@ -235,10 +246,12 @@ struct FilterSummary {
       wave_sync();
       if (RP == 2) {
         const uint2 v = *(const uint2*)(tbl + 2 * lane);
-        s[2 * pass] |= v.x; s[2 * pass + 1] |= v.y;
+        s[2 * pass] |= v.x;
+        if (2 * pass + 1 < SUMM_REGS) s[2 * pass + 1] |= v.y;
       } else {
         const uint4 v = *(const uint4*)(tbl + 4 * lane);
-        s[4 * pass] |= v.x; s[4 * pass + 1] |= v.y;
+        s[4 * pass] |= v.x;
+        if (4 * pass + 1 < SUMM_REGS) s[4 * pass + 1] |= v.y;
         if (4 * pass + 2 < SUMM_REGS) s[4 * pass + 2] |= v.z;
         if (4 * pass + 3 < SUMM_REGS) s[4 * pass + 3] |= v.w;
       }
@@ -581,7 +594,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   };
   // which words of the current query's filter have been stored to (self-paced form; the host-paced instances have no registers to spare)
   constexpr bool SUMM = (BANG_FILTER_SUMMARY != 0) && (!HOST || search_maxt(NDW, HOST) < 1024);   // (needs 6 VGPRs the 16-wave host-paced instances do not have)
-  FilterSummary summ;
+  // unit of the summary = unit of the filter's loads and plain stores: a 32-bit word, or (12 registers, the 168-VGPR instances) a half-word
+  constexpr int SR = (SUMM && BANG_SUMMARY_HALFWORDS && !HOST && search_maxt(NDW, HOST) < 1024) ? 12 : 6;   // (the host-paced instances spill with 12)
+  constexpr uint32_t UB = (SR == 12) ? 4u : 5u, UM = (1u << UB) - 1u;
+  FilterSummary<SR> summ;
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
   uint32_t pool_jobs = 0;                          // diagnostic counter (d_pool_jobs): iterations whose distance stage went to the K2 pool
@@ -735,17 +751,22 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // A word the summary knows to be untouched is zero: no request (FilterSummary).
       bool la = v0, lb = v0;                                 // load word a / b?
       if (SUMM) {
-        la = summ.test(h0a >> 5) && v0;
-        lb = summ.test(h0b >> 5) && v0;
+        la = summ.test(h0a >> UB) && v0;
+        lb = summ.test(h0b >> UB) && v0;
         probes_skipped += (uint32_t)__popcll(__ballot(v0 && !la)) + (uint32_t)__popcll(__ballot(v0 && !lb));
       }
-      if (la) w0a = ld_bypass_l1(&bloom[h0a >> 5]);
-      if (lb) w0b = ld_bypass_l1(&bloom[h0b >> 5]);
+      if (UB == 5u) {
+        if (la) w0a = ld_bypass_l1(&bloom[h0a >> 5]);
+        if (lb) w0b = ld_bypass_l1(&bloom[h0b >> 5]);
+      } else {                                               // (global_load_ushort sc1)
+        if (la) w0a = __hip_atomic_load((const uint16_t*)bloom + (h0a >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lb) w0b = __hip_atomic_load((const uint16_t*)bloom + (h0b >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (v1) {
         h1a = hash1(x1); h1b = hash2(x1);
         if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
       }
-      const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
+      const bool pass0 = v0 && !(((w0a >> (h0a & UM)) & 1u) && ((w0b >> (h0b & UM)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
       const uint64_t m1 = __ballot(pass1);
@@ -793,17 +814,22 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       bool pa = pass0, pb = pass0, st_a = false, st_b = false;
       uint32_t sv_a = 0, sv_b = 0;
       if (POOL && pooled) {         // (the first 128 words of the scratch are the job's ids and distances: claim table and transposition area behind them)
-        filter_commit<128>(scratch + 128, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
-        if (SUMM) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+        filter_commit<128>(scratch + 128, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
+        if (SUMM) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
       } else {
-        filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+        filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
         // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-        if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+        if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
       }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
-        if (st_a) bloom[h0a >> 5] = sv_a;
-        if (st_b) bloom[h0b >> 5] = sv_b;
+        if (UB == 5u) {
+          if (st_a) bloom[h0a >> 5] = sv_a;
+          if (st_b) bloom[h0b >> 5] = sv_b;
+        } else {                                             // (global_store_short: the other half of the word is not touched)
+          if (st_a) ((uint16_t*)bloom)[h0a >> 4] = (uint16_t)sv_a;
+          if (st_b) ((uint16_t*)bloom)[h0b >> 4] = (uint16_t)sv_b;
+        }
         const uint64_t left = __ballot(pa || pb || pass1);
         if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
