@@ -826,3 +826,23 @@ def test_rows_partly_in_hbm_do_not_change_results(request, libbang, fixture, mon
     monkeypatch.delenv("BANG_ROWS_HBM_MAX_ROWS")
     full = run(rows_hbm=64)
     assert full["rows_in_hbm"] == ix.N and full["pulled_bytes"] == 0
+
+
+def test_candidate_log_hook(libbang, small_u8):
+    """bang_get_candidate_log: the nodes every query expanded, in expansion order ([0] = MEDOID, bang_search.cu:452-464,1451-1458) --
+    lengths = the per-query candidate counters, every returned id among them (the re-rank only sees expanded nodes)."""
+    import bang_amd
+    ix, q, _, _ = small_u8
+    with bang_amd.Engine(ix.dtype, graph=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 48)
+        e.alloc(q.shape[0])
+        e.init(q.shape[0])
+        ids, _ = e.query(q)
+        cand, cnt = e.candidate_log(q.shape[0], 48)
+        ctr = e.query_counters(q.shape[0])
+        e.free(); e.unload()
+    assert np.array_equal(cnt.astype(np.int64), ctr[:, 1]) and (cand[:, 0] == ix.medoid).all()
+    for i in range(q.shape[0]):
+        log = set(cand[i, :cnt[i]].tolist())
+        assert len(log) == cnt[i] and all(int(x) in log for x in ids[i])

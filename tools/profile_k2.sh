@@ -45,7 +45,7 @@ if f:
         du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp]
         print(f"| m = {m} | {len(grp)} | {sum(du)/len(du):.1f} | {min(du):.1f} | {max(du):.1f} | {grp[0]['Kernel_Name'].split('(')[0][:60]} |")
     print()
-for name, label in (("pmc_fetch", "FETCH_SIZE (KB; raw -- random 32-74-byte rows are 64-byte requests, the gfx950 x2 correction for wide coalesced reads does not apply)"),
+for name, label in (("pmc_fetch", "FETCH_SIZE (KB; tallies every read request at 64 bytes although each is a 128-byte line: HBM bytes = 2 x FETCH_SIZE = TCC_EA0_RDREQ x 128, profiles/r04_traffic_calibration.md)"),
                     ("pmc_l2", "L2 / fabric counters"),
                     ("pmc_sq1", "where the wave cycles go (SQ, quad-cycles summed over waves)"),
                     ("pmc_sq2", "instructions and LDS bank conflicts (SQ)")):
