@@ -104,7 +104,14 @@ int alloc_buffers(bang_engine* e, int Q) {
   HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));
   else BANG_TRY(dmalloc(&e->d_lut, nq * e->m * 256));                       // :380
-  BANG_TRY(dmalloc(&e->d_bloom, nq * BANG_BF_WORDS));                        // :393 (bit-packed: 8x smaller)
+  // :393 (bit-packed: 8x smaller).  BANG_FILTER_MEM: 1 = uncached, 2 = fine-grained device memory (experiment: does a filter probe
+  // still move a whole 128-byte line when L2 does not cache the filter?  DESIGN 4.6)
+  {
+    const long fm = env_long("BANG_FILTER_MEM", 0);
+    if (fm == 1 || fm == 2) {
+      HIP_TRY(hipExtMallocWithFlags((void**)&e->d_bloom, std::max<size_t>(nq * BANG_BF_WORDS * 4, 16), fm == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    } else BANG_TRY(dmalloc(&e->d_bloom, nq * BANG_BF_WORDS));
+  }
   BANG_TRY(dmalloc(&e->d_nbrs, nq * BANG_NBR_STRIDE));
   BANG_TRY(dmalloc(&e->d_dist, nq * BANG_NBR_STRIDE));
   BANG_TRY(dmalloc(&e->d_cnt, nq));

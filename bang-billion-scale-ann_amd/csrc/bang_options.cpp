@@ -79,6 +79,7 @@ static const SwitchDef kSwitches[] = {
     {"BANG_GRAPH_MMAP", "0 = private copy of the graph file (transparent huge pages) instead of a shared read-only mapping"},
     {"BANG_SEARCH_MAX_WGS", "search kernel: cap on workgroups (experiments / tests)"},
     {"BANG_SEARCH_MAX_WAVES", "search kernel: cap on waves per workgroup"},
+    {"BANG_FILTER_MEM", "visited filters in 1 = uncached / 2 = fine-grained device memory instead of ordinary device memory (experiment, read at bang_alloc)"},
     {"BANG_POOL_HELPERS", "search kernel, K2 pool: cap on the waves launched beyond those that own a query from the start (experiments)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},

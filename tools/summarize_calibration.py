@@ -17,8 +17,12 @@ for p in sorted(glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv
     disp = sorted({int(r["Dispatch_Id"]) for r in rows})
     # launches come in two rounds of len(order): the second round is the warm one
     second = disp[len(order):2 * len(order)] if len(disp) >= 2 * len(order) else disp[-len(order):]
+    extra = disp[2 * len(order):][-2:]                        # (the uncached-memory probes / stores: last round)
     for r in rows:
         d = int(r["Dispatch_Id"])
+        if d in extra:
+            k = ("probe4_uncached", "store4_uncached")[extra.index(d)]
+            vals[k][r["Counter_Name"]] = vals[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         if d in second:
             vals[order[second.index(d)]][r["Counter_Name"]] = vals[order[second.index(d)]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 print("# gfx950 memory-side counters against known byte counts (tools/traffic_calib.hip, 16 GB table, second launch of each kernel)\n")
@@ -41,7 +45,11 @@ print("| kernel | unit | FETCH_SIZE x 1024 | + 64 x RDREQ_128B | 32 x (RDREQ_DRA
 print("|---|---|---|---|---|---|---|---|---|")
 for k, unit, n in (("rows128", "row of 128 B", known["rows128"]["rows"]), ("rows70", "row of 70 B (packed)", known["rows70"]["rows"]),
                    ("probe4", "4-byte probe", known["probe4"]["probes"]), ("store4", "4-byte store", known["store4"]["stores"]),
-                   ("stream", "byte streamed", known["stream"]["bytes"])):
+                   ("stream", "byte streamed", known["stream"]["bytes"]),
+                   ("probe4_uncached", "4-byte probe, uncached device memory", known["probe4"]["probes"]),
+                   ("store4_uncached", "4-byte store, uncached device memory", known["store4"]["stores"])):
+    if k not in vals:
+        continue
     f = g(k, "FETCH_SIZE") * 1024
     f2 = f + 64 * g(k, "TCC_EA0_RDREQ_128B_sum")
     dr = 32 * (g(k, "TCC_EA0_RDREQ_DRAM_32B_sum") + g(k, "TCC_EA0_RDREQ_IO_32B_sum"))

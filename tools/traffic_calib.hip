@@ -73,6 +73,19 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(threads), 0, 0, (const uint4*)t, table / 16, out);
     CHECK(hipDeviceSynchronize());
   }
+  // the same probes / stores on UNCACHED device memory (is a 4-byte access still a 128-byte line when L2 does not cache the table?)
+  {
+    uint8_t* u = nullptr;
+    const uint64_t ub = 4ull << 30;
+    if (hipExtMallocWithFlags((void**)&u, ub, hipDeviceMallocUncached) == hipSuccess) {
+      CHECK(hipMemset(u, 1, ub));
+      for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_probe4, dim3(blocks), dim3(threads), 0, 0, (const uint32_t*)u, ub / 4, it_p, out);
+        hipLaunchKernelGGL(k_store4, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)u, ub / 4, it_p);
+        CHECK(hipDeviceSynchronize());
+      }
+    } else fprintf(stderr, "no uncached device memory\n");
+  }
   // known counts per launch, in launch order (JSON on stdout: the summary script joins them with the counter CSV by dispatch order)
   printf("{\"table_bytes\": %llu, \"launch_order\": [\"rows128\", \"rows70\", \"probe4\", \"store4\", \"stream\"], "
          "\"rows128\": {\"rows\": %llu, \"bytes\": %llu}, \"rows70\": {\"rows\": %llu, \"useful_bytes\": %llu}, "
