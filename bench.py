@@ -405,6 +405,10 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                 "traffic_over_algorithmic": (round(traffic / (evals_per_launch * bpe), 3) if traffic else None),
+                # what the launch MOVES (every read request a 128-byte line, 32 B per scattered store) against the same peak: the algorithmic
+                # fraction above counts m + 8 bytes per evaluation, the memory system carries ~4x that
+                "hbm_traffic_GBps": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None),
+                "hbm_traffic_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
                 "k2_alone_frac": None, "k2_alone_GBps": None,
                 "algorithmic_bytes_per_launch": round(evals_per_launch * bpe, 1),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches, "bytes_per_distance_eval": bpe,
