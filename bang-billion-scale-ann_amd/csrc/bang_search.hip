@@ -750,7 +750,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip.
       // A word the summary knows to be untouched is zero: no request (FilterSummary).
       bool la = v0, lb = v0;                                 // load word a / b?
-      if (SUMM) {
+      const bool summ_on = SUMM && (HOST || iter <= p.summ_iters);     // (uniform; one-way per query: once off, the registers go stale.  bang_k_search resolves 0 = auto)
+      if (SUMM && summ_on) {
         la = summ.test(h0a >> UB) && v0;
         lb = summ.test(h0b >> UB) && v0;
         probes_skipped += (uint32_t)__popcll(__ballot(v0 && !la)) + (uint32_t)__popcll(__ballot(v0 && !lb));
@@ -815,11 +816,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       uint32_t sv_a = 0, sv_b = 0;
       if (POOL && pooled) {         // (the first 128 words of the scratch are the job's ids and distances: claim table and transposition area behind them)
         filter_commit<128>(scratch + 128, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
-        if (SUMM) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        if (SUMM && summ_on) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
       } else {
         filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
         // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-        if (SUMM) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        if (SUMM && summ_on) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
       }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
@@ -1414,6 +1415,11 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (rc != BANG_OK) return rc;
   a.nctx = nctx;
   a.gs = gs;
+  // The filter summary trades LDS-crossbar work on the chain of every iteration (12 ds_bpermute + two transposition passes) for
+  // memory requests.  A full chip is short of requests-in-flight: with it the 10 K SIFT1B-shape batch takes 8.36 instead of 9.09 ms, 5 000 /
+  // 2 500 queries 4.68 / 2.37 instead of 4.99 / 2.71.  A lightly loaded one is short of nothing but the chain: 1 250 queries (5 waves per CU)
+  // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto: off up to 5 waves per CU.
+  if (a.p.summ_iters == 0u) a.p.summ_iters = ((p->Q + grid_n - 1) / grid_n <= 5u) ? 1u : 0xFFFFFFFFu;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   // K2 pool: every wave slot of a CU is launched whatever the batch size -- the waves beyond the batch are the helpers

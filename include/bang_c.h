@@ -362,6 +362,9 @@ typedef struct {
   uint32_t* d_pool_jobs;               /* [Q] out, or NULL: iterations of the query whose distance stage went to the pool */
   uint32_t n_nodes;                    /* nodes of the index, or 0: an adjacency id >= n_nodes (and not the pad value) is never expanded nor evaluated -- the row
                                           counts as empty and *d_abort is set to 2 (a corrupt row must not become a wild read of the code table) */
+  uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
+                                          (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 5 queries per CU, where its
+                                          LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
   uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);

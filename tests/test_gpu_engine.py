@@ -846,3 +846,18 @@ def test_candidate_log_hook(libbang, small_u8):
     for i in range(q.shape[0]):
         log = set(cand[i, :cnt[i]].tolist())
         assert len(log) == cnt[i] and all(int(x) in log for x in ids[i])
+
+
+@pytest.mark.parametrize("summ_iters", ["-1", "1", "7"])
+@pytest.mark.parametrize("graph", [0, 1])
+def test_filter_summary_policy_does_not_change_results(libbang, small_u8, monkeypatch, summ_iters, graph):
+    """The on-chip filter summary may serve all of a query's iterations (-1: what a full chip gets), none but the first (1: what
+    bang_k_search picks for launches of at most 5 queries per CU) or any prefix: a probe it does not answer is simply loaded."""
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 64, with_stats=True)
+    ids, dists, st = _run_engine(ix, q, 10, 64, graph=graph, search=1)
+    assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    assert st["dist_evals"] == int(st_o[:, 2].sum()) and st["fetched"] == int(st_o[:, 3].sum())
+    assert (st["filter_loads_skipped"] > 0) == (summ_iters != "1") or summ_iters == "1"
