@@ -24,6 +24,12 @@
 //    sort/merge.  In host-graph mode the parents of a workgroup's waves go to the host walker in one coalesced store per round,
 //    and the sort/merge overlaps the walker's round trip.
 //
+//  * Round 4: a launch of at most 5 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of
+//    every iteration and a lightly loaded chip is not short of requests); an adjacency id >= N is never followed (n_nodes: the batch
+//    ends with an error instead of a wild read); and two experiments that measured no faster stay in the source behind build flags,
+//    bit-identical and tested: the K2 POOL (-DBANG_SEARCH_POOL=1: waves without a query serve the distance stage of their workgroup's
+//    queries, four lanes per code row -- pq_row_reduce_team) and the summary per half-word (-DBANG_SUMMARY_HALFWORDS=1).
+//
 // Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
 // canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
 //
