@@ -2,7 +2,7 @@
 """What one rank's shard of the 10 K-query batch costs on a GPU of its own -- ONE load of the workload, then every batch size and
 engine-option variant measured on the same engine (bench.py's own measure()).
 
-    python tools/shard_sweep.py [--workload sift1b_shape] [--queries 10000,5000,2500,1250] [--variants pool=1,pool=0] [--steps 6]
+    python tools/shard_sweep.py [--workload sift1b_shape] [--queries 10000,5000,2500,1250] [--variants pool=0 | BANG_SUMM_ITERS=0,BANG_SUMM_ITERS=1 | ...] [--steps 6]
                                 [--shape-n N] [--out gpurun_out/shard_sweep.md] [--check]
 
 --check: the ids of every variant must equal those of the first variant at the same batch size (results do not depend on the pool).
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="sift1b_shape")
     ap.add_argument("--queries", default="10000,5000,2500,1250")
-    ap.add_argument("--variants", default="pool=1,pool=0", help="comma list of option settings; '+' joins several options of one variant (pool=1+rows_hbm=0)")
+    ap.add_argument("--variants", default="pool=0", help="comma list of option settings; '+' joins several options of one variant (pool=1+rows_hbm=0)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape-n", type=int, default=0)
