@@ -53,7 +53,6 @@ struct SearchArgs {
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
-  uint32_t coop;             // self-paced form, long code rows: 1 = cooperative row fetch, 0 = one row per lane (light launches)
   uint32_t pool;             // self-paced form: waves without a query of their own serve the distance stage of their workgroup's queries (K2 pool)
 };
 
@@ -575,9 +574,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 #endif
   constexpr bool EARLY_ROWS = !HOST || BANG_HOST_EARLY_ROWS;   // code rows requested before the filter update (else: behind it)
   constexpr bool COOP = search_coop(NDW, HOST);                // ... by P adjacent lanes per row, one 16-byte piece each
-  // (experiment switch coop_rows = 2: every lane loads its own row -- the cooperative fetch saves look-ups and pays with six ds_bpermute and six
-  // piece-exchange rounds on the chain of every iteration; measured a wash for light launches and a 20 % loss for full ones)
-  const bool coop_on = COOP && (HOST || a.coop != 0u);
   const uint32_t code_stride = p.code_stride ? p.code_stride : p.m;
 
   // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
@@ -816,8 +812,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         }
       }
       if (POOL && pooled) {}
-      else if (COOP && coop_on && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-      else if ((!COOP || !coop_on) && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
+      else if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
@@ -874,19 +870,19 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         if ((uint32_t)lane < n && !me) d0 = ((const float*)(scratch + 64))[src];
         wave_sync();
       } else {
-        if (COOP && coop_on && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-        if (COOP && coop_on) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
+        if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+        if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if (BANG_FILTER_STORES_LATE && EARLY_ROWS) {
           // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
           // for them): now the filter stores -- their acknowledgements are not waited for until the next row is needed
-          if (!COOP || !coop_on) {
+          if (!COOP) {
 #pragma unroll
             for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4 * 4; ++i) asm volatile("" : "+v"(row.w[i]));
           }
           filter_stores();
         }
         if ((uint32_t)lane < n) {
-          if ((!COOP || !coop_on) && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
+          if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
           d0 = (BANG_REDUCE_PIPE && !HOST) ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
                                            : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
@@ -1431,9 +1427,6 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto: off up to 5 waves per CU.
   const bool light = (p->Q + grid_n - 1) / grid_n <= 5u;
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
-  // (one row per lane instead of the cooperative fetch for light launches: 1 250 queries 1.798 -> 1.787 ms, 625: launch 1.455 -> 1.412 ms,
-  // DEEP100M-shape 1 250: 1.710 -> 1.635 ms; 2 500: 2.46 -> 2.93, 10 000: 8.62 -> 10.55 ms -- within noise where it helps: auto = cooperative)
-  a.coop = p->coop_rows == 2u ? 0u : 1u;                                                  // 0 = auto = 1 = on, 2 = off
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   // K2 pool: every wave slot of a CU is launched whatever the batch size -- the waves beyond the batch are the helpers

@@ -365,8 +365,6 @@ typedef struct {
   uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
                                           (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 5 queries per CU, where its
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
-  uint32_t coop_rows;                  /* self-paced form, code rows of >= 3 pieces: 0 / 1 = fetched cooperatively (one request per line), 2 = one row per lane
-                                          (experiment: a wash for light launches, 20 % slower for full ones) */
   uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
