@@ -199,6 +199,11 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 #ifndef BANG_SUMMARY_HALFWORDS
 #define BANG_SUMMARY_HALFWORDS 0
 #endif
+// the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting for the next
+// adjacency row, instead of inside the filter update in front of the distance stage (self-paced form; nothing reads the summary in between)
+#ifndef BANG_SUMM_SET_LATE
+#define BANG_SUMM_SET_LATE 1
+#endif
 // the row reduce as a software pipeline over groups of 8 chunks (pq_row_reduce_pipe): search kernel / K2 streaming kernel
 // the filter's stores issued behind the arrival of the code rows instead of in front of the wait for them
 #ifndef BANG_FILTER_STORES_LATE
@@ -710,6 +715,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
+    constexpr bool SET_LATE = (BANG_SUMM_SET_LATE != 0) && !HOST;
+    bool sl_a = false, sl_b = false;                  // summary marks of this iteration's survivors, applied behind the merge
+    uint32_t sl_ua = 0, sl_ub = 0;
     float d0 = BIG_DIST, d1 = BIG_DIST;
     bool found = false;
     const bool first = (iter == 1);
@@ -822,11 +830,17 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       uint32_t sv_a = 0, sv_b = 0;
       if (POOL && pooled) {         // (the first 128 words of the scratch are the job's ids and distances: claim table and transposition area behind them)
         filter_commit<128>(scratch + 128, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
-        if (SUMM && summ_on) summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        if (SUMM && summ_on) {
+          if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> UB; sl_ub = h0b >> UB; }
+          else summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        }
       } else {
         filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
         // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-        if (SUMM && summ_on) summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        if (SUMM && summ_on) {
+          if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> UB; sl_ub = h0b >> UB; }
+          else summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
+        }
       }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
@@ -1015,6 +1029,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         have_row = found;
         cnt_in = n_cnt; x0 = n_x0;
         head = worklist_head(s, w_n, lane);
+        // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
+        if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
       }
     }
     if (HOST && nctx == 2) {                                             // park context c
