@@ -56,7 +56,7 @@ class SearchParams(C.Structure):
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
         ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
-        ("pool", C.c_uint32), ("d_pool_jobs", C.c_void_p), ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("pool_helpers", C.c_uint32),
+        ("pool", C.c_uint32), ("d_pool_jobs", C.c_void_p), ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32), ("pool_helpers", C.c_uint32),
     ]
 
 

@@ -156,6 +156,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_pool_jobs = e->d_pool_jobs + ln.q0;
     sp.pool = e->pool_opt > 0 ? 1u : 0u;                 // (auto = off: measured no faster)
     sp.pool_helpers = (uint32_t)std::max(0L, env_long("BANG_POOL_HELPERS", 0));
+    sp.merge_late = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_MERGE_LATE", 0)));
     { const long si = env_long("BANG_SUMM_ITERS", 0); sp.summ_iters = si < 0 ? 0xFFFFFFFFu : (uint32_t)si; }     // 0 = auto, -1 = always
     sp.d_ktime = ktime_slot(e, ln);
     sp.max_wgs = (uint32_t)std::max(0L, env_long("BANG_SEARCH_MAX_WGS", 0));          // experiment / test knobs

@@ -53,6 +53,7 @@ struct SearchArgs {
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
+  uint32_t merge_late;       // self-paced form: 1 = K3 of iteration i runs behind the probe issue of iteration i + 1 (full launches)
   uint32_t pool;             // self-paced form: waves without a query of their own serve the distance stage of their workgroup's queries (K2 pool)
 };
 
@@ -203,6 +204,11 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 // adjacency row, instead of inside the filter update in front of the distance stage (self-paced form; nothing reads the summary in between)
 #ifndef BANG_SUMM_SET_LATE
 #define BANG_SUMM_SET_LATE 1
+#endif
+// K3a + K3b of iteration i run in iteration i + 1, behind the issue of its filter probes -- the one wait of an iteration that had nothing
+// to cover it -- instead of behind the request for the next adjacency row, whose latency (0.8 us from HBM) is shorter than the merge (self-paced form)
+#ifndef BANG_MERGE_LATE
+#define BANG_MERGE_LATE 1
 #endif
 // the row reduce as a software pipeline over groups of 8 chunks (pq_row_reduce_pipe): search kernel / K2 streaming kernel
 // the filter's stores issued behind the arrival of the code rows instead of in front of the wait for them
@@ -586,6 +592,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   uint32_t q = 0, iter = 0, w_n = 0, cc = 0, mark = 0, evals = 0, fetched = 0;
   uint32_t cnt_in = 0, x0 = 0, x1 = 0;
   bool have_row = false;
+  bool mg_pending = false;                         // MERGE_LATE: the survivors of the previous iteration still wait for their merge
+  uint32_t mg_n = 0, mg_iter = 0, mg_sid0 = 0;
+  float mg_d0 = BIG_DIST;
   WlHead head;                                     // first unvisited worklist entry + last distance, as of the last merge (uniform)
   head.found = false; head.idx = 0; head.id = 0; head.d = 0.0f; head.tail = 0.0f;
   // the centred query of the current context, in registers (lane l of qc.v[r] = element 64 r + l; read with v_readlane): loaded
@@ -700,6 +709,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         active = true;
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
+        mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
         pool_jobs = 0;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
@@ -716,6 +726,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
     constexpr bool SET_LATE = (BANG_SUMM_SET_LATE != 0) && !HOST;
+    constexpr bool MERGE_LATE_C = (BANG_MERGE_LATE != 0) && !HOST && !POOL;   // (the pool's job area and the sort's scratch are the same words)
+    const bool MERGE_LATE = MERGE_LATE_C && a.merge_late != 0u;               // (uniform: full launches only, bang_k_search)
     bool sl_a = false, sl_b = false;                  // summary marks of this iteration's survivors, applied behind the merge
     uint32_t sl_ua = 0, sl_ub = 0;
     float d0 = BIG_DIST, d1 = BIG_DIST;
@@ -780,6 +792,13 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       if (v1) {
         h1a = hash1(x1); h1b = hash2(x1);
         if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
+      }
+      if (MERGE_LATE && !first) {
+        // ---------------- K3a + K3b of the PREVIOUS iteration, while this one's filter words travel (nothing below needs the worklist
+        // before the parent decision; the scratch is free until the compaction)
+        if (mg_pending) w_n = sort_and_merge(s, mg_n, mg_d0, mg_sid0, BIG_DIST, 0u, mg_iter, w_n, L, medoid, mark, head.tail, lane);
+        mg_pending = false;
+        head = worklist_head(s, w_n, lane);
       }
       const bool pass0 = v0 && !(((w0a >> (h0a & UM)) & 1u) && ((w0b >> (h0b & UM)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
@@ -1007,7 +1026,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
-      if (n > 0 && iter < cap_iter) w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
+      if (n > 0 && iter < cap_iter) {
+        if (MERGE_LATE && !first) { mg_pending = true; mg_n = n; mg_iter = iter; mg_d0 = d0; mg_sid0 = sid0; }      // (n <= 64 behind the seed list)
+        else w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
+      }
       PH(6);   // (publish +) sort/merge
 #ifdef BANG_SEARCH_PHASE_PROF
       if (wave == 0) ++ph_n;
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         ++iter;
         have_row = found;
         cnt_in = n_cnt; x0 = n_x0;
-        head = worklist_head(s, w_n, lane);
+        if (!MERGE_LATE || first) head = worklist_head(s, w_n, lane);
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
         if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
       }
@@ -1442,6 +1464,13 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // 2 500 queries 4.68 / 2.37 instead of 4.99 / 2.71.  A lightly loaded one is short of nothing but the chain: 1 250 queries (5 waves per CU)
   // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto: off up to 5 waves per CU.
   const bool light = (p->Q + grid_n - 1) / grid_n <= 5u;
+  // the merge behind the NEXT iteration's probe issue instead of behind the row request: a full chip (every wave slot taken) has its longest
+  // uncovered wait there (10 000 queries 8.52 -> 8.26 ms, DEEP100M-shape 7.54 -> 7.26); a partly filled one gets its rows and filter words
+  // back sooner than a merge takes and loses 1-4 % (2 500 queries 2.38 -> 2.42 ms, 1 250: 1.71 -> 1.77)
+  {
+    const uint32_t fit = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L, 1, false);
+    a.merge_late = (p->merge_late == 1u || (p->merge_late == 0u && (uint64_t)p->Q >= (uint64_t)grid_n * fit)) ? 1u : 0u;     // 0 = auto, 1 = on, 2 = off
+  }
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);

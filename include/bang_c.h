@@ -365,6 +365,8 @@ typedef struct {
   uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
                                           (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 5 queries per CU, where its
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
+  uint32_t merge_late;                 /* self-paced form: K3a + K3b of iteration i run behind the issue of iteration i + 1's filter probes (1) instead of behind
+                                          the request for the next adjacency row (2); 0 = auto: 1 for launches that fill every wave slot of the chip */
   uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
