@@ -1,5 +1,7 @@
-"""bench.py's own measurement of roofline.traffic: two child runs of the primary configuration under rocprofv3 --pmc (FETCH_SIZE,
-WRITE_SIZE), before the parent touches the GPU (MI355X_MICROARCH.md: HBM bytes, one counter per pass)."""
+"""bench.py's own measurement of roofline.traffic: two child runs of the primary configuration under rocprofv3 --pmc (pass A: FETCH_SIZE +
+TCC_EA0_RDREQ_DRAM_32B, pass B: WRITE_SIZE + TCC_EA0_RDREQ_IO_32B + TCC_EA0_WRREQ), before the parent touches the GPU
+(MI355X_MICROARCH.md: HBM bytes, separate passes; the byte-exact counters are calibrated in profiles/r04_traffic_calibration.md), and the
+order of the line's keys (the driver's record keeps the leading scalars)."""
 import json
 import os
 import shutil
@@ -26,6 +28,15 @@ def test_bench_measures_hbm_traffic_in_the_same_run(libbang):
     # L2 on a 100 K-point index; what must hold is that the counters saw the launches (> 0) and stay within a sane multiple
     assert 0 < rf["traffic"] < 200 * rf["algorithmic_bytes_per_launch"]
     assert d["config"]["parity_vs_oracle_first_64"] is True
+    by = rf["traffic_by_stream"]
+    assert set(by) >= {"code_rows", "filter_reads", "filter_writes"} and by["code_rows"] > 0 and by["filter_writes"] > 0
+    assert rf["traffic_over_algorithmic"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"], rel=1e-3) and rf["hbm_traffic_GBps"] > 0
+    # scalars first: the keys the record must keep sit in front of the prose and the nested objects
+    first = list(d["config"])[:24]
+    for key in ("workload", "L", "recall_at_10", "k2_alone_frac", "traffic_over_algorithmic", "qps_incl_init", "sift200m_qps", "sift1m_qps", "walker_qps"):
+        assert key in first, key
+    rkeys = list(rf)
+    assert rkeys.index("traffic") < rkeys.index("kernel") and rkeys.index("k2_alone_frac") < rkeys.index("kernel")
 
 
 def test_bench_without_live_traffic_quotes_the_committed_passes(libbang):
