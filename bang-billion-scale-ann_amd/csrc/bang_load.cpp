@@ -274,7 +274,8 @@ static int cache_rows_in_hbm(bang_engine* e) {
   if (!e->pull || !e->h_adj || e->rows_hbm_opt == 0) return BANG_OK;
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  const size_t keep = (size_t)12 << 30;                                   // per-batch state (filters: 50 KB per query; 0.6 GB at 10 K queries) + slack
+  const size_t keep = (size_t)6 << 30;                                    // per-batch state (filters: 50 KB per query; 0.6 GB at 10 K queries) + slack; a batch
+                                                                          // that needs more gets it: bang_alloc drops this copy and retries (bang_cabi.cpp)
   size_t budget = free_b > keep ? free_b - keep : 0;
   if (e->rows_hbm_opt > 0) budget = std::min(budget, (size_t)e->rows_hbm_opt << 20);
   size_t n = std::min<size_t>(e->N, budget / 256);

@@ -41,7 +41,7 @@ static const OptionDef kOptions[] = {
     {"pull", "BANG_PULL", &bang_engine::pull_opt, -1, 1, INT, BEFORE_LOAD,
      "host graph: 1 = the search kernel pulls 256-byte adjacency rows from pinned host memory over PCIe, 0 = C++ walker threads serve them, -1 = auto"},
     {"rows_hbm", "BANG_ROWS_HBM", &bang_engine::rows_hbm_opt, -1, 1 << 22, INT, BEFORE_LOAD,
-     "pull mode: MB of HBM for a copy of the first adjacency rows, read from there instead of over PCIe (-1 = auto: what the index leaves beyond 12 GB, "
+     "pull mode: MB of HBM for a copy of the first adjacency rows, read from there instead of over PCIe (-1 = auto: what the index leaves beyond 6 GB, "
      "where the rows do not all fit; 0 = none)"},
     // ---- loop shape: consumed by bang_alloc
     {"lanes", "BANG_LANES", &bang_engine::lanes_opt, 0, BANG_MAX_LANES, INT, BEFORE_ALLOC, "launch-per-iteration loop: independent query groups pipelined against each other (0 = auto)"},
