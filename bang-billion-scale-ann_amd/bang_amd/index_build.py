@@ -142,26 +142,37 @@ def smallworld_links(P: Partition, first: int, count: int, n_links: int, N: int,
 
 
 def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = synth.SEED, cells: int = 0, log=None, cell: int = 2048,
-                         idx_dtype=torch.int64, want_partition: bool = False, select: str = "topk"):
+                         idx_dtype=torch.int64, want_partition: bool = False, select: str = "topk", state=None, cell_range=None):
     """Approximate K nearest neighbours of every point (excluding itself) through a coarse partition.
     Returns (ids [N, K] of idx_dtype, squared distances f32 [N, K]) sorted ascending (+ the Partition if asked for).
-    x may be f32 or (exact for 8-bit data) bf16."""
+    x may be f32 or (exact for 8-bit data) bf16.
+    SLICED use (an index whose [N, K] tables do not fit HBM beside the vectors): `state` = a dict that carries the partition, the
+    norms and the random stream from slice to slice, `cell_range` = (c0, c1) -- the tables then hold the points of those cells only, in
+    the partition's order: row j belongs to point P.order[P.starts[c0] + j].  Slice by slice the results equal the one-shot call's."""
     N, D = x.shape
     dev = x.device
-    g = synth._gen(seed + 11, dev)
-    t0 = time.time()
-    P = partition(x, cell, g, cells=cells)
+    if state is not None and "P" in state:
+        P, g, xn = state["P"], state["g"], state["xn"]
+    else:
+        g = synth._gen(seed + 11, dev)
+        t0 = time.time()
+        P = partition(x, cell, g, cells=cells)
+        if log:
+            log(f"[build] partition: {P.C} cells of ~{N // max(1, P.C)} points in {time.time() - t0:.1f}s")
+        xn = (x.float() * x.float()).sum(1) if x.dtype == torch.float32 else torch.cat([(x[a:a + (1 << 22)].float() ** 2).sum(1) for a in range(0, N, 1 << 22)])
+        if state is not None:
+            state.update(P=P, g=g, xn=xn)
     C = P.C
     order = P.order
-    if log:
-        log(f"[build] partition: {C} cells of ~{N // max(1, C)} points in {time.time() - t0:.1f}s")
-    xn = (x.float() * x.float()).sum(1) if x.dtype == torch.float32 else torch.cat([(x[a:a + (1 << 22)].float() ** 2).sum(1) for a in range(0, N, 1 << 22)])
-    out_i = torch.empty((N, K), dtype=idx_dtype, device=dev)
-    out_d = torch.empty((N, K), dtype=torch.float32, device=dev)
     starts_h, counts_h, near_h = P.starts.tolist(), P.counts.tolist(), P.near[:, :probes].tolist()
+    c0, c1 = cell_range if cell_range is not None else (0, C)
+    base = starts_h[c0] if c0 < C else N
+    n_out = N if cell_range is None else (starts_h[c1 - 1] + counts_h[c1 - 1] - base if c1 > c0 else 0)
+    out_i = torch.empty((n_out, K), dtype=idx_dtype, device=dev)
+    out_d = torch.empty((n_out, K), dtype=torch.float32, device=dev)
     t0 = time.time()
     step = max(512, C // 8)
-    for c in range(C):
+    for c in range(c0, c1):
         if counts_h[c] == 0:
             continue
         rows = order[starts_h[c]: starts_h[c] + counts_h[c]]
@@ -193,8 +204,13 @@ def candidate_neighbours(x: torch.Tensor, K: int, probes: int = 6, seed: int = s
                 gv = torch.where(cand[gi] == r[:, None], torch.full_like(gv, float("inf")), gv)   # (the point itself won its group)
                 dd, o = torch.sort(gv, dim=1)
                 dd, ii = dd[:, :K], torch.gather(gi, 1, o[:, :K])
-            out_i[r] = cand[ii].to(idx_dtype)
-            out_d[r] = (dd + xn[r][:, None]).clamp_min_(0.0)
+            if cell_range is not None:                               # (the points of a cell are consecutive in the partition's order)
+                j0 = starts_h[c] - base + a
+                out_i[j0:j0 + r.shape[0]] = cand[ii].to(idx_dtype)
+                out_d[j0:j0 + r.shape[0]] = (dd + xn[r][:, None]).clamp_min_(0.0)
+            else:
+                out_i[r] = cand[ii].to(idx_dtype)
+                out_d[r] = (dd + xn[r][:, None]).clamp_min_(0.0)
         if log and (c + 1) % step == 0:
             log(f"[build] candidate search: cell {c + 1}/{C} ({time.time() - t0:.1f}s)")
     return (out_i, out_d, P) if want_partition else (out_i, out_d)
@@ -230,13 +246,10 @@ def robust_prune(x: torch.Tensor, cand_i: torch.Tensor, cand_d: torch.Tensor, ke
     return out
 
 
-def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tensor, slots: int = 24, block: int = 1 << 20):
-    """Every kept edge p -> c offers p to c (Vamana's reverse insertion).  near_i [N, K1] (-1 = empty), near_d [N, K1].
-    A point keeps at most `slots` offers: an offer lands in slot hash(p, c) % slots and the largest p wins a contested slot
-    (scatter-max: deterministic, no global sort of the ~N x 30 edges).  Returns the merged candidate lists -- own kept + offered,
-    distinct, sorted ascending by distance, padding id -1 / distance +inf: (ids [N, K1 + slots] of near_i.dtype, d2 f32)."""
-    N, K1 = near_i.shape
-    dev = x.device
+def reverse_slots(near_i: torch.Tensor, slots: int = 24, block: int = 1 << 20) -> torch.Tensor:
+    """rev [N, slots]: the offers every point received (see reverse_candidates), -1 = empty"""
+    N = near_i.shape[0]
+    dev = near_i.device
     rev = torch.full((N * slots,), -1, dtype=(torch.int32 if N < (1 << 31) else torch.int64), device=dev)   # (2e8 points x 24 slots: 19 GB instead of 38)
     for s in range(0, N, block):
         c = near_i[s:s + block].long()
@@ -245,11 +258,23 @@ def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tens
         cc, pp = c[ok], p[ok]
         slot = ((pp * 0x9E3779B1 + cc * 0x85EBCA77) >> 7) % slots
         rev.scatter_reduce_(0, cc * slots + slot, pp.to(rev.dtype), reduce="amax", include_self=True)
-    rev = rev.view(N, slots)
-    out_i = torch.empty((N, K1 + slots), dtype=near_i.dtype, device=dev)
-    out_d = torch.empty((N, K1 + slots), dtype=torch.float32, device=dev)
-    for s in range(0, N, 1 << 18):
-        r = rev[s:s + (1 << 18)].long()
+    return rev.view(N, slots)
+
+
+def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tensor, slots: int = 24, block: int = 1 << 20, rev=None, row_range=None):
+    """Every kept edge p -> c offers p to c (Vamana's reverse insertion).  near_i [N, K1] (-1 = empty), near_d [N, K1].
+    A point keeps at most `slots` offers: an offer lands in slot hash(p, c) % slots and the largest p wins a contested slot
+    (scatter-max: deterministic, no global sort of the ~N x 30 edges).  Returns the merged candidate lists -- own kept + offered,
+    distinct, sorted ascending by distance, padding id -1 / distance +inf: (ids [N, K1 + slots] of near_i.dtype, d2 f32)."""
+    N, K1 = near_i.shape
+    dev = x.device
+    if rev is None:
+        rev = reverse_slots(near_i, slots, block)
+    r0, r1 = row_range if row_range is not None else (0, N)          # (sliced use: the merged lists of the points [r0, r1) only)
+    out_i = torch.empty((r1 - r0, K1 + slots), dtype=near_i.dtype, device=dev)
+    out_d = torch.empty((r1 - r0, K1 + slots), dtype=torch.float32, device=dev)
+    for s in range(r0, r1, 1 << 18):
+        r = rev[s:min(s + (1 << 18), r1)].long()
         B = r.shape[0]
         xr = x[r.clamp_min(0)].float()                            # [B, slots, D]
         xp = x[s:s + B].float()
@@ -266,8 +291,8 @@ def reverse_candidates(x: torch.Tensor, near_i: torch.Tensor, near_d: torch.Tens
         dd_o, o2 = torch.sort(dd_s, dim=1, stable=True)
         ids_o = torch.gather(ids_s, 1, o2)
         ids_o = torch.where(torch.isfinite(dd_o), ids_o, torch.full_like(ids_o, -1))
-        out_i[s:s + B] = ids_o.to(near_i.dtype)
-        out_d[s:s + B] = dd_o
+        out_i[s - r0:s - r0 + B] = ids_o.to(near_i.dtype)
+        out_d[s - r0:s - r0 + B] = dd_o
     return out_i, out_d
 
 
@@ -292,14 +317,136 @@ def _count_true(mask: torch.Tensor, block: int = 1 << 22) -> int:
     return sum(int(torch.count_nonzero(mask[a:a + block])) for a in range(0, mask.shape[0], block))
 
 
-def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None,
-                      reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64,
-                      links: str = "smallworld", select: str = "topk"):
-    """(degrees int64 [N], adjacency [N, R] of idx_dtype): robust-pruned near neighbours (two passes with reverse edges in
-    between; at most R - n_random of them) + random long-range links up to R, distinct, != self, sorted ascending; the tail of a
-    short row is 0.  reverse=False, n_random=R//2: the one-pass builder of round 2."""
+def _finish_rows(near_i: torch.Tensor, P: Partition, R: int, N: int, seed: int, links: str, idx_dtype):
+    """the near neighbours of every point, then random long-range links up to R entries; distinct, != self, sorted ascending"""
+    dev = near_i.device
+    g = synth._gen(seed + 1, dev)
+    adj_out = torch.zeros((N, R), dtype=idx_dtype, device=dev)
+    deg_out = torch.empty(N, dtype=torch.int64, device=dev)
+    W = near_i.shape[1]
+    for s in range(0, N, 1 << 20):                               # per row: the near neighbours, then random links; R entries in all
+        near = near_i[s:s + (1 << 20)].long()
+        B = near.shape[0]
+        rnd = smallworld_links(P, s, B, R, N, g) if links == "smallworld" else torch.randint(0, N, (B, R), generator=g, device=dev)
+        n_n = (near >= 0).sum(1, keepdim=True)
+        col = torch.arange(R, device=dev)[None, :]
+        pad = torch.full((B, R - W), -1, dtype=torch.int64, device=dev)
+        adj = torch.where(col < n_n, torch.cat([near, pad], 1), rnd)
+        adj, _ = torch.sort(adj, dim=1)
+        self_id = torch.arange(s, s + B, device=dev)[:, None]
+        ok = torch.ones_like(adj, dtype=torch.bool)
+        ok[:, 1:] = adj[:, 1:] != adj[:, :-1]
+        ok &= adj != self_id
+        deg_out[s:s + B] = ok.sum(dim=1)
+        pos = torch.cumsum(ok.to(torch.int64), dim=1) - 1
+        out = torch.zeros_like(adj)
+        rows = torch.arange(B, device=dev)[:, None].expand_as(adj)
+        out[rows[ok], pos[ok]] = adj[ok]
+        adj_out[s:s + B] = out.to(idx_dtype)
+    return deg_out, adj_out
+
+
+def _build_graph_sliced(holder: list, R, seed, K, probes, alpha, log, reverse, n_random, cell, cells, idx_dtype, links, select, slices, narrow):
+    """build_graph_large with the big per-point tables held for one slice of the points at a time (see there)."""
+    x = holder[0]
     N = x.shape[0]
     dev = x.device
+    n_near = R - n_random
+    keep1 = min(n_near, R // 2)
+    st = {}
+    t0 = time.time()
+    near_i = near_d = None
+    kept_total = 0
+    for sl in range(slices):
+        if sl == 0:                                              # (the partition is made by the first call)
+            ci, cd, P = candidate_neighbours(x, K, probes=probes, seed=seed, log=log, cell=cell, cells=cells, idx_dtype=idx_dtype, want_partition=True,
+                                             select=select, state=st, cell_range=(0, 0))
+            del ci, cd
+            C = P.C
+            near_i = torch.full((N, keep1), -1, dtype=idx_dtype, device=dev)
+            near_d = torch.full((N, keep1), float("inf"), dtype=torch.float32, device=dev)
+        c0, c1 = C * sl // slices, C * (sl + 1) // slices
+        if c1 <= c0:
+            continue
+        ci, cd = candidate_neighbours(x, K, probes=probes, seed=seed, log=None, cell=cell, cells=cells, idx_dtype=idx_dtype, select=select, state=st,
+                                      cell_range=(c0, c1))
+        kept = robust_prune(x, ci, cd, keep=keep1, alpha=alpha)
+        kept_total += _count_true(kept)
+        ni, nd = _compact_kept(ci, cd, kept, keep1)
+        del ci, cd, kept
+        base = int(P.starts[c0])
+        rows = P.order[base:base + ni.shape[0]]
+        near_i[rows] = ni
+        near_d[rows] = nd
+        del ni, nd, rows
+        if x.is_cuda:
+            torch.cuda.empty_cache()
+        if log:
+            log(f"[build] slice {sl + 1}/{slices}: candidates + robust prune of cells [{c0}, {c1}) ({time.time() - t0:.1f}s)")
+    if log:
+        log(f"[build] {K} candidate neighbours per point, robust prune (alpha {alpha}): {kept_total / N:.1f} kept on average, {time.time() - t0:.1f}s")
+    st.pop("xn", None)
+    if narrow in ("uint8", "int8") and x.dtype != torch.float32:
+        # the matmuls are done: from here on only `x[...].float()` gathers follow -- the bf16 copy (2 bytes per value) makes room
+        x8 = torch.empty(x.shape, dtype=(torch.uint8 if narrow == "uint8" else torch.int8), device=dev)
+        for a in range(0, N, 1 << 24):
+            x8[a:a + (1 << 24)] = x[a:a + (1 << 24)].to(x8.dtype)
+        holder[0] = x8
+        del x
+        x = x8
+        if x.is_cuda:
+            torch.cuda.empty_cache()
+    if reverse:
+        t0 = time.time()
+        slots = max(8, R // 2 - 8)
+        rev = reverse_slots(near_i, slots)
+        near2 = torch.full((N, n_near), -1, dtype=idx_dtype, device=dev)
+        kept2_total = 0
+        for sl in range(slices * 3):                             # (the merged lists are wider than the candidate tables, and the final lists are alive beside them)
+            r0, r1 = N * sl // (slices * 3), N * (sl + 1) // (slices * 3)
+            mi, md = reverse_candidates(x, near_i, near_d, slots=slots, rev=rev, row_range=(r0, r1))
+            kept2 = robust_prune(x, mi, md, keep=n_near, alpha=alpha)
+            kept2_total += _count_true(kept2)
+            n2, _ = _compact_kept(mi, md, kept2, n_near)
+            near2[r0:r1] = n2
+            del mi, md, kept2, n2
+            if x.is_cuda:
+                torch.cuda.empty_cache()
+        del rev, near_i, near_d
+        near_i = near2
+        if x.is_cuda:
+            torch.cuda.empty_cache()
+        if log:
+            log(f"[build] reverse edges + second prune: {kept2_total / N:.1f} near neighbours per point, {time.time() - t0:.1f}s")
+    else:
+        del near_d
+    return _finish_rows(near_i, P, R, N, seed, links, idx_dtype)
+
+
+def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 48, probes: int = 6, alpha: float = 1.2, log=None,
+                      reverse: bool = True, n_random: int = 12, cell: int = 2048, cells: int = 0, idx_dtype=torch.int64,
+                      links: str = "smallworld", select: str = "topk", slices: int = 0, narrow: str | None = None):
+    """(degrees int64 [N], adjacency [N, R] of idx_dtype): robust-pruned near neighbours (two passes with reverse edges in
+    between; at most R - n_random of them) + random long-range links up to R, distinct, != self, sorted ascending; the tail of a
+    short row is 0.  reverse=False, n_random=R//2: the one-pass builder of round 2.
+    x: the vectors, or a one-element LIST holding them (sliced build: the builder swaps the bf16 tensor for its 8-bit original once
+    the matmuls are done -- narrow = "uint8" / "int8" -- and the caller finds the swapped tensor in the list).
+    slices > 1 (0 = auto: 1 up to 2e8 points, else ceil(N / 1e8)): the [N, 48] candidate tables and the [N, 56] merged lists exist
+    for one slice of the points at a time (2e8 points peak at 224 GiB of HBM in one piece; 3e8 in slices at ~210).  Same graph as the
+    one-shot build (tests/test_build.py)."""
+    holder = x if isinstance(x, list) else None
+    if holder is not None:
+        x = holder[0]
+    N = x.shape[0]
+    dev = x.device
+    if slices <= 0:
+        slices = 1 if N <= 200_000_000 else -(-N // 100_000_000)
+    if slices > 1:
+        if holder is None:
+            holder = [x]
+        del x
+        return _build_graph_sliced(holder, R, seed, K, probes, alpha, log, reverse, n_random, cell, cells, idx_dtype, links, select,
+                                   slices, narrow)
     t0 = time.time()
     ci, cd, P = candidate_neighbours(x, K, probes=probes, seed=seed, log=log, cell=cell, cells=cells, idx_dtype=idx_dtype, want_partition=True,
                                      select=select)
@@ -328,30 +475,7 @@ def build_graph_large(x: torch.Tensor, R: int, seed: int = synth.SEED, K: int = 
         del mi, md, kept2, near_d
         if x.is_cuda:
             torch.cuda.empty_cache()
-    g = synth._gen(seed + 1, dev)
-    adj_out = torch.zeros((N, R), dtype=idx_dtype, device=dev)
-    deg_out = torch.empty(N, dtype=torch.int64, device=dev)
-    W = near_i.shape[1]
-    for s in range(0, N, 1 << 20):                               # per row: the near neighbours, then random links; R entries in all
-        near = near_i[s:s + (1 << 20)].long()
-        B = near.shape[0]
-        rnd = smallworld_links(P, s, B, R, N, g) if links == "smallworld" else torch.randint(0, N, (B, R), generator=g, device=dev)
-        n_n = (near >= 0).sum(1, keepdim=True)
-        col = torch.arange(R, device=dev)[None, :]
-        pad = torch.full((B, R - W), -1, dtype=torch.int64, device=dev)
-        adj = torch.where(col < n_n, torch.cat([near, pad], 1), rnd)
-        adj, _ = torch.sort(adj, dim=1)
-        self_id = torch.arange(s, s + B, device=dev)[:, None]
-        ok = torch.ones_like(adj, dtype=torch.bool)
-        ok[:, 1:] = adj[:, 1:] != adj[:, :-1]
-        ok &= adj != self_id
-        deg_out[s:s + B] = ok.sum(dim=1)
-        pos = torch.cumsum(ok.to(torch.int64), dim=1) - 1
-        out = torch.zeros_like(adj)
-        rows = torch.arange(B, device=dev)[:, None].expand_as(adj)
-        out[rows[ok], pos[ok]] = adj[ok]
-        adj_out[s:s + B] = out.to(idx_dtype)
-    return deg_out, adj_out
+    return _finish_rows(near_i, P, R, N, seed, links, idx_dtype)
 
 
 def pack_graph_device(x: torch.Tensor, dtype: str, deg: torch.Tensor, adj: torch.Tensor, block: int = 1 << 20) -> np.ndarray:
@@ -430,7 +554,12 @@ def make_index_large(N: int, D: int, dtype: str, R: int, m: int, Q: int, K: int 
                            out_dtype=(torch.bfloat16 if dtype != "float" and str(device).startswith("cuda") else None))
     if log:
         log(f"[build] {N} vectors generated in {time.time() - t0:.1f}s")
-    deg, adj = build_graph_large(x, R, seed=seed, log=log, idx_dtype=(torch.int32 if big else torch.int64), **graph_kw)
+    xh = [x]                                                     # (a sliced build swaps the bf16 tensor for its 8-bit original half-way: see build_graph_large)
+    del x
+    deg, adj = build_graph_large(xh, R, seed=seed, log=log, idx_dtype=(torch.int32 if big else torch.int64),
+                                 narrow=(dtype if dtype in ("uint8", "int8") else None), **graph_kw)
+    x = xh[0]
+    del xh
     medoid = synth.medoid_of(x)
     if diag and log:
         t1 = time.time()

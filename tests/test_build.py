@@ -83,3 +83,17 @@ def test_knn_big_equals_exact_knn():
     i1, d1 = synth.knn(base, q, 10, row_block=40)
     i2, d2 = synth.knn_big(base, q, 10)
     assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+def test_sliced_build_equals_the_one_shot_build():
+    """build_graph_large with its per-point tables held for one slice of the points at a time (what lets a 3e8-point index fit HBM)
+    returns the graph of the one-shot build, with and without the swap of the bf16 vectors for their 8-bit original."""
+    x = synth.make_vectors(30_000, 32, "uint8", n_clusters=24, seed=5)
+    deg1, adj1 = build.build_graph_large(x, 32, seed=5, K=24, probes=4, n_random=8, cell=512)
+    deg3, adj3 = build.build_graph_large(x, 32, seed=5, K=24, probes=4, n_random=8, cell=512, slices=3)
+    assert torch.equal(deg1, deg3) and torch.equal(adj1, adj3)
+    xh = [x.to(torch.bfloat16)]
+    deg4, adj4 = build.build_graph_large(xh, 32, seed=5, K=24, probes=4, n_random=8, cell=512, slices=2, narrow="uint8")
+    assert xh[0].dtype == torch.uint8 and torch.equal(xh[0].float(), x)
+    deg5, adj5 = build.build_graph_large(x.to(torch.bfloat16), 32, seed=5, K=24, probes=4, n_random=8, cell=512)
+    assert torch.equal(deg4, deg5) and torch.equal(adj4, adj5)
