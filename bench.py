@@ -55,9 +55,9 @@ WORKLOADS = {
                                                                   # Vamana-style build on the GPU (bang_amd/index_build.py), SURVEY 8 f-3
     "sift100m": (100_000_000, 128, "uint8", 64, 70, 10_000, 10_000),  # SIFT1B's layout (m = 70) on a recall-verified 1e8-point index: 38.8 GB
                                                                       # of graph entries, built on the GPU in about a minute
-    "sift200m": (200_000_000, 128, "uint8", 64, 70, 10_000, 20_000),  # the same, a fifth of the headline's N: 78 GB of graph entries, 51 GB of pull rows;
-                                                                      # built on the GPU in ~2.5 min (peak ~240 GB of HBM: 2.5e8 ran out of HBM next to the
-                                                                      # candidate / reverse-edge tables of the builder)
+    "sift300m": (300_000_000, 128, "uint8", 64, 70, 10_000, 30_000),  # the same, three tenths of the headline's N: 116 GB of graph entries, 77 GB of pull rows;
+                                                                      # built on the GPU in ~4 min by the sliced builder (peak 236 GiB of HBM; 4e8 would not fit the host beside its
+                                                                      # 155 GB of graph entries and 102 GB of pull rows)
     "small": (100_000, 128, "uint8", 64, 32, 10_000, 64),       # quick functional run
     "tiny": (20_000, 128, "uint8", 64, 32, 1_000, 32),
 }
@@ -838,7 +838,7 @@ def main():
                          "oracle can check the results -- parity runs of the sharded job at reduced N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
-    ap.add_argument("--legs", default="", help="comma list of legs to run (default: k2,sift1m,deep100m,walker,sift200m,sift10m; on request: sift100m, sift1b)")
+    ap.add_argument("--legs", default="", help="comma list of legs to run (default: k2,sift1m,deep100m,walker,sift300m,sift10m; on request: sift100m, sift1b)")
     ap.add_argument("--leg-budget-s", type=float, default=600.0,
                     help="a leg is skipped (and listed in config.legs_skipped) once the run -- counted from the start of the process -- has "
                          "taken this long: the default run stays within minutes")
@@ -919,8 +919,8 @@ def main():
                "reduced_n_hip_ids_equal_oracle": None, "k2_alone_frac": None, "k2_alone_GBps": None,
                "traffic_over_algorithmic": (res["roofline"] or {}).get("traffic_over_algorithmic"),
                "qps_incl_init": res["qps_incl_init"],
-               "sift200m_qps": None, "sift200m_recall": None, "sift200m_L": None, "sift200m_parity_ok": None,
-               "sift200m_hops_p50": None, "sift1m_qps": None, "sift1m_recall": None, "sift1m_parity_ok": None,
+               "sift300m_qps": None, "sift300m_recall": None, "sift300m_L": None, "sift300m_parity_ok": None,
+               "sift300m_hops_p50": None, "sift1m_qps": None, "sift1m_recall": None, "sift1m_parity_ok": None,
                "deep100m_shape_qps": None, "deep100m_shape_frac": None, "walker_qps": None,
                "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "legs_skipped": None,
                "graph_placement": prim["placement_note"] or f"{graph} (requested)",
@@ -1079,16 +1079,16 @@ def main():
             release_config(r)
         guarded("at_sift1b_shape_walker", leg_walker)
 
-    if leg_on("sift200m"):
+    if leg_on("sift300m"):
         def leg_250m():
-            # SIFT1B's PQ layout and placement (graph in host RAM, rows pulled over PCIe) on a structured, recall-verified index a fifth of the
-            # headline's size: "QPS @ recall >= 0.9" at 2e8 points, the first 64 queries against the oracle
-            r = run_config("sift200m", ctx, args, O, graph="host", steps=leg_steps, warmup=leg_warm, traffic=False, keep=True)
-            cfg["at_sift200m"] = leg_summary(r["res"], r["wl"], "host", recall=r["recall"], extra={"parity_vs_oracle_first_64": r["ok"]})
-            flat(cfg, "sift200m", cfg["at_sift200m"])
-            cfg["sift200m_hops_max"] = cfg["at_sift200m"]["hops_p50_p99_max"][2]
+            # SIFT1B's PQ layout and placement (graph in host RAM, rows pulled over PCIe) on a structured, recall-verified index three tenths of the
+            # headline's size: "QPS @ recall >= 0.9" at 3e8 points, the first 64 queries against the oracle
+            r = run_config("sift300m", ctx, args, O, graph="host", steps=leg_steps, warmup=leg_warm, traffic=False, keep=True)
+            cfg["at_sift300m"] = leg_summary(r["res"], r["wl"], "host", recall=r["recall"], extra={"parity_vs_oracle_first_64": r["ok"]})
+            flat(cfg, "sift300m", cfg["at_sift300m"])
+            cfg["sift300m_hops_max"] = cfg["at_sift300m"]["hops_p50_p99_max"][2]
             release_config(r)
-        guarded("at_sift200m", leg_250m)
+        guarded("at_sift300m", leg_250m)
 
     if "sift100m" in want and leg_on("sift100m"):
         def leg_100m():

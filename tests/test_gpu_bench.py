@@ -33,7 +33,7 @@ def test_bench_measures_hbm_traffic_in_the_same_run(libbang):
     assert rf["traffic_over_algorithmic"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"], rel=1e-3) and rf["hbm_traffic_GBps"] > 0
     # scalars first: the keys the record must keep sit in front of the prose and the nested objects
     first = list(d["config"])[:24]
-    for key in ("workload", "L", "recall_at_10", "k2_alone_frac", "traffic_over_algorithmic", "qps_incl_init", "sift200m_qps", "sift1m_qps", "walker_qps"):
+    for key in ("workload", "L", "recall_at_10", "k2_alone_frac", "traffic_over_algorithmic", "qps_incl_init", "sift300m_qps", "sift1m_qps", "walker_qps"):
         assert key in first, key
     rkeys = list(rf)
     assert rkeys.index("traffic") < rkeys.index("kernel") and rkeys.index("k2_alone_frac") < rkeys.index("kernel")
