@@ -1080,7 +1080,7 @@ def main():
         guarded("at_sift1b_shape_walker", leg_walker)
 
     if leg_on("sift300m"):
-        def leg_250m():
+        def leg_300m():
             # SIFT1B's PQ layout and placement (graph in host RAM, rows pulled over PCIe) on a structured, recall-verified index three tenths of the
             # headline's size: "QPS @ recall >= 0.9" at 3e8 points, the first 64 queries against the oracle
             r = run_config("sift300m", ctx, args, O, graph="host", steps=leg_steps, warmup=leg_warm, traffic=False, keep=True)
@@ -1088,7 +1088,7 @@ def main():
             flat(cfg, "sift300m", cfg["at_sift300m"])
             cfg["sift300m_hops_max"] = cfg["at_sift300m"]["hops_p50_p99_max"][2]
             release_config(r)
-        guarded("at_sift300m", leg_250m)
+        guarded("at_sift300m", leg_300m)
 
     if "sift100m" in want and leg_on("sift100m"):
         def leg_100m():
