@@ -56,7 +56,7 @@ class SearchParams(C.Structure):
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
         ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
-        ("pool", C.c_uint32), ("d_pool_jobs", C.c_void_p), ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32), ("pool_helpers", C.c_uint32),
+        ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32),
     ]
 
 
@@ -76,7 +76,7 @@ class Stats(C.Structure):
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
                 ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64),
-                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64), ("pool_jobs", C.c_uint64), ("pool_self_chunks", C.c_uint64)]
+                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64)]
 
 
 ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source
@@ -286,7 +286,7 @@ class Engine:
         """(ids [Q][L + 50] u32, counts [Q]): the nodes every query of the last batch expanded, in expansion order."""
         ids = np.zeros((Q, L + EXTRA_ITERS), np.uint32)
         cnt = np.zeros(Q, np.uint32)
-        _check(lib().bang_get_candidate_log(self._h, _vp(ids), C.c_uint32(ids.shape[1]), _vp(cnt)), "bang_get_candidate_log")
+        _check(lib().bang_get_candidate_log(self._h, _vp(ids), C.c_uint32(ids.shape[1]), _vp(cnt), C.c_uint32(Q)), "bang_get_candidate_log")
         return ids, cnt
 
     def free(self):

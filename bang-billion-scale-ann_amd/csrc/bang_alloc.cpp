@@ -26,7 +26,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_queries); dfree(e->d_qc); dfree(e->d_lut); dfree(e->d_bloom); dfree(e->d_nbrs);
   dfree(e->d_dist); dfree(e->d_cnt); dfree(e->d_wl_ids); dfree(e->d_wl_dist); dfree(e->d_wl_vis); dfree(e->d_wl_cnt);
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
-  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_pool_jobs); dfree(e->d_fp); dfree(e->d_results);
+  dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_fp); dfree(e->d_results);
   e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
   if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
   dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
@@ -43,8 +43,15 @@ void free_batch(bang_engine* e) {
   e->inited = false;
 }
 
-int alloc_buffers(bang_engine* e, int Q) {
-  BANG_TRY(validate_pull_rows(e));
+// an allocation that fails for want of HBM is BANG_ERR_NOMEM (bang_alloc_e then retries without the HBM row cache); anything else BANG_ERR_HIP
+#define HIP_TRY_ALLOC(x)                                                  \
+  do {                                                                     \
+    const hipError_t _a = (x);                                             \
+    if (_a == hipErrorOutOfMemory) { (void)hipGetLastError(); bang_set_error("out of device memory: %s", #x); return BANG_ERR_NOMEM; } \
+    HIP_TRY(_a);                                                           \
+  } while (0)
+
+int alloc_buffers(bang_engine* e, int Q) {         // (bang_alloc_e has validated the pull rows)
   const size_t L = (size_t)e->L, nq = (size_t)Q;
   const size_t rows = L + BANG_EXTRA_ITERS;                                  // uMAX_PARENTS_PERQUERY :370
   const size_t vb = vec_bytes(e);
@@ -101,7 +108,7 @@ int alloc_buffers(bang_engine* e, int Q) {
   // from an entry source has nothing to map: error)
   if (!dev_graph && !e->search_v2 && !e->graph) BANG_TRY(map_graph_file(e));
   e->fp_direct = false;
-  HIP_TRY(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
+  HIP_TRY_ALLOC(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));
   else BANG_TRY(dmalloc(&e->d_lut, nq * e->m * 256));                       // :380
   // :393 (bit-packed: 8x smaller).  BANG_FILTER_MEM: 1 = uncached, 2 = fine-grained device memory (experiment: does a filter probe
@@ -109,7 +116,7 @@ int alloc_buffers(bang_engine* e, int Q) {
   {
     const long fm = env_long("BANG_FILTER_MEM", 0);
     if (fm == 1 || fm == 2) {
-      HIP_TRY(hipExtMallocWithFlags((void**)&e->d_bloom, std::max<size_t>(nq * BANG_BF_WORDS * 4, 16), fm == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+      HIP_TRY_ALLOC(hipExtMallocWithFlags((void**)&e->d_bloom, std::max<size_t>(nq * BANG_BF_WORDS * 4, 16), fm == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
     } else BANG_TRY(dmalloc(&e->d_bloom, nq * BANG_BF_WORDS));
   }
   BANG_TRY(dmalloc(&e->d_nbrs, nq * BANG_NBR_STRIDE));
@@ -124,7 +131,6 @@ int alloc_buffers(bang_engine* e, int Q) {
   BANG_TRY(dmalloc(&e->d_cand_cnt, nq));
   BANG_TRY(dmalloc(&e->d_qstats, nq * 2));
   BANG_TRY(dmalloc(&e->d_qskip, nq));
-  BANG_TRY(dmalloc(&e->d_pool_jobs, nq));
   {
     const size_t a64 = 63;
     e->res_off_dists = ((size_t)nq * e->k * 8 + a64) & ~a64;
@@ -149,7 +155,7 @@ int alloc_buffers(bang_engine* e, int Q) {
       e->fp_direct = true;                                                   // walker threads write the vector log through the BAR
     } else {
       (void)hipGetLastError();
-      HIP_TRY(hipMalloc((void**)&e->d_fp, rows * nq * vb));                  // :398
+      HIP_TRY_ALLOC(hipMalloc((void**)&e->d_fp, rows * nq * vb));                  // :398
     }
     HIP_TRY(hipHostMalloc((void**)&e->h_parents, slots_cap * 4, hipHostMallocMapped));       // :419
     HIP_TRY(hipHostGetDevicePointer((void**)&e->d_parents_map, e->h_parents, 0));
@@ -227,7 +233,7 @@ int alloc_buffers(bang_engine* e, int Q) {
     if (e->search_host) ln.pw_expect.reset(new std::atomic<uint32_t>[8 * KT_WGS]);
     if (e->timing) {
       ln.kt_launches = rows + 4;
-      HIP_TRY(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));     // {start, end} stamp per workgroup and launch
+      HIP_TRY_ALLOC(hipMalloc((void**)&ln.d_ktime, ln.kt_launches * KT_WGS * 16));     // {start, end} stamp per workgroup and launch
       HIP_TRY(hipMemset(ln.d_ktime, 0, ln.kt_launches * KT_WGS * 16));
     }
   }

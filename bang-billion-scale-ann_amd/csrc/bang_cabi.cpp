@@ -162,8 +162,9 @@ extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
   e->Qcap = Q;
   e->Qcur = 0;
   e->cand_stride = (uint32_t)e->L + BANG_EXTRA_ITERS;
+  BANG_TRY(validate_pull_rows(e));       // a truncated / overwritten rows file is reported as such -- and never costs the HBM row cache below
   int rc = alloc_buffers(e, Q);
-  if (rc != BANG_OK && e->d_rows_hbm) {
+  if (rc == BANG_ERR_NOMEM && e->d_rows_hbm) {
     // the copy of the first adjacency rows took the HBM a batch of this size needs: the rows are in host memory anyway
     free_batch(e);
     dfree(e->d_rows_hbm);
@@ -188,7 +189,7 @@ extern "C" int bang_init_e(bang_engine_t* e, int Q) {
   ia.Q = (uint32_t)Q; ia.medoid = (uint32_t)e->medoid; ia.cand_stride = e->cand_stride;
   ia.d_bloom = e->d_bloom; ia.d_cand_ids = e->d_cand_ids; ia.d_cand_row = e->d_cand_row; ia.d_cand_cnt = e->d_cand_cnt;
   ia.d_wl_cnt = e->d_wl_cnt; ia.d_mark = e->d_mark; ia.d_parents = e->d_parents_dev; ia.d_cnt = e->d_cnt;
-  ia.d_qstats = e->d_qstats; ia.d_qskip = e->d_qskip; ia.d_pool_jobs = e->d_pool_jobs;
+  ia.d_qstats = e->d_qstats; ia.d_qskip = e->d_qskip;
   ia.d_active = e->d_active; ia.n_active = e->d_active ? e->cand_stride + 2 : 0;
   hipStream_t st = e->lanes.empty() ? nullptr : e->lanes[0]->s_main;
   BANG_TRY(bang_k_init_all(&ia, st));
@@ -343,8 +344,6 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
       std::vector<uint32_t> sk((size_t)e->Qcur);
       HIP_TRY(hipMemcpy(sk.data(), e->d_qskip, sk.size() * 4, hipMemcpyDeviceToHost));
       for (uint32_t v : sk) s.filter_loads_skipped += v;
-      HIP_TRY(hipMemcpy(sk.data(), e->d_pool_jobs, sk.size() * 4, hipMemcpyDeviceToHost));
-      for (uint32_t v : sk) { s.pool_jobs += v & 0xffffu; s.pool_self_chunks += v >> 16; }
     }
     std::vector<uint32_t> cc((size_t)e->Qcur);
     HIP_TRY(hipMemcpy(cc.data(), e->d_cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
@@ -388,10 +387,11 @@ extern "C" int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, u
   return BANG_OK;
 }
 
-extern "C" int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts) {
+extern "C" int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts, uint32_t num_queries) {
   if (!e || !ids || !counts) return BANG_ERR_ARG;
   if (!e->allocated || e->Qcur <= 0) { bang_set_error("bang_get_candidate_log: no query has run on this allocation"); return BANG_ERR_ARG; }
   if (stride < e->cand_stride) { bang_set_error("bang_get_candidate_log: stride %u < %u (L + 50)", stride, e->cand_stride); return BANG_ERR_ARG; }
+  if (num_queries < (uint32_t)e->Qcur) { bang_set_error("bang_get_candidate_log: buffers hold %u queries, the last batch had %d", num_queries, e->Qcur); return BANG_ERR_ARG; }
   const size_t Q = (size_t)e->Qcur;
   HIP_TRY(hipMemcpy(counts, e->d_cand_cnt, Q * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy2D(ids, (size_t)stride * 4, e->d_cand_ids, (size_t)e->cand_stride * 4, (size_t)e->cand_stride * 4, Q, hipMemcpyDeviceToHost));

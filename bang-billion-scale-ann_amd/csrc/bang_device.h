@@ -73,34 +73,8 @@ struct QcRegs {
   }
 };
 
-// QcRow16: the centred query replicated per 16-lane row -- lane l of v[r] holds qc[16 r + (l & 15)] -- so that "pivot - query" is ONE
-// instruction, v_subrev_f32 with a DPP row broadcast of the query operand, instead of v_readlane + v_sub (K2 alone spends 128 of its
-// 597 VALU instructions per 64 rows on those v_readlanes).  ceil(QW / 16) registers per query: for kernels with registers to spare.
-template <int NR>
-struct QcRow16 {
-  float v[NR];
-};
-template <int N>
-__device__ __forceinline__ float sub_row_bcast(float p, float qreg) {     // p - (lane N of qreg's 16-lane row)
-  float d;
-  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(qreg), "v"(p), "n"(N));
-  return d;
-}
 template <class QC>
 __device__ __forceinline__ float qc_sub(const QC& qc, float p, uint32_t i) { return p - qc[i]; }
-template <int NR>
-__device__ __forceinline__ float qc_sub(const QcRow16<NR>& qc, float p, uint32_t i) {
-  const float r = qc.v[i >> 4];
-  switch (i & 15u) {                                   // i is a constant after unrolling: one case survives
-    case 0: return sub_row_bcast<0>(p, r);   case 1: return sub_row_bcast<1>(p, r);   case 2: return sub_row_bcast<2>(p, r);
-    case 3: return sub_row_bcast<3>(p, r);   case 4: return sub_row_bcast<4>(p, r);   case 5: return sub_row_bcast<5>(p, r);
-    case 6: return sub_row_bcast<6>(p, r);   case 7: return sub_row_bcast<7>(p, r);   case 8: return sub_row_bcast<8>(p, r);
-    case 9: return sub_row_bcast<9>(p, r);   case 10: return sub_row_bcast<10>(p, r); case 11: return sub_row_bcast<11>(p, r);
-    case 12: return sub_row_bcast<12>(p, r); case 13: return sub_row_bcast<13>(p, r); case 14: return sub_row_bcast<14>(p, r);
-    default: return sub_row_bcast<15>(p, r);
-  }
-}
-
 template <int PSZ, int NHI, class QC>
 __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, const QC& qc, uint32_t c, uint32_t code) {
   float t = 0.0f;
@@ -158,13 +132,7 @@ struct PqRow {
   uint32_t sh;
 };
 
-// NT: the row is requested with the non-temporal hint (global_load ... nt).  A code row is read once per evaluation from a table of
-// 32 MB .. 70 GB and never again soon: streamed through L2 / Infinity Cache with the default policy it evicts the lines that ARE
-// re-used -- the live queries' visited filters (50 KB each, ~200 MB in all).
-#ifndef BANG_CODES_NT
-#define BANG_CODES_NT 0
-#endif
-template <int NDW, bool ALIGNED, bool NT = (BANG_CODES_NT != 0)>
+template <int NDW, bool ALIGNED>
 __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_t* __restrict__ codes, uint32_t m,
                                             uint32_t id) {
   const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
@@ -172,7 +140,7 @@ __device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_
   const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
 #pragma unroll
   for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4; ++i) {
-    const u32x4a v = NT ? __builtin_nontemporal_load(p + i) : p[i];
+    const u32x4a v = p[i];
     r.w[4 * i + 0] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
   }
   r.w[PqRow<NDW, ALIGNED>::NX4 * 4] = 0;
@@ -368,138 +336,6 @@ __device__ __forceinline__ float pq_row_reduce_pipe(const PqRow<NDW, ALIGNED>& r
   const float x = (s[0] + s[1]) + (s[2] + s[3]);
   const float y = (s[4] + s[5]) + (s[6] + s[7]);
   return x + y;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// TEAM form of the row reduce: LPR adjacent lanes share ONE code row (the search kernel's helper waves, bang_search.hip)
-// ---------------------------------------------------------------------------------------------------------------------
-// A wave alone on its SIMD reduces 64 rows in the time ONE row's chain of 4 NDW chunks takes (one lane per row, ~10 VALU
-// instructions per chunk: issue-bound).  Here lane j of a group of LPR (2 or 4) lanes takes the chunks c == j (mod LPR) -- byte j
-// (and j + 2) of every code dword -- so a row is done after 4 NDW / LPR chunk steps, and 64 / LPR rows fit a wave instruction.
-// The canonical order (:1229-1239) survives: partial sum s_l takes the chunks c == l (mod 8) in ascending order, and
-// all of them belong to lane l mod LPR, which meets them in ascending order (local slot v = (c & 7) / LPR); the tree
-// ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) is then two (LPR = 4) or one (LPR = 2) DPP quad-swap adds plus lane-local adds -- float
-// addition commutes bit for bit, so which lane's operand comes first does not matter.  Lane 0 of every group ends with the value
-// pq_row_reduce() computes.
-// TeamQc: the centred query in the lane's own order -- element [u * PSZ + i] = qc[(c(u) ) * PSZ + i], c(u) = LPR u + j the lane's
-// u-th chunk -- loaded from d_qc when a helper wave starts serving another query (QW / LPR registers).
-template <int PSZ, int NDW, int LPR>
-struct TeamQc {
-  static constexpr int NU = 4 * NDW / LPR;              // chunks per lane
-  float v[NU * PSZ];
-  __device__ __forceinline__ void load(const float* __restrict__ src /* d_qc + q * QW */, uint32_t j) {
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const float* a = src + ((uint32_t)(LPR * u) + j) * PSZ;
-      if (PSZ == 1) v[u] = a[0];
-      else if (PSZ == 2) { const float2 t = *(const float2*)a; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
-      else {
-#pragma unroll
-        for (int i = 0; i < PSZ; i += 4) { const float4 t = *(const float4*)(a + i); v[u * PSZ + i] = t.x; v[u * PSZ + i + 1] = t.y; v[u * PSZ + i + 2] = t.z; v[u * PSZ + i + 3] = t.w; }
-      }
-    }
-  }
-};
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float x) {     // x of another lane of my quad (quad_perm CTRL); every lane of the quad must be executing
-  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, true));
-}
-template <int PSZ, int NDW, bool ALIGNED, int NHI, int LPR>
-__device__ __forceinline__ float pq_row_reduce_team(const PqRow<NDW, ALIGNED>& r, const float* __restrict__ piv_lds, const TeamQc<PSZ, NDW, LPR>& qq,
-                                                    uint32_t j /* lane & (LPR - 1) */) {
-  static_assert(LPR == 2 || LPR == 4, "2 or 4 lanes per row");
-  constexpr int NU = 4 * NDW / LPR;                     // chunks per lane: u -> dword k = u / BPD, byte j + LPR (u % BPD)
-  constexpr int BPD = 4 / LPR;                          // bytes of a dword per lane
-  constexpr int NS = 8 / LPR;                           // partial sums per lane: ps[v] = s_{j + LPR v}
-  constexpr int G = PSZ <= 2 ? 8 : PSZ == 4 ? 4 : 2;    // chunks per pipeline group (<= 16 pivot floats in flight per lane and group)
-  constexpr int NG = (NU + G - 1) / G;
-  float ps[NS];
-#pragma unroll
-  for (int v = 0; v < NS; ++v) ps[v] = 0.0f;
-  PivEntry<PSZ, NHI> e[2][G];
-  uint32_t* w = const_cast<uint32_t*>(r.w);
-  const uint32_t sh8 = 8u * j;
-  // the lane's pivot entry of chunk c = c0 + j (c0 a compile-time multiple of LPR): "is this a 2-dim chunk" is known at compile time
-  // for every dword but the one the 2-dim / 1-dim boundary of the exact-size table falls into (NHI not a multiple of LPR)
-  auto load_group = [&](int g, PivEntry<PSZ, NHI>* dst) {
-#pragma unroll
-    for (int jj = 0; jj < G; ++jj) {
-      const int u = g * G + jj;
-      if (u < NU) {
-        const int k = u / BPD, c0 = 4 * k + LPR * (u % BPD);
-        const uint32_t dw = ALIGNED ? w[k] : __builtin_amdgcn_alignbyte(w[k + 1], w[k], r.sh);
-        const uint32_t code = (dw >> (sh8 + 8u * (uint32_t)(LPR * (u % BPD)))) & 0xffu;
-        const uint32_t c = (uint32_t)c0 + j;
-        if (PSZ == 2 && NHI > 0) {
-          if (c0 + LPR - 1 < NHI) { const float2 t = *(const float2*)(piv_lds + c * 512u + code * 2u); dst[jj].v[0] = t.x; dst[jj].v[1] = t.y; }
-          else if (c0 >= NHI) { dst[jj].v[0] = piv_lds[(uint32_t)NHI * 256u + c * 256u + code]; dst[jj].v[1] = 0.0f; }
-          else if (c < (uint32_t)NHI) { const float2 t = *(const float2*)(piv_lds + c * 512u + code * 2u); dst[jj].v[0] = t.x; dst[jj].v[1] = t.y; }
-          else { dst[jj].v[0] = piv_lds[(uint32_t)NHI * 256u + c * 256u + code]; dst[jj].v[1] = 0.0f; }
-        } else {
-          const float* a = piv_lds + ((size_t)c * 256 + code) * PSZ;
-          if (PSZ == 1) dst[jj].v[0] = a[0];
-          else if (PSZ == 2) { const float2 t = *(const float2*)a; dst[jj].v[0] = t.x; dst[jj].v[1] = t.y; }
-          else {
-#pragma unroll
-            for (int i = 0; i < PSZ; i += 4) { const float4 t = *(const float4*)(a + i); dst[jj].v[i] = t.x; dst[jj].v[i + 1] = t.y; dst[jj].v[i + 2] = t.z; dst[jj].v[i + 3] = t.w; }
-          }
-        }
-      }
-    }
-  };
-  auto eval = [&](int u, const PivEntry<PSZ, NHI>& en) -> float {      // == lut_entry(): the fmaf chain of K1 (:1118-1128)
-    const int c0 = 4 * (u / BPD) + LPR * (u % BPD);
-    float t = 0.0f;
-    if (PSZ == 2 && NHI > 0) {
-      const float d0 = en.v[0] - qq.v[2 * u];
-      t = __builtin_fmaf(d0, d0, t);
-      if (c0 + LPR - 1 < NHI) { const float d1 = en.v[1] - qq.v[2 * u + 1]; t = __builtin_fmaf(d1, d1, t); }
-      else if (c0 < NHI) {                                                // the boundary dword: 1-dim chunks keep the one-term value
-        const float d1 = en.v[1] - qq.v[2 * u + 1];
-        const float t2 = __builtin_fmaf(d1, d1, t);
-        t = ((uint32_t)c0 + j < (uint32_t)NHI) ? t2 : t;
-      }
-      return t;
-    }
-#pragma unroll
-    for (int i = 0; i < PSZ; ++i) { const float d = en.v[i] - qq.v[u * PSZ + i]; t = __builtin_fmaf(d, d, t); }
-    return t;
-  };
-  auto fence = [&](int g) {
-    reg_fence<NS>(ps);
-    if (g < NG) {
-#pragma unroll
-      for (int jj = 0; jj < G; ++jj) reg_fence<PSZ>(e[g & 1][jj].v);
-    }
-#pragma unroll
-    for (int u = (g + 1) * G; u < (g + 2) * G && u < NU; u += BPD) {
-      asm volatile("" : "+v"(w[u / BPD]));
-      if (!ALIGNED) asm volatile("" : "+v"(w[u / BPD + 1]));
-    }
-  };
-  load_group(0, e[0]);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    fence(g);
-    if (g + 1 < NG) load_group(g + 1, e[(g + 1) & 1]);
-#pragma unroll
-    for (int jj = 0; jj < G; ++jj) {
-      const int u = g * G + jj;
-      if (u < NU) ps[u % NS] = ps[u % NS] + eval(u, e[g & 1][jj]);
-    }
-  }
-  if (LPR == 4) {
-    float x = ps[0], y = ps[1];
-    x = x + dpp_quad<0xB1>(x);          // lane 0: s0 + s1, lane 2: s2 + s3
-    y = y + dpp_quad<0xB1>(y);
-    x = x + dpp_quad<0x4E>(x);          // lane 0: (s0 + s1) + (s2 + s3)
-    y = y + dpp_quad<0x4E>(y);
-    return x + y;
-  }
-  float a[NS];
-#pragma unroll
-  for (int v = 0; v < NS; ++v) a[v] = ps[v] + dpp_quad<0xB1>(ps[v]);      // a0 = s0 + s1, a1 = s2 + s3, a2 = s4 + s5, a3 = s6 + s7
-  return (a[0] + a[NS > 1 ? 1 : 0]) + (a[NS > 2 ? 2 : 0] + a[NS > 3 ? 3 : 0]);
 }
 
 __device__ __forceinline__ uint32_t lower_bound_lds(const float* arr, uint32_t hi, float target) {  // :1718-1732

@@ -226,8 +226,6 @@ struct bang_engine {
   uint32_t* d_pub_c = nullptr;
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
   uint32_t* d_qskip = nullptr;         // [Q] filter-word loads saved by the on-chip summary (search kernel, self-paced)
-  uint32_t* d_pool_jobs = nullptr;     // [Q] iterations whose distance stage went to the K2 pool (search kernel, self-paced)
-  int pool_opt = -1;                   // option "pool": the K2 pool of the self-paced search kernel, -1 = auto (on), 0 = off, 1 = on
   std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
   int pq_ragged = 1;                   // 2-float PQ layouts: exact-size pivot table where possible (0 = always the padded table)
@@ -289,7 +287,13 @@ inline int ensure_device(bang_engine* e) {
 
 template <typename T>
 int dmalloc(T** p, size_t count) {
-  HIP_TRY(hipMalloc((void**)p, std::max<size_t>(count * sizeof(T), 16)));
+  const hipError_t err = hipMalloc((void**)p, std::max<size_t>(count * sizeof(T), 16));
+  if (err == hipErrorOutOfMemory) {                 // told apart from other failures: bang_alloc retries without the HBM row cache
+    (void)hipGetLastError();
+    bang_set_error("out of device memory (%zu bytes wanted)", count * sizeof(T));
+    return BANG_ERR_NOMEM;
+  }
+  HIP_TRY(err);
   return BANG_OK;
 }
 template <typename T>

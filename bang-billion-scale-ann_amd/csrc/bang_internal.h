@@ -35,7 +35,7 @@ typedef struct {
   uint32_t Q, medoid, cand_stride, n_active;
   uint32_t* d_bloom;                                   /* [Q][BANG_BF_WORDS] */
   uint32_t *d_cand_ids, *d_cand_row, *d_cand_cnt, *d_wl_cnt, *d_mark, *d_parents, *d_cnt;
-  uint32_t *d_qstats, *d_qskip, *d_pool_jobs, *d_active;   /* may be NULL */
+  uint32_t *d_qstats, *d_qskip, *d_active;   /* may be NULL */
 } bang_init_params;
 int bang_k_init_all(const bang_init_params* a, void* stream);
 

@@ -1202,7 +1202,6 @@ __global__ __launch_bounds__(256) void init_all_kernel(bang_init_params a) {
     a.d_cnt[q] = 0;
     if (a.d_qstats) { a.d_qstats[2 * q] = 0; a.d_qstats[2 * q + 1] = 0; }
     if (a.d_qskip) a.d_qskip[q] = 0;
-    if (a.d_pool_jobs) a.d_pool_jobs[q] = 0;
   }
   if (a.d_active) for (size_t i = tid; i < a.n_active; i += nt) a.d_active[i] = 0;
 }

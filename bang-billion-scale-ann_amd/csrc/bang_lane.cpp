@@ -153,9 +153,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1; sp.n_nodes = e->N;
     sp.d_qskip = e->d_qskip + ln.q0;
-    sp.d_pool_jobs = e->d_pool_jobs + ln.q0;
-    sp.pool = e->pool_opt > 0 ? 1u : 0u;                 // (auto = off: measured no faster)
-    sp.pool_helpers = (uint32_t)std::max(0L, env_long("BANG_POOL_HELPERS", 0));
     sp.merge_late = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_MERGE_LATE", 0)));
     { const long si = env_long("BANG_SUMM_ITERS", 0); sp.summ_iters = si < 0 ? 0xFFFFFFFFu : (uint32_t)si; }     // 0 = auto, -1 = always
     sp.d_ktime = ktime_slot(e, ln);
@@ -175,14 +172,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       (void)hipMemcpy(pr.data(), d_prof, pr.size() * 8, hipMemcpyDeviceToHost);
       (void)hipFree(d_prof);
       print_phase_prof(pr, Gd);
-      if (sp.pool) {                                                         // K2 pool: where the leaders' and the helpers' time went
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t w = 0; w < Gd; ++w) for (int k = 0; k < 8; ++k) a[k] += (double)pr[(size_t)w * 16 + k];
-        if (a[0] > 0)
-          fprintf(stderr, "[search] K2 pool: %.0f jobs; per job: owner reduced %.2f chunks itself in %.2f us, then waited %.2f us for the helpers; %.0f helper chunks of %.2f us "
-                          "each (%.0f %% of the helpers' time; %.2f query switches per chunk)\n", a[0], a[3] / a[0], a[1] * 0.01 / a[0], a[2] * 0.01 / a[0], a[4],
-                  a[4] > 0 ? a[5] * 0.01 / a[4] : 0.0, a[6] > 0 ? 100.0 * a[5] / a[6] : 0.0, a[4] > 0 ? a[7] / a[4] : 0.0);
-      }
     }
     iter = cap_iter;                                                         // refined from the per-query counts below
   } else if (e->search_host) {

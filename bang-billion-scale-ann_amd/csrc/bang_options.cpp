@@ -53,9 +53,6 @@ static const OptionDef kOptions[] = {
     {"numa", "BANG_NUMA", &bang_engine::numa_opt, -1, 1, INT, BEFORE_ALLOC, "1 = pin walker threads to the GPU's NUMA node, one physical core each; 0 / -1 = leave them to the scheduler"},
     {"timing", "BANG_TIMING", &bang_engine::timing, 0, 1, INT, BEFORE_ALLOC, "1 = stamp every search / front launch in-kernel (s_memrealtime) for bang_get_stats"},
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
-    {"pool", "BANG_POOL", &bang_engine::pool_opt, -1, 1, INT, ANY,
-     "self-paced search kernel, long code rows: waves without a query of their own (a batch smaller than CUs x waves; the drain of any batch) serve the "
-     "distance stage of their workgroup's queries (the K2 pool); 1 = on, 0 / -1 (auto) = off: measured no faster (DESIGN 4.6) and compiled in only with -DBANG_SEARCH_POOL=1 (lib_pool).  Same results"},
     // ---- may change between queries
     {"use_flag", "BANG_USE_FLAG", &bang_engine::use_flag, 0, 1, FLAG, BEFORE_ALLOC, "0 = wait for the front kernel with runtime calls instead of its in-kernel completion flag (ablation)"},
     {"compact", "BANG_COMPACT", &bang_engine::compact, 0, 1, FLAG, ANY, "launch-per-iteration loop: straggler compaction on / off"},
@@ -82,7 +79,6 @@ static const SwitchDef kSwitches[] = {
     {"BANG_FILTER_MEM", "visited filters in 1 = uncached / 2 = fine-grained device memory instead of ordinary device memory (experiment, read at bang_alloc)"},
     {"BANG_SUMM_ITERS", "search kernel, self-paced form: the filter summary serves a query's first N iterations only (0 = auto: all, off for launches of <= 5 queries per CU; -1 = all)"},
     {"BANG_MERGE_LATE", "search kernel, self-paced form: 1 = sort/merge of an iteration behind the next iteration's probe issue, 2 = behind the row request, 0 = auto (1 for launches that fill the chip)"},
-    {"BANG_POOL_HELPERS", "search kernel, K2 pool: cap on the waves launched beyond those that own a query from the start (experiments)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},
     {"BANG_MAILBOX_BYTES", "results up to this size return through the pinned mirror in one copy (default 8 MB)"},

@@ -24,11 +24,10 @@
 //    sort/merge.  In host-graph mode the parents of a workgroup's waves go to the host walker in one coalesced store per round,
 //    and the sort/merge overlaps the walker's round trip.
 //
-//  * Round 4: a launch of at most 5 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of
-//    every iteration and a lightly loaded chip is not short of requests); an adjacency id >= N is never followed (n_nodes: the batch
-//    ends with an error instead of a wild read); and two experiments that measured no faster stay in the source behind build flags,
-//    bit-identical and tested: the K2 POOL (-DBANG_SEARCH_POOL=1: waves without a query serve the distance stage of their workgroup's
-//    queries, four lanes per code row -- pq_row_reduce_team) and the summary per half-word (-DBANG_SUMMARY_HALFWORDS=1).
+//  * A launch of at most 5 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of every iteration and
+//    a lightly loaded chip is not short of requests); an adjacency id >= N is never followed (n_nodes: the batch ends with an error
+//    instead of a wild read).  Experiments that measured no faster (K2 pool, half-word summary, ...) live in git history and
+//    docs/HISTORY.md, not here.
 //
 // Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
 // canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
@@ -54,18 +53,12 @@ struct SearchArgs {
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
   uint32_t merge_late;       // self-paced form: 1 = K3 of iteration i runs behind the probe issue of iteration i + 1 (full launches)
-  uint32_t pool;             // self-paced form: waves without a query of their own serve the distance stage of their workgroup's queries (K2 pool)
 };
 
-#ifndef BANG_SEARCH_COOP
-#define BANG_SEARCH_COOP 1          // self-paced form: code rows fetched cooperatively (CoopFetch, bang_device.h)
-#endif
-// The cooperative fetch pays from three 16-byte pieces per row on (rows of 12+ code dwords, m > 44): two-piece rows (m = 32) gain
-// nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging area.
-#ifndef BANG_HOST_FULL
-#define BANG_HOST_FULL 1            // host-paced instances of the long-row layouts: 12 waves x 168 VGPRs, with filter summary + cooperative fetch
-#endif
-__host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return BANG_SEARCH_COOP && ndw >= 12 && (!host_paced || (BANG_HOST_FULL && ndw >= 16)); }
+// Code rows are fetched cooperatively (CoopFetch, bang_device.h) from three 16-byte pieces per row on (rows of 12+ code dwords,
+// m > 44): two-piece rows (m = 32) gain nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging
+// area.  The host-paced instances do so for the long-row layouts only (12 waves x 168 VGPRs, with the filter summary).
+__host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return ndw >= 12 && (!host_paced || ndw >= 16); }
 // per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots; 256 where the scratch has them) and the
 // summary's transposition area alias both, and so does the staging area of the cooperative code-row fetch (256 words: one wave
 // instruction's worth of 16-byte pieces)
@@ -75,31 +68,6 @@ __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L
 __host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx, int ndw, bool host_paced) {
   return nctx * search_wl_words(L) + search_scratch_words(ndw, host_paced) + (nctx == 2 ? 32u : 0u);
 }
-
-// ---- the K2 POOL (self-paced form): what a wave without a query of its own does.
-// A lightly loaded wave's iteration is bound by its own instruction issue: the row reduce alone is 4 NDW chunk steps of ~10 VALU
-// instructions (1.3 us of the 7.9 us a 1 250-query shard's iteration takes), and the other three SIMDs of its CU idle.  Waves that
-// find the query hand-out exhausted -- at once when Q < CUs x waves (a rank's shard of 8), and in the drain of every batch -- become
-// HELPERS of their workgroup: a wave that owns a query ("leader") posts the <= 64 survivors of an iteration as a job of chunks of
-// 64 / LPR rows in its own LDS scratch, runs the filter update meanwhile, and the helpers fetch the code rows and reduce them with
-// LPR lanes per row (pq_row_reduce_team: a quarter of the chunk steps per row, bit-identical sums).  Leaders never wait for a
-// helper that is not there: a job is only posted while a helper is idle, and whatever is unclaimed when the filter update is done
-// the leader reduces itself.
-// Compiled OUT of the default build: measured no faster (the helpers' chunk takes 2.8 us, two dependent memory round
-// trips like the owner's own path, and what the owner saves it loses to the hand-over and to twelve waves sharing the LDS), and the
-// extra uniform state costs the 168-VGPR instances their last free registers (SGPRs spill into VGPR lanes: 32-100 B of scratch with
-// reloads inside the row reduce, 8.0 -> 9.8 ms per SIFT1B-shape batch).  `make OUT=lib_pool EXTRA_CXXFLAGS=-DBANG_SEARCH_POOL=1` builds
-// it (option "pool" = 1 then turns it on); tests/test_gpu_pool.py runs that build against the oracle.
-#ifndef BANG_SEARCH_POOL
-#define BANG_SEARCH_POOL 0
-#endif
-#ifndef BANG_POOL_LPR
-#define BANG_POOL_LPR 4             // lanes per code row in a helper wave
-#endif
-__host__ __device__ constexpr bool search_pool(int ndw, bool host_paced) { return BANG_SEARCH_POOL && !host_paced && search_coop(ndw, host_paced); }
-#define POOL_CTL_WORDS 80u          // LDS behind the waves' regions: [0] leaders left, [1] helpers, [2] idle helpers; per wave slot s at 4 + 4 s:
-                                    // {state = rows << 8 | chunks handed out, chunks done, query, -}
-#define POOL_RPC (64 / BANG_POOL_LPR)   // rows per chunk
 
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -187,41 +155,10 @@ __device__ __forceinline__ void filter_commit(uint32_t* tbl, int lane, bool& pa,
 // with p >= 192 share the positions p - 192: a set bit then also covers an alias, which only costs that word its shortcut),
 // register p >> 5, bit p & 31.  Read: six ds_bpermute (no LDS memory touched) + selects.  Set: the survivors' bits are transposed
 // through 128 (256) words of the wave's LDS scratch, two (four) registers per pass (ds_or_b32), and OR-ed into the registers.
-// HALF-WORD units (-DBANG_SUMMARY_HALFWORDS=1: NR = 12 registers, self-paced 168-VGPR instances): one bit per 16-bit half of a filter
-// word -- 25 024 units, probed with 16-bit loads and updated with 16-bit stores.  A query sets ~22 K of its 400 K slots in 201
-// iterations: at the end a WORD is still untouched with probability e^-1.8, a HALF-WORD with e^-0.9 -- measured 65 % of all probes
-// need no load instead of 46 % (DEEP100M-shape: 147 M of 225 M per batch instead of 103 M), and every probe that does reach memory
-// moves a whole 128-byte line (profiles/r04_traffic_calibration.md).  NOT the default: bit-identical (all GPU tests green with it),
-// but the twelve ds_bpermute per probe and the third transposition pass cost more than the saved requests give back -- SIFT1B-shape
-// 8.31 -> 8.57 ms per 10 K batch, a 1 250-query shard 1.74 -> 1.87 ms, DEEP100M-shape 7.53 -> 7.51 ms.
 #ifndef BANG_FILTER_SUMMARY
-#define BANG_FILTER_SUMMARY 1
+#define BANG_FILTER_SUMMARY 1       // build switch (A/B libraries): 0 = every probe is loaded
 #endif
-#ifndef BANG_SUMMARY_HALFWORDS
-#define BANG_SUMMARY_HALFWORDS 0
-#endif
-// the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting for the next
-// adjacency row, instead of inside the filter update in front of the distance stage (self-paced form; nothing reads the summary in between)
-#ifndef BANG_SUMM_SET_LATE
-#define BANG_SUMM_SET_LATE 1
-#endif
-// K3a + K3b of iteration i run in iteration i + 1, behind the issue of its filter probes -- the one wait of an iteration that had nothing
-// to cover it -- instead of behind the request for the next adjacency row, whose latency (0.8 us from HBM) is shorter than the merge (self-paced form)
-#ifndef BANG_MERGE_LATE
-#define BANG_MERGE_LATE 1
-#endif
-// the row reduce as a software pipeline over groups of 8 chunks (pq_row_reduce_pipe): search kernel / K2 streaming kernel
-// the filter's stores issued behind the arrival of the code rows instead of in front of the wait for them
-#ifndef BANG_FILTER_STORES_LATE
-#define BANG_FILTER_STORES_LATE 1
-#endif
-#ifndef BANG_REDUCE_PIPE
-#define BANG_REDUCE_PIPE 1
-#endif
-#ifndef BANG_K2_REDUCE_PIPE
-#define BANG_K2_REDUCE_PIPE 0
-#endif
-template <int SUMM_REGS>                               // 6: one bit per filter word; 12: one bit per half-word
+template <int SUMM_REGS>                               // 6: one bit per filter word
 struct FilterSummary {
   uint32_t s[SUMM_REGS];
   __device__ __forceinline__ void clear() {
@@ -558,32 +495,20 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   uint32_t* wg_lds = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words + (size_t)grp_in_wg * 128;
   if (HOST && gslot == 0) { wg_lds[lane] = 0u; wg_lds[64 + lane] = 0u; }
   if (HOST && nctx == 2 && lane < (int)(2 * SRCH_CTX_WORDS)) park[lane] = 0u;        // both contexts: inactive
-  // K2 pool (self-paced form): control words behind the waves' regions
-  constexpr bool POOL = search_pool(NDW, HOST);
-  const bool pool_on = POOL && a.pool != 0u;
-  uint32_t* pool_ctl = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)nwaves * a.wave_words;
-  if (pool_on && wave == 0) {
-    pool_ctl[lane] = (lane == 0) ? nwaves : 0u;
-    if (lane < (int)(POOL_CTL_WORDS - 64u)) pool_ctl[64 + lane] = 0u;
-  }
   __syncthreads();
   if (p.d_ktime && threadIdx.x == 0) p.d_ktime[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
   float* sd = (float*)scratch;
   uint32_t* ti = scratch;
   float* td = (float*)(scratch + 72);
-  uint32_t* sc = POOL ? scratch + 128 : scratch + 72;   // compaction scratch (== td: dead before the sort; K2 pool: behind the job's ids and distances, where the
-                                                        // filter's claim table follows it; [64..128) of it: the survivors' source lanes)
-  uint32_t* my_ctl = pool_ctl + 4 + 4 * wave;      // this wave's job words (K2 pool)
+  uint32_t* sc = scratch + 72;                     // compaction scratch (== td: dead before the sort)
   uint32_t* tbl = scratch;                         // filter claim table, 128 words (== sd + td: dead between the stages that use them)
   const uint32_t total_waves = gridDim.x * nwaves;
   const uint32_t gw = blockIdx.x * nwaves + wave;
   const uint32_t cand_stride = L + BANG_EXTRA_ITERS;
   constexpr int SB = (NDW >= 18) ? 6 : 0;          // long rows (70 .. 128 chunks): consumed 6 code dwords (24 chunks) at a time
-#ifndef BANG_HOST_EARLY_ROWS
-#define BANG_HOST_EARLY_ROWS 0     // host-paced instances: 60-100 B of scratch per lane with it, SIFT1B-shape 13.5 -> 16.3 ms
-#endif
-  constexpr bool EARLY_ROWS = !HOST || BANG_HOST_EARLY_ROWS;   // code rows requested before the filter update (else: behind it)
+  constexpr bool EARLY_ROWS = !HOST;                           // code rows requested before the filter update (host-paced instances: behind it --
+                                                               // 60-100 B of scratch per lane otherwise)
   constexpr bool COOP = search_coop(NDW, HOST);                // ... by P adjacent lanes per row, one 16-byte piece each
   const uint32_t code_stride = p.code_stride ? p.code_stride : p.m;
 
@@ -614,14 +539,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   };
   // which words of the current query's filter have been stored to (self-paced form; the host-paced instances have no registers to spare)
   constexpr bool SUMM = (BANG_FILTER_SUMMARY != 0) && (!HOST || search_maxt(NDW, HOST) < 1024);   // (needs 6 VGPRs the 16-wave host-paced instances do not have)
-  // unit of the summary = unit of the filter's loads and plain stores: a 32-bit word, or (12 registers, the 168-VGPR instances) a half-word
-  constexpr int SR = (SUMM && BANG_SUMMARY_HALFWORDS && !HOST && search_maxt(NDW, HOST) < 1024) ? 12 : 6;   // (the host-paced instances spill with 12)
-  constexpr uint32_t UB = (SR == 12) ? 4u : 5u, UM = (1u << UB) - 1u;
-  FilterSummary<SR> summ;
+  FilterSummary<6> summ;
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
-  uint32_t pool_jobs = 0;                          // diagnostic counter (d_pool_jobs): iterations whose distance stage went to the K2 pool
-  unsigned long long pl_self = 0, pl_wait = 0, pl_jobs = 0, pl_selfchunks = 0;   // diagnostic (p.d_prof): 100 MHz ticks of this wave as a leader
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -698,7 +618,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     // ---------------- a finished context takes its next query: the first one by position, then from the hand-out counter
     if (!active && !exhausted) {
-      if (!((started >> c) & 1u)) q = pool_on ? wave * gridDim.x + blockIdx.x : c * total_waves + gw;   // (pool: every CU gets its share of leaders)
+      if (!((started >> c) & 1u)) q = c * total_waves + gw;
       else {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
@@ -711,10 +631,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         evals = 0; fetched = 0; iter = 1;
         mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
-        pool_jobs = 0;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
-        if (pool_on && lane == 0) my_ctl[2] = q;
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
         cnt_in = p.d_seed[0]; x0 = p.d_seed[1 + lane]; x1 = p.d_seed[65];
         have_row = true;
@@ -725,9 +643,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
-    constexpr bool SET_LATE = (BANG_SUMM_SET_LATE != 0) && !HOST;
-    constexpr bool MERGE_LATE_C = (BANG_MERGE_LATE != 0) && !HOST && !POOL;   // (the pool's job area and the sort's scratch are the same words)
-    const bool MERGE_LATE = MERGE_LATE_C && a.merge_late != 0u;               // (uniform: full launches only, bang_k_search)
+    // self-paced form: the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting
+    // for the next adjacency row (nothing reads the summary in between); and in launches that fill every wave slot (a.merge_late,
+    // bang_k_search) K3a + K3b of iteration i run in iteration i + 1, behind the issue of its filter probes -- the one wait of an iteration
+    // that had nothing to cover it -- instead of behind the request for the next adjacency row
+    constexpr bool SET_LATE = !HOST;
+    const bool MERGE_LATE = !HOST && a.merge_late != 0u;                      // (uniform)
     bool sl_a = false, sl_b = false;                  // summary marks of this iteration's survivors, applied behind the merge
     uint32_t sl_ua = 0, sl_ub = 0;
     float d0 = BIG_DIST, d1 = BIG_DIST;
@@ -754,23 +675,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       fetched += ci;
       const bool v0 = (uint32_t)lane < ci;
       const bool v1 = ci > 64;                               // the 65th id exists in the seed list only (uniform)
-      // K2 pool: with a helper of this workgroup idle, the row goes out as a job the moment it has arrived -- ALL its ids, in chunks of
-      // POOL_RPC: the helpers fetch the code rows and reduce them while this wave hashes, probes, compacts and updates the filter, and the
-      // distances of the ids that turn out to be visited already are simply not looked at (a distance is a function of the id alone)
-      bool pooled = false;
-      uint32_t nchunks = 0;
-      if (POOL) {
-        if (pool_on && !first && ci > 0u && uni(__hip_atomic_load(&pool_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) {
-          pooled = true;
-          ++pool_jobs;
-          nchunks = (ci + (uint32_t)POOL_RPC - 1u) / (uint32_t)POOL_RPC;
-          if (v0) scratch[lane] = x0;
-          if (lane == 0) {
-            __hip_atomic_store(&my_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&my_ctl[0], ci << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (behind the ids: one wave's LDS operations execute in order)
-          }
-        }
-      }
       const uint32_t h0a = hash1(x0), h0b = hash2(x0);
       uint32_t h1a = 0, h1b = 0, w0a = 0, w0b = 0, w1a = 0, w1b = 0;
       // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip.
@@ -778,17 +682,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       bool la = v0, lb = v0;                                 // load word a / b?
       const bool summ_on = SUMM && (HOST || iter <= p.summ_iters);     // (uniform; one-way per query: once off, the registers go stale.  bang_k_search resolves 0 = auto)
       if (SUMM && summ_on) {
-        la = summ.test(h0a >> UB) && v0;
-        lb = summ.test(h0b >> UB) && v0;
+        la = summ.test(h0a >> 5) && v0;
+        lb = summ.test(h0b >> 5) && v0;
         probes_skipped += (uint32_t)__popcll(__ballot(v0 && !la)) + (uint32_t)__popcll(__ballot(v0 && !lb));
       }
-      if (UB == 5u) {
-        if (la) w0a = ld_bypass_l1(&bloom[h0a >> 5]);
-        if (lb) w0b = ld_bypass_l1(&bloom[h0b >> 5]);
-      } else {                                               // (global_load_ushort sc1)
-        if (la) w0a = __hip_atomic_load((const uint16_t*)bloom + (h0a >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lb) w0b = __hip_atomic_load((const uint16_t*)bloom + (h0b >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (la) w0a = ld_bypass_l1(&bloom[h0a >> 5]);
+      if (lb) w0b = ld_bypass_l1(&bloom[h0b >> 5]);
       if (v1) {
         h1a = hash1(x1); h1b = hash2(x1);
         if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
@@ -800,7 +699,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         mg_pending = false;
         head = worklist_head(s, w_n, lane);
       }
-      const bool pass0 = v0 && !(((w0a >> (h0a & UM)) & 1u) && ((w0b >> (h0b & UM)) & 1u));
+      const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
       const uint64_t m1 = __ballot(pass1);
@@ -810,12 +709,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // ordered compaction through LDS: survivors keep input order (CANON; the reference emits in atomicAdd order :1161)
       if (pass0) sc[lanes_below(m0)] = x0;
       if (pass1) sc[n0] = x1;
-      if (POOL) { if (pooled && pass0) sc[64 + lanes_below(m0)] = (uint32_t)lane; }
       wave_sync();
       if ((uint32_t)lane < n) sid0 = sc[lane];
       if (lane == 0 && n > 64) sid1 = sc[64];
-      uint32_t src = 0;                                      // K2 pool: where in the row this lane's survivor stood
-      if (POOL) { if (pooled && (uint32_t)lane < n) src = sc[64 + lane]; }
       wave_sync();
       evals += n;
       PH(2);   // compaction
@@ -823,23 +719,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      // K2 pool: chunks no helper has claimed by now are withdrawn and their survivors' rows requested here, as always (one lane per
-      // row); the helpers' chunks are waited for behind the filter update
-      uint32_t claimed = 0;
-      bool me = false;
-      if (POOL) {
-        if (pooled) {
-          uint32_t old = 0;
-          if (lane == 0) old = __hip_atomic_fetch_add(&my_ctl[0], nchunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (no claim succeeds behind this)
-          claimed = uni(old) & 0xffu;
-          if (claimed > nchunks) claimed = nchunks;
-          pool_jobs += (nchunks - claimed) << 16;                // (high half: chunks this wave reduced itself)
-          me = (uint32_t)lane < n && src / (uint32_t)POOL_RPC >= claimed;
-          if (__ballot(me) != 0ull) pq_row_load(row, p.d_codes, code_stride, me ? sid0 : 0u);     // (unconditional: the compiler's count of outstanding loads stays exact)
-        }
-      }
-      if (POOL && pooled) {}
-      else if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
       else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
@@ -847,29 +727,16 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // The claim rounds run now, on LDS, while the code rows travel; the stores they decide on are issued once the rows are here.
       bool pa = pass0, pb = pass0, st_a = false, st_b = false;
       uint32_t sv_a = 0, sv_b = 0;
-      if (POOL && pooled) {         // (the first 128 words of the scratch are the job's ids and distances: claim table and transposition area behind them)
-        filter_commit<128>(scratch + 128, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
-        if (SUMM && summ_on) {
-          if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> UB; sl_ub = h0b >> UB; }
-          else summ.template set<2>(scratch + 128, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
-        }
-      } else {
-        filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> UB, 1u << (h0a & UM), w0a, pb, h0b >> UB, 1u << (h0b & UM), w0b, st_a, sv_a, st_b, sv_b);
-        // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
-        if (SUMM && summ_on) {
-          if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> UB; sl_ub = h0b >> UB; }
-          else summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> UB, pass0 && !lb, h0b >> UB, pass1, h1a >> UB, h1b >> UB);
-        }
+      filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+      // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
+      if (SUMM && summ_on) {
+        if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> 5; sl_ub = h0b >> 5; }
+        else summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
       }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
-        if (UB == 5u) {
-          if (st_a) bloom[h0a >> 5] = sv_a;
-          if (st_b) bloom[h0b >> 5] = sv_b;
-        } else {                                             // (global_store_short: the other half of the word is not touched)
-          if (st_a) ((uint16_t*)bloom)[h0a >> 4] = (uint16_t)sv_a;
-          if (st_b) ((uint16_t*)bloom)[h0b >> 4] = (uint16_t)sv_b;
-        }
+        if (st_a) bloom[h0a >> 5] = sv_a;
+        if (st_b) bloom[h0b >> 5] = sv_b;
         const uint64_t left = __ballot(pa || pb || pass1);
         if (left) {                                            // rare: lost three claim rounds; or the 65th id of the seed list
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // behind the plain stores (which were computed from the old words)
@@ -881,31 +748,14 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           }
         }
       };
-      if (!BANG_FILTER_STORES_LATE || !EARLY_ROWS || (POOL && pooled)) filter_stores();
+      if (!EARLY_ROWS) filter_stores();
 
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
-      if (POOL && pooled) {
-        const bool pprof = p.d_prof != nullptr;                  // diagnostic (BANG_SEARCH_PROF=1): where the pool's time goes
-        unsigned long long pt0 = 0, pt1 = 0;
-        if (pprof) pt0 = __builtin_amdgcn_s_memrealtime();
-        if (__ballot(me) != 0ull) {                              // uniform: rows of withdrawn chunks
-          if (me) d0 = BANG_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc) : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
-        }
-        if (pprof) pt1 = __builtin_amdgcn_s_memrealtime();
-        // the helpers' chunks (a claimed chunk is always finished: helpers leave only when no wave of the workgroup owns a query any more)
-        while (uni(__hip_atomic_load(&my_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < claimed) __builtin_amdgcn_s_sleep(1);
-        if (pprof) {
-          const unsigned long long pt2 = __builtin_amdgcn_s_memrealtime();
-          pl_self += pt1 - pt0; pl_wait += pt2 - pt1; ++pl_jobs; pl_selfchunks += nchunks - claimed;
-        }
-        wave_sync();
-        if ((uint32_t)lane < n && !me) d0 = ((const float*)(scratch + 64))[src];
-        wave_sync();
-      } else {
+      {
         if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
         if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
-        if (BANG_FILTER_STORES_LATE && EARLY_ROWS) {
+        if (EARLY_ROWS) {
           // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
           // for them): now the filter stores -- their acknowledgements are not waited for until the next row is needed
           if (!COOP) {
@@ -916,8 +766,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         }
         if ((uint32_t)lane < n) {
           if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
-          d0 = (BANG_REDUCE_PIPE && !HOST) ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
-                                           : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
+          d0 = !HOST ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
+                     : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
         }
         if (n > 64) {                                          // survivor 64 (seed list only), lane 0
           if (lane == 0) {
@@ -1043,7 +893,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
           if (p.d_qiters) p.d_qiters[q] = iter;
           if (p.d_qskip) p.d_qskip[q] = probes_skipped;
-          if (p.d_pool_jobs) p.d_pool_jobs[q] = pool_jobs;
         }
         active = false;
       } else {
@@ -1066,66 +915,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     }
     PF_STAMP(pf_back);
   }
-  if (POOL) {
-    if (pool_on) {
-      // ---------------- no query left for this wave: it serves the distance stage of the queries its workgroup still runs (K2 pool)
-      if (lane == 0) {
-        (void)__hip_atomic_fetch_sub(&pool_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)__hip_atomic_fetch_add(&pool_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      constexpr int LPR = BANG_POOL_LPR;
-      const uint32_t j = (uint32_t)lane & (uint32_t)(LPR - 1), rsub = (uint32_t)lane / (uint32_t)LPR;
-      const bool hprof = p.d_prof != nullptr;
-      unsigned long long ht_busy = 0, ht_chunks = 0, ht_qq = 0, ht_start = hprof ? __builtin_amdgcn_s_memrealtime() : 0ull, ht_c0 = 0;
-      for (;;) {
-        const uint32_t stw = ((uint32_t)lane < nwaves) ? __hip_atomic_load(&pool_ctl[4 + 4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-        const uint64_t mk = __ballot((stw & 0xffu) * (uint32_t)POOL_RPC < ((stw >> 8) & 0xffu));        // waves with unclaimed chunks
-        if (mk == 0ull) {
-          if (uni(__hip_atomic_load(&pool_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break;   // nobody owns a query any more
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        // the nearest posting wave at or behind this wave's own slot (spreads the helpers over the jobs)
-        const uint64_t rot = wave ? ((mk >> wave) | (mk << (64u - wave))) : mk;
-        const uint32_t sl = ((uint32_t)__builtin_ctzll(rot) + wave) & 63u;
-        uint32_t* ctl = pool_ctl + 4 + 4 * sl;
-        uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = uni(old);
-        const uint32_t cidx = old & 0xffu, nrows = (old >> 8) & 0xffu;
-        if (cidx * (uint32_t)POOL_RPC >= nrows) continue;                   // another wave was faster
-        if (lane == 0) (void)__hip_atomic_fetch_sub(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (hprof) ht_c0 = __builtin_amdgcn_s_memrealtime();
-        const uint32_t* jids = (const uint32_t*)(lds + a.lds_piv_floats) + (size_t)sl * a.wave_words + (size_t)nctx * a.wl_words;   // that wave's scratch: ids [64], distances [64]
-        float* jdist = (float*)(jids + 64);
-        const uint32_t qs = uni(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        const uint32_t rr = cidx * (uint32_t)POOL_RPC + rsub;
-        const bool valid = rr < nrows;
-        const uint32_t id = jids[valid ? rr : cidx * (uint32_t)POOL_RPC];   // (a lane group without a row re-reads the chunk's first: every lane executes the reduce)
-        PqRow<NDW, ALIGNED> hrow;
-        pq_row_load(hrow, p.d_codes, code_stride, id);                      // the LPR lanes of a group ask for the same 16-byte pieces: one request per line
-        // the served query, centred, in this lane's chunk order: fetched per chunk (L2 hits that travel with the code rows; kept across
-        // chunks "while the query is the same" the 36 registers become loop-carried and the poll loop above fills with copies of them)
-        TeamQc<PSZ, NDW, LPR> qq;
-        qq.load(p.d_qc + (size_t)qs * QW, j);
-        ++ht_qq;
-        const float d = pq_row_reduce_team<PSZ, NDW, ALIGNED, NHI, LPR>(hrow, piv_lds, qq, j);
-        if (valid && j == 0u) jdist[rr] = d;
-        wave_sync();
-        if (lane == 0) {                                                    // (behind the distances: one wave's LDS operations execute in order)
-          (void)__hip_atomic_fetch_add(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          (void)__hip_atomic_fetch_add(&pool_ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (hprof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ht_busy += __builtin_amdgcn_s_memrealtime() - ht_c0; ++ht_chunks; }
-      }
-      if (hprof && lane == 0) {
-        unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
-        atomicAdd(&o[0], pl_jobs); atomicAdd(&o[1], pl_self); atomicAdd(&o[2], pl_wait); atomicAdd(&o[3], pl_selfchunks);
-        atomicAdd(&o[4], ht_chunks); atomicAdd(&o[5], ht_busy); atomicAdd(&o[6], __builtin_amdgcn_s_memrealtime() - ht_start); atomicAdd(&o[7], ht_qq);
-      }
-    }
-  }
   if (prof && lane == 0) {
     unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16;
     o[0] = pf_poll; o[1] = pf_front; o[2] = pf_pub; o[3] = pf_back; o[4] = pf_n;
@@ -1142,208 +931,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   if (p.d_ktime) {
     __syncthreads();
     if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K2 alone, streaming form (compute_neighborDist_par :1201-1241): dist[q][j] for the cnt[q] <= 64 neighbours of every query
-// ---------------------------------------------------------------------------------------------------------------------
-// The stage the BASELINE metric quotes an HBM figure for.  One wave per query row at a time, the NEXT row's ids and code rows in
-// flight while the current one is reduced (two register sets, ping-pong), pivot table in LDS, centred query through scalar loads:
-// the launch is bound by how fast the memory system returns random 32-74-byte rows, not by dependent round trips.
-// runs f(integral_constant<0>), f(integral_constant<1>), ... until one returns false
-template <class F, int... I>
-__device__ __forceinline__ bool pipe_trip(F& f, std::integer_sequence<int, I...>) {
-  return (f(std::integral_constant<int, I>{}) && ...);
-}
-
-// Experiment (-DBANG_K2_QC_ROW16=1): the query replicated per 16-lane row and subtracted with a DPP row broadcast (QcRow16,
-// bang_device.h) -- 380 instead of 597 VALU instructions per 64 rows, yet only +1.5 % rows/s (the stage is not VALU-bound), and the
-// DPP instruction is inline asm, outside the compiler's hazard recogniser: not the default.
-#ifndef BANG_K2_QC_ROW16
-#define BANG_K2_QC_ROW16 0
-#endif
-#ifndef BANG_K2_COOP
-#define BANG_K2_COOP 1              // code rows fetched cooperatively (CoopFetch, bang_device.h); 0 = one row per lane, NX4 loads each
-#endif
-#ifndef BANG_K2_COOP_MIN_P
-#define BANG_K2_COOP_MIN_P 3        // rows of at least this many 16-byte pieces are fetched cooperatively (two-piece rows, m = 32: measured slower)
-#endif
-#ifndef BANG_K2_M32_MAXT
-#define BANG_K2_M32_MAXT 1024
-#endif
-__host__ __device__ constexpr bool k2_coop(int ndw, bool aligned) { return BANG_K2_COOP && (ndw + (aligned ? 0 : 1) + 3) / 4 >= BANG_K2_COOP_MIN_P; }
-template <int PSZ, int NDW, bool ALIGNED, int NHI, int MAXT>
-__global__ __launch_bounds__(MAXT) void pqdist_stream_kernel(const bang_iter_params p, uint32_t lds_piv_floats) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* piv_lds = lds;
-  constexpr bool COOP = k2_coop(NDW, ALIGNED);
-  const uint32_t stride = p.code_stride ? p.code_stride : p.m;
-  // staging area of this wave's cooperative row fetch, behind the pivot table
-  uint32_t* coop_buf = (uint32_t*)(lds + lds_piv_floats) + (size_t)(threadIdx.x >> 6) * CoopFetch<NDW, ALIGNED>::LDS_WORDS;
-  {
-    const float4* src = (const float4*)p.d_pivots_packed;
-    float4* dst = (float4*)piv_lds;
-    const uint32_t n4 = lds_piv_floats >> 2;
-    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-  }
-  // segments of the row reduce (dependency fence in pq_row_reduce): at most ~32-48 pivot floats in flight per lane
-  constexpr int SB = (NDW >= 18) ? 6 : (BANG_K2_QC_ROW16 && PSZ == 4 && NDW >= 8) ? 2 : (BANG_K2_QC_ROW16 && PSZ == 8 && NDW >= 4) ? 1
-                   : (BANG_K2_QC_ROW16 && PSZ <= 2 && NDW >= 16) ? 4 : 0;
-  const int lane = lane_id();
-  const uint32_t nwaves = blockDim.x >> 6;
-  const uint32_t step = gridDim.x * nwaves;
-  const uint32_t q = blockIdx.x * nwaves + uni(threadIdx.x >> 6);
-  if (q >= p.Q) return;
-  constexpr int QW = NDW * 4 * PSZ;                 // floats of a centred query (padded layout)
-#if BANG_K2_QC_ROW16
-  // the centred query replicated per 16-lane row: "pivot - query" is one v_subrev_f32 with a DPP row broadcast (bang_device.h)
-  constexpr int NV = (QW + 15) / 16;
-  typedef QcRow16<NV> Qc;
-  auto load_qc = [&](Qc& dst, uint32_t qq) {
-    const float* src = p.d_qc + (size_t)qq * QW;
-#pragma unroll
-    for (int r = 0; r < NV; ++r) {
-      const uint32_t i = (uint32_t)r * 16u + ((uint32_t)lane & 15u);
-      dst.v[r] = src[i < (uint32_t)QW ? i : 0u];
-    }
-  };
-#else
-  constexpr int NV = (QW + 63) / 64;
-  typedef QcRegs<NV> Qc;                            // the centred query in registers (v_readlane): no scalar-load waits inside the reduce
-  // n_all != 0: the Q neighbour rows belong to n_all distinct queries (row q -> query q mod n_all), as the rows of successive
-  // iterations of a search do; 0: one query per row
-  const uint32_t qc_rows = p.n_all ? p.n_all : p.Q;
-  auto load_qc = [&](Qc& dst, uint32_t qq) {
-    const float* src = p.d_qc + (size_t)(qq % qc_rows) * QW;
-#pragma unroll
-    for (int r = 0; r < NV; ++r) {
-      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
-      dst.v[r] = src[i < (uint32_t)QW ? i : 0u];
-    }
-  };
-#endif
-  // Software pipeline per wave: while row t is reduced, the code rows of rows t+1 .. t+RD-1 are in flight (requested when their ids
-  // had arrived) and so are the ids, count and centred query of row t+RD -- no step waits for a dependent round trip.  Code-row
-  // buffers rotate by RD, the {ids, count, query} slots by RD + 1; the steps are generated with compile-time slot numbers
-  // (RD (RD + 1) of them per trip of the loop) so that everything stays in registers.
-  // (RD = 3 / 4 with exact waits: m = 32 35.7 -> 34.6 / 28.6 G rows/s, the long-row instances spill and halve -- tools/dev/run_k2rd.sh)
-#ifndef BANG_K2_RD
-#define BANG_K2_RD 2
-#endif
-  constexpr int RD = BANG_K2_RD, SD = RD + 1;
-  PqRow<NDW, ALIGNED> row[COOP ? 1 : RD];
-  CoopFetch<NDW, ALIGNED> raw[COOP ? RD : 1];
-  Qc qc[SD];
-  uint32_t ids[SD], cnt[SD], qq[SD];
-  bool has[SD];
-  uint32_t qnext = q;
-  // Every load of the pipeline is issued unconditionally -- behind the last row of this wave the slots re-read its FIRST row, a lane
-  // without a neighbour reads code row 0 -- so that the compiler's count of outstanding loads is exact and a step waits for the rows
-  // requested one step earlier, not for the ones it has just requested (one load under a branch and every wait becomes vmcnt(0)).
-  auto load_ids = [&](int s) {
-    has[s] = qnext < p.Q;
-    const uint32_t qv = has[s] ? qnext : q;
-    qq[s] = qv;
-    cnt[s] = p.d_cnt[qv];                             // (same address in every lane: no readfirstlane, which would wait for the load here)
-    ids[s] = p.d_nbrs[(size_t)qv * BANG_NBR_STRIDE + lane];
-    load_qc(qc[s], qv);
-    qnext += step;
-  };
-  auto load_rows = [&](int s, int r) {
-    const uint32_t nn = cnt[s] < 64u ? cnt[s] : 64u;
-    if (COOP) raw[r].issue(p.d_codes, stride, ids[s], nn, lane);
-    else pq_row_load(row[r], p.d_codes, stride, (uint32_t)lane < nn ? ids[s] : 0u);
-  };
-#pragma unroll
-  for (int i = 0; i < RD; ++i) load_ids(i);
-#pragma unroll
-  for (int i = 0; i < RD - 1; ++i) load_rows(i, i);
-  auto pipe_step = [&](auto U) -> bool {              // one pipeline step with compile-time slot numbers
-    constexpr int u = decltype(U)::value, s = u % SD, r = u % RD;
-    load_ids((s + RD) % SD);
-    load_rows((s + RD - 1) % SD, (r + RD - 1) % RD);
-    if (!has[s]) return false;                        // (queries are handed out in increasing order: nothing behind this one)
-    // all lanes, full EXEC (v_readlane / DPP read other lanes); the s_nop covers the EXEC -> DPP hazard of a branch just taken
-    asm volatile("s_nop 4");
-    if (COOP) raw[r].collect(row[0], coop_buf, stride, ids[s], lane);
-    const float d = BANG_K2_REDUCE_PIPE ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row[COOP ? 0 : r], piv_lds, qc[s])
-                                        : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row[COOP ? 0 : r], piv_lds, qc[s]);
-    if ((uint32_t)lane < (cnt[s] < 64u ? cnt[s] : 64u)) p.d_dist[(size_t)qq[s] * BANG_NBR_STRIDE + lane] = d;
-    return true;
-  };
-  for (;;)
-    if (!pipe_trip(pipe_step, std::make_integer_sequence<int, RD * SD>{})) return;
-}
-
-template <int PSZ, int NDW, bool ALIGNED, int NHI>
-static int launch_pqdist_inst(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  // long rows: two cooperative fetches in flight + the row being reduced need more than the 128 VGPRs of a 16-wave workgroup
-#ifndef BANG_K2_LONG_MAXT
-#define BANG_K2_LONG_MAXT 768        // 12 waves x 168 VGPRs: rows 128 B apart 30.5 -> 32.3 (m = 70), 30.9 -> 32.9 G rows/s (m = 74) against 8 waves x 256
-#endif
-  constexpr int MAXT = (NDW >= 18 || (NDW >= 16 && PSZ == 2)) ? BANG_K2_LONG_MAXT : (PSZ == 4 && NDW == 8) ? BANG_K2_M32_MAXT : 1024;
-  static bool attr_done[BANG_MAX_DEVICES] = {false};
-  const int dev = current_device();
-  if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    attr_done[dev] = true;
-  }
-  const uint32_t cus = (uint32_t)num_cus();
-  const uint32_t waves = MAXT / WAVE;
-  uint32_t grid = (p.Q + waves - 1) / waves;
-  if (grid > cus) grid = cus;
-  const size_t lds_bytes = (size_t)piv_floats * 4 + (k2_coop(NDW, ALIGNED) ? (size_t)waves * CoopFetch<NDW, ALIGNED>::LDS_WORDS * 4 : 0);
-  if (lds_bytes > 160 * 1024) { bang_set_error("K2 streaming form: pivot table + staging exceed LDS"); return BANG_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((pqdist_stream_kernel<PSZ, NDW, ALIGNED, NHI, MAXT>), dim3(grid), dim3(MAXT), lds_bytes, st, p, piv_floats);
-  HIP_TRY(hipGetLastError());
-  return BANG_OK;
-}
-
-template <int PSZ, int NDW>
-static int launch_pqdist_al(const bang_iter_params& p, uint32_t piv_floats, hipStream_t st) {
-  const bool al = ((p.code_stride ? p.code_stride : p.m) % 4u) == 0;            // rows start dword-aligned
-  if (p.pq_nhi) {
-    constexpr int NHI = (PSZ == 2 && NDW == 18) ? 58 : (PSZ == 2 && NDW == 19) ? 22 : 0;
-    if constexpr (NHI != 0) {
-      if ((int)p.pq_nhi == NHI) return al ? launch_pqdist_inst<PSZ, NDW, true, NHI>(p, piv_floats, st) : launch_pqdist_inst<PSZ, NDW, false, NHI>(p, piv_floats, st);
-    }
-    bang_set_error("no K2 instance for the exact-size pivot table psz=%u mp=%u nhi=%u", p.psz, p.mp, p.pq_nhi);
-    return BANG_ERR_UNSUPPORTED;
-  }
-  return al ? launch_pqdist_inst<PSZ, NDW, true, 0>(p, piv_floats, st) : launch_pqdist_inst<PSZ, NDW, false, 0>(p, piv_floats, st);
-}
-
-extern "C" int bang_k_pqdist_stream(const bang_iter_params* p, void* stream) {
-  if (!p) return BANG_ERR_ARG;
-  if (p->Q == 0) return BANG_OK;
-  if (p->psz == 0 || p->mp < p->m || (p->mp & 3u) || p->m == 0) { bang_set_error("K2 streaming form needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
-  if (!p->d_nbrs || !p->d_dist || !p->d_cnt || !p->d_codes || !p->d_pivots_packed || !p->d_qc) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
-  if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
-  const uint32_t pf = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
-  hipStream_t st = (hipStream_t)stream;
-  switch (p->psz * 100u + p->mp / 4u) {
-#ifdef BANG_DEV_ONLY_218
-    case 218: return launch_pqdist_al<2, 18>(*p, pf, st);
-    default: bang_set_error("development build: psz=2 mp=72 only"); return BANG_ERR_UNSUPPORTED;
-  }
-  switch (0u) {
-#endif
-    case 108: return launch_pqdist_al<1, 8>(*p, pf, st);
-    case 116: return launch_pqdist_al<1, 16>(*p, pf, st);
-    case 124: return launch_pqdist_al<1, 24>(*p, pf, st);
-    case 132: return launch_pqdist_al<1, 32>(*p, pf, st);
-    case 208: return launch_pqdist_al<2, 8>(*p, pf, st);
-    case 216: return launch_pqdist_al<2, 16>(*p, pf, st);
-    case 218: return launch_pqdist_al<2, 18>(*p, pf, st);
-    case 219: return launch_pqdist_al<2, 19>(*p, pf, st);
-    case 404: return launch_pqdist_al<4, 4>(*p, pf, st);
-    case 408: return launch_pqdist_al<4, 8>(*p, pf, st);
-    case 802: return launch_pqdist_al<8, 2>(*p, pf, st);
-    case 804: return launch_pqdist_al<8, 4>(*p, pf, st);
-    default: bang_set_error("no K2 instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
   }
 }
 
@@ -1394,7 +981,7 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
 static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t nctx, bool host_paced) {
   const size_t piv_bytes = (size_t)pivot_table_floats(psz, mp, nhi) * 4u;
   const size_t per_wave = (size_t)search_wave_words(L, nctx, (int)(mp / 4u), host_paced) * 4u;
-  const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u) - (search_pool((int)(mp / 4u), host_paced) ? POOL_CTL_WORDS * 4u : 0u);
+  const size_t cap = (size_t)160 * 1024 - (host_paced ? SRCH_WG_SHARED_BYTES : 0u);
   if (piv_bytes + per_wave > cap) return 0;
   const size_t w = (cap - piv_bytes) / per_wave;
   const size_t most = (size_t)search_maxt((int)(mp / 4u), host_paced) / WAVE;      // what the instance is compiled for
@@ -1474,15 +1061,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
-  // K2 pool: every wave slot of a CU is launched whatever the batch size -- the waves beyond the batch are the helpers
-  a.pool = (p->d_graph && p->pool && search_pool((int)(p->mp / 4u), false)) ? 1u : 0u;
-  if (a.pool) {
-    const uint32_t leaders = waves;                      // what bang_search_geometry gave the batch: the waves that own a query from the start
-    waves = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L, 1, false);
-    if (p->max_waves && p->max_waves < waves) waves = p->max_waves;
-    if (p->pool_helpers && leaders + p->pool_helpers < waves) waves = leaders + p->pool_helpers;
-  }
-  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES) + (a.pool ? POOL_CTL_WORDS * 4u : 0u);
+  const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t key = p->psz * 100u + p->mp / 4u;

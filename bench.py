@@ -335,7 +335,7 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
                 "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride", "rows_in_hbm")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
-               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0, pool_jobs=0, pool_self_chunks=0)
+               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0)
     agg.update({kk: 0 for kk in keys_max})
     ids = dists = None
     for _ in range(steps):
@@ -859,8 +859,13 @@ def main():
     # Everything that compiles is built HERE, before anything is profiled or touches the GPU: a child under `rocprofv3 --pmc` must never
     # start make / hipcc / gcc (every hop of such a tree would be an exec from a GPU-initialised process).  The children assert this.
     build_everything(rank, world)
+    # A bench that is ITSELF being profiled (BANG_NO_BUILD is what every profiling script exports; the profiler's preloaded tool library
+    # shows in LD_PRELOAD / ROCP_TOOL_LIBRARIES / ROCPROFILER_*) never starts the nested rocprofv3 passes: that launcher would be an exec from
+    # a process whose GPU the preloaded library has already initialised.
+    profiled = bool(os.environ.get("BANG_NO_BUILD") or os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", "")
+                    or any(k.startswith("ROCPROF") for k in os.environ))
     if (world == 1 and not args.no_legs and not args.no_live_traffic and args.batches == 1 and not os.environ.get("BANG_BENCH_NO_TRAFFIC")
-            and not os.environ.get("BANG_BENCH_FORCE_GATHER")):
+            and not profiled and not os.environ.get("BANG_BENCH_FORCE_GATHER")):
         # (before anything here touches the GPU: the profiled children need the HBM and must have exited by then)
         ctx.live_traffic = live_traffic(args, lambda *a: print(*a, file=sys.stderr, flush=True))
     import torch

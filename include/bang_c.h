@@ -179,9 +179,6 @@ typedef struct {
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
-  uint64_t pool_jobs;         /* search kernel, self-paced form: query-iterations whose distance stage was served by waves without a query of
-                                 their own (the K2 pool: a batch smaller than CUs x waves, the drain of any batch) */
-  uint64_t pool_self_chunks;  /* ... chunks of such jobs (64 / lanes-per-row rows each) that no helper had claimed when the owner was ready for them */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -190,8 +187,9 @@ int bang_get_stats(bang_engine_t* e, bang_stats* out);
 int bang_get_query_counters(bang_engine_t* e, uint32_t* dist_evals, uint32_t* fetched, uint32_t* candidates, uint32_t* iterations);
 
 /* The candidate log of the last bang_query_e (bang_search.cu:1451-1458: the nodes a query expanded, in expansion order, [0] = MEDOID): ids
- * [num_queries][stride] with stride >= L + 50, counts [num_queries].  Analysis hook (which adjacency rows a batch really reads). */
-int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts);
+ * [num_queries][stride] with stride >= L + 50, counts [num_queries]; num_queries = rows the caller's buffers hold, refused when smaller than
+ * the last batch (the rows of that batch are what is copied).  Analysis hook (which adjacency rows a batch really reads). */
+int bang_get_candidate_log(bang_engine_t* e, uint32_t* ids, uint32_t stride, uint32_t* counts, uint32_t num_queries);
 
 /* The reference's own C mirror (bang.h:91-100), uint8 only, one process-global engine. */
 int bang_load_c(char* indexfile_path_prefix);
@@ -357,9 +355,6 @@ typedef struct {
                                           leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the
                                           word was still zero (self-paced form; 0 in the host-paced form) */
-  uint32_t pool;                       /* self-paced form, long code rows: 1 = waves without a query of their own (a batch smaller than CUs x waves; the drain of
-                                          any batch) serve the distance stage of their workgroup's queries -- the K2 pool, csrc/bang_search.hip; 0 = off.  Same results. */
-  uint32_t* d_pool_jobs;               /* [Q] out, or NULL: iterations of the query whose distance stage went to the pool */
   uint32_t n_nodes;                    /* nodes of the index, or 0: an adjacency id >= n_nodes (and not the pad value) is never expanded nor evaluated -- the row
                                           counts as empty and *d_abort is set to 2 (a corrupt row must not become a wild read of the code table) */
   uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
@@ -367,7 +362,6 @@ typedef struct {
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
   uint32_t merge_late;                 /* self-paced form: K3a + K3b of iteration i run behind the issue of iteration i + 1's filter probes (1) instead of behind
                                           the request for the next adjacency row (2); 0 = auto: 1 for launches that fill every wave slot of the chip */
-  uint32_t pool_helpers;               /* cap on the waves launched beyond those that own a query from the start (0 = every wave slot of the CU) */
 } bang_search_params;
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */

@@ -841,6 +841,8 @@ def test_candidate_log_hook(libbang, small_u8):
         ids, _ = e.query(q)
         cand, cnt = e.candidate_log(q.shape[0], 48)
         ctr = e.query_counters(q.shape[0])
+        with pytest.raises(bang_amd.BangError):            # buffers for fewer queries than the batch had: refused, not overrun
+            e.candidate_log(q.shape[0] - 1, 48)
         e.free(); e.unload()
     assert np.array_equal(cnt.astype(np.int64), ctr[:, 1]) and (cand[:, 0] == ix.medoid).all()
     for i in range(q.shape[0]):

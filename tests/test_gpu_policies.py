@@ -1,0 +1,67 @@
+"""Launch policies of the search kernel never change results (bang_search.cu:1533-1715 is the merge whose POSITION in the iteration the
+`merge_late` policy moves; the filter summary only drops requests whose answer is known).
+
+The fixtures' own batches (40-64 queries) are far below a full chip, where both policies resolve to "off": here the batch is LARGE
+(more queries than wave slots, so the launch is full and queries are handed out from the queue) and the policies are forced both ways,
+on the long-row instances (m = 70 / 74: 12 waves, cooperative row fetch) and a short-row one (m = 32: 16 waves, per-lane loads)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_big = {}
+
+
+def _big_batch(request, fixture, Q):
+    """The fixture's index with a batch of Q queries (its own queries first, then random points of the same type) + the oracle's answer."""
+    if fixture not in _big:
+        from oracle import oracle as O
+        ix, q, _, _ = request.getfixturevalue(fixture)
+        rng = np.random.default_rng(99)
+        if q.dtype == np.float32:
+            more = (q[rng.integers(0, q.shape[0], Q - q.shape[0])] + rng.normal(0, 0.05, (Q - q.shape[0], q.shape[1]))).astype(np.float32)
+        else:
+            info = np.iinfo(q.dtype)
+            more = rng.integers(info.min, info.max + 1, (Q - q.shape[0], q.shape[1])).astype(q.dtype)
+        qq = np.ascontiguousarray(np.concatenate([q, more]))
+        ids_o, dists_o, st_o = O.Oracle(ix).search(qq, 10, 64, with_stats=True)
+        _big[fixture] = (ix, qq, ids_o, dists_o, st_o)
+    return _big[fixture]
+
+
+@pytest.mark.parametrize("merge_late,summ_iters,max_wgs", [("1", "-1", "0"), ("2", "3", "0"), ("1", "3", "96"), ("2", "-1", "96"), ("0", "0", "0")])
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
+def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, merge_late, summ_iters, max_wgs):
+    import bang_amd
+    ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: full for every instance
+    monkeypatch.setenv("BANG_MERGE_LATE", merge_late)
+    monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
+    monkeypatch.setenv("BANG_SEARCH_MAX_WGS", max_wgs)
+    with bang_amd.Engine(ix.dtype, graph=graph, search=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 64)
+        e.alloc(qq.shape[0])
+        e.init(qq.shape[0])
+        ids, dists = e.query(qq)
+        st = e.stats()
+        ctr = e.query_counters(qq.shape[0])
+        e.free(); e.unload()
+    assert st["search_kernel"] == 1
+    assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+    assert np.array_equal(ctr, st_o.astype(np.int64))                         # iterations, expansions, evaluations, ids offered: per query
+
+
+def test_soak_slice(libbang):
+    """A 60-second slice of tools/soak_random.py: random index shapes and search parameters, three loop forms, launch policies drawn at random."""
+    sys.path.insert(0, ROOT)
+    from tools import soak_random
+    lines = []
+    done, batches, bad = soak_random.run(n_cases=400, seed=int(os.environ.get("BANG_SOAK_SEED", "20261003")), budget_s=60.0, log=lines.append)
+    assert bad == 0, "\n".join(l for l in lines if "MISMATCH" in l)
+    assert done >= 5 and batches >= 30

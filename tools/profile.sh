@@ -13,6 +13,7 @@ ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
 python3 -c "import __graft_entry__ as g; g.build()" || exit 1     # build BEFORE profiling: no compiler may start under rocprofv3 --pmc
 PY=$(python3 -c "import os,sys; print(os.path.realpath(sys.executable))")
 export BANG_NO_BUILD=1
+export BANG_BENCH_NO_TRAFFIC=1   # a profiled bench must never start its own nested rocprofv3 passes (bench.py: live_traffic())
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "$PY" bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- "$PY" bench.py $ARGS > "$OUT/bench_pmc_fetch.json" 2> "$OUT/bench_pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- "$PY" bench.py $ARGS > "$OUT/bench_pmc_write.json" 2> "$OUT/bench_pmc_write.err"

@@ -2,10 +2,10 @@
 """What one rank's shard of the 10 K-query batch costs on a GPU of its own -- ONE load of the workload, then every batch size and
 engine-option variant measured on the same engine (bench.py's own measure()).
 
-    python tools/shard_sweep.py [--workload sift1b_shape] [--queries 10000,5000,2500,1250] [--variants pool=0 | BANG_SUMM_ITERS=0,BANG_SUMM_ITERS=1 | ...] [--steps 6]
+    python tools/shard_sweep.py [--workload sift1b_shape] [--queries 10000,5000,2500,1250] [--variants BANG_SUMM_ITERS=0,BANG_SUMM_ITERS=1 | rows_hbm=0 | ...] [--steps 6]
                                 [--shape-n N] [--out gpurun_out/shard_sweep.md] [--check]
 
---check: the ids of every variant must equal those of the first variant at the same batch size (results do not depend on the pool).
+--check: the ids of every variant must equal those of the first variant at the same batch size (launch policies never change results).
 Prints a markdown table (and writes it to --out)."""
 import argparse
 import json
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="sift1b_shape")
     ap.add_argument("--queries", default="10000,5000,2500,1250")
-    ap.add_argument("--variants", default="pool=0", help="comma list of option settings; '+' joins several options of one variant (pool=1+rows_hbm=0)")
+    ap.add_argument("--variants", default="default", help="comma list of option settings; '+' joins several options of one variant (BANG_MERGE_LATE=1+rows_hbm=0); 'default' = none")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape-n", type=int, default=0)
@@ -52,7 +52,7 @@ def main():
         my_q = np.ascontiguousarray(wl["queries"][:q])
         ctx.Q_total = q
         for var in a.variants.split(","):
-            for kv in var.split("+"):
+            for kv in ([] if var == "default" else var.split("+")):
                 key, val = kv.split("=")
                 if key.startswith("BANG_"):              # an environment switch (read when used)
                     os.environ[key] = val
@@ -71,7 +71,7 @@ def main():
             eng.free()
             r = res["roofline"] or {}
             rows.append(dict(queries=q, variant=var, qps=res["queries_per_s"], ms=res["ms_per_step"], launch_us=r.get("avg_launch_us"),
-                             qps_incl_init=res["qps_incl_init"], pool_jobs=int(st.get("pool_jobs", 0) // max(1, a.steps)), pool_self_chunks=int(st.get("pool_self_chunks", 0) // max(1, a.steps)),
+                             qps_incl_init=res["qps_incl_init"],
                              iters=int(st["iterations"]), step_ms=res["step_ms"], same_as_first=same))
             print(json.dumps(rows[-1]), flush=True)
     eng.unload(); eng.close()
@@ -80,9 +80,9 @@ def main():
     lines = [f"# {wl['name']}", "",
              f"`tools/shard_sweep.py --workload {a.workload} --queries {a.queries} --variants {a.variants}`: one load, L = {L}, {a.steps} timed steps per cell "
              f"(bang_query wall time; bang_init outside).  speed-up = time of the {qs[0]}-query batch of the same variant / this time.", "",
-             "| queries | variant | QPS | ms per batch | search launch us | speed-up of the batch | pool jobs per batch | ids equal first variant |", "|---|---|---|---|---|---|---|---|"]
+             "| queries | variant | QPS | ms per batch | search launch us | speed-up of the batch | ids equal first variant |", "|---|---|---|---|---|---|---|"]
     for r in rows:
-        lines.append(f"| {r['queries']} | {r['variant']} | {r['qps']:.0f} | {r['ms']:.3f} | {r['launch_us']} | {base[r['variant']] / r['ms']:.2f} x | {r['pool_jobs']} | {r['same_as_first']} |")
+        lines.append(f"| {r['queries']} | {r['variant']} | {r['qps']:.0f} | {r['ms']:.3f} | {r['launch_us']} | {base[r['variant']] / r['ms']:.2f} x | {r['same_as_first']} |")
     txt = "\n".join(lines) + "\n"
     print(txt)
     if a.out:
