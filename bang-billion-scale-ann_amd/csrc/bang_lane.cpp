@@ -137,6 +137,8 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   };
 
   uint32_t pw_stats[2] = {0, 0};
+  const bool fused_rerank = e->search_v2 && e->fuse_rerank != 0 && (dev_graph || e->vec_on_device) &&
+                            bang_search_can_rerank(e->dtype, e->D, dev_graph ? e->entry_len : vb, dim_adjust) != 0;
   if (e->search_v2) {
     // graph resident in HBM: ONE launch of the query-resident search kernel; no host involvement until the re-rank
     LANE_HIP(hipMemsetAsync(ln.d_pcnt, 0, 64, ln.s_main));
@@ -154,6 +156,13 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1; sp.n_nodes = e->N;
     sp.d_qskip = e->d_qskip + ln.q0;
     sp.merge_late = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_MERGE_LATE", 0)));
+    sp.spec_rows = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_SPEC_ROWS", 0)));
+    e->rerank_fused = fused_rerank;
+    if (fused_rerank) {                                                      // K6 + K7 by the wave that finishes the query: no launch behind this one
+      sp.rr_queries = e->d_queries; sp.rr_dtype = (uint32_t)e->dtype; sp.rr_D = e->D; sp.rr_k = (uint32_t)e->k; sp.rr_q0 = ln.q0; sp.rr_Q_total = (uint32_t)Q;
+      sp.rr_vec_base = dev_graph ? e->d_graph : e->d_vecs; sp.rr_vec_stride = dev_graph ? e->entry_len : vb;
+      sp.rr_ids_out = e->d_ids_out; sp.rr_dists_out = e->d_dists_out;
+    }
     { const long si = env_long("BANG_SUMM_ITERS", 0); sp.summ_iters = si < 0 ? 0xFFFFFFFFu : (uint32_t)si; }     // 0 = auto, -1 = always
     sp.d_ktime = ktime_slot(e, ln);
     sp.max_wgs = (uint32_t)std::max(0L, env_long("BANG_SEARCH_MAX_WGS", 0));          // experiment / test knobs
@@ -335,7 +344,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     LANE_HIP(hipEventRecord(ln.ev_fp, ln.s_fp));
     LANE_HIP(hipStreamWaitEvent(ln.s_main, ln.ev_fp, 0));
   }
-  {
+  if (!fused_rerank) {
     if (dev_graph)
       BANG_TRY(bang_k_rerank_range(e->d_graph, e->entry_len, e->d_medoid_vec, e->d_queries, e->dtype, e->d_cand_ids,
                                    nullptr, e->d_cand_cnt, e->cand_stride, ln.q0, ln.nq, (uint32_t)Q, e->D,

@@ -53,6 +53,9 @@ static const OptionDef kOptions[] = {
     {"numa", "BANG_NUMA", &bang_engine::numa_opt, -1, 1, INT, BEFORE_ALLOC, "1 = pin walker threads to the GPU's NUMA node, one physical core each; 0 / -1 = leave them to the scheduler"},
     {"timing", "BANG_TIMING", &bang_engine::timing, 0, 1, INT, BEFORE_ALLOC, "1 = stamp every search / front launch in-kernel (s_memrealtime) for bang_get_stats"},
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
+    {"fuse_rerank", "BANG_FUSE_RERANK", &bang_engine::fuse_rerank, -1, 1, INT, ANY,
+     "self-paced search kernel, 8-bit vectors resident in HBM: 1 / -1 (auto) = the wave that finishes a query re-ranks it on the spot (K6 + K7 inside the search launch), "
+     "0 = a re-rank launch behind the search.  Same results"},
     // ---- may change between queries
     {"use_flag", "BANG_USE_FLAG", &bang_engine::use_flag, 0, 1, FLAG, BEFORE_ALLOC, "0 = wait for the front kernel with runtime calls instead of its in-kernel completion flag (ablation)"},
     {"compact", "BANG_COMPACT", &bang_engine::compact, 0, 1, FLAG, ANY, "launch-per-iteration loop: straggler compaction on / off"},
@@ -78,6 +81,7 @@ static const SwitchDef kSwitches[] = {
     {"BANG_SEARCH_MAX_WAVES", "search kernel: cap on waves per workgroup"},
     {"BANG_FILTER_MEM", "visited filters in 1 = uncached / 2 = fine-grained device memory instead of ordinary device memory (experiment, read at bang_alloc)"},
     {"BANG_SUMM_ITERS", "search kernel, self-paced form: the filter summary serves a query's first N iterations only (0 = auto: all, off for launches of <= 5 queries per CU; -1 = all)"},
+    {"BANG_SPEC_ROWS", "search kernel, self-paced form, launches without merge_late: 1 = the row of the worklist's first unvisited entry is requested speculatively behind the merge (experiment: measured no faster), 0 / 2 = off"},
     {"BANG_MERGE_LATE", "search kernel, self-paced form: 1 = sort/merge of an iteration behind the next iteration's probe issue, 2 = behind the row request, 0 = auto (1 for launches that fill the chip)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},

@@ -53,6 +53,7 @@ struct SearchArgs {
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
   uint32_t merge_late;       // self-paced form: 1 = K3 of iteration i runs behind the probe issue of iteration i + 1 (full launches)
+  uint32_t spec;             // self-paced form: 1 = the row of the worklist's first unvisited entry is requested speculatively behind the merge
 };
 
 // Code rows are fetched cooperatively (CoopFetch, bang_device.h) from three 16-byte pieces per row on (rows of 12+ code dwords,
@@ -403,6 +404,76 @@ __device__ __forceinline__ WlHead worklist_head(const WaveLds& s, uint32_t w_n, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K6 + K7 by the wave that finished the query (compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368), 8-bit vectors
+// ---------------------------------------------------------------------------------------------------------------------
+// The candidate log of the query (n <= L + 50 expanded nodes, written by this wave) is read back, G = D / 16 adjacent lanes fetch one
+// candidate's vector in one instruction (16 bytes each: one request per line), eight such instructions in flight.  The squared distance
+// is an INTEGER below 2^24 (256 x 255^2), so sum(a - b)^2 = sum a^2 - 2 sum a b + sum b^2 by v_dot4 is exact, and its float image is the
+// value the reference's ascending fmaf chain over float(a - b) produces (every partial sum of that chain is such an integer too:
+// rerank_kernel, bang_kernels.hip).  Distances go to LDS (the query's worklist and scratch are dead); rank = #{(distance bits, index)
+// pairs below mine} -- ties keep expansion order (:1330-1363); the first k land in ids_out [Q][k] / dists_out [rank][Q], a short log is
+// padded with UINT64_MAX / BIG_DIST (CANON 8).
+template <bool SIGNED>
+__device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
+  if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+  return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
+}
+template <bool SIGNED>
+__device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n + 4 words */,
+                                             int lane) {
+  constexpr int U = 8;                                            // vector fetches in flight per lane
+  const uint32_t D = p.rr_D, G = D >> 4, per = 64u / G;           // lanes per candidate, candidates per wave instruction
+  const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
+  const uint32_t* cand = p.d_cand_ids + (size_t)q * cand_stride;
+  const size_t qabs = (size_t)p.rr_q0 + q;
+  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.rr_queries + qabs * D + 16u * sub);
+  const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
+  for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
+    uint32_t id[U];
+    u32x4a v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.rr_vec_base + (uint64_t)id[u] * p.rr_vec_stride + 16u * sub);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      int vv = dot4_8<SIGNED>(v[u].x, v[u].x, dot4_8<SIGNED>(v[u].y, v[u].y, dot4_8<SIGNED>(v[u].z, v[u].z, dot4_8<SIGNED>(v[u].w, v[u].w, qq))));
+      const int vq = dot4_8<SIGNED>(v[u].x, qw.x, dot4_8<SIGNED>(v[u].y, qw.y, dot4_8<SIGNED>(v[u].z, qw.z, dot4_8<SIGNED>(v[u].w, qw.w, 0))));
+      vv -= 2 * vq;
+      for (uint32_t off = 1; off < G; off <<= 1) vv += __shfl_xor(vv, (int)off);       // (the G lanes of a candidate are adjacent)
+      if (i < n && sub == 0u) e[i] = __float_as_uint((float)vv);
+    }
+  }
+  if (lane < 4) e[n + (uint32_t)lane] = 0xFFFFFFFFu;              // padding of the last float4: below nobody, equal to nobody
+  wave_sync();
+  for (uint32_t i = (uint32_t)lane; i < ((n + 63u) & ~63u); i += WAVE) {
+    const uint32_t mine = e[i < n ? i : 0u];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < n; j += 4) {
+      const uint4 o = *(const uint4*)(e + j);
+      r += (o.x < mine || (o.x == mine && j + 0u < i)) ? 1u : 0u;
+      r += (o.y < mine || (o.y == mine && j + 1u < i)) ? 1u : 0u;
+      r += (o.z < mine || (o.z == mine && j + 2u < i)) ? 1u : 0u;
+      r += (o.w < mine || (o.w == mine && j + 3u < i)) ? 1u : 0u;
+    }
+    if (i < n && r < p.rr_k) {
+      p.rr_ids_out[qabs * p.rr_k + r] = (uint64_t)ld_bypass_l1(cand + i);             // [Q][k] u64 :1366
+      p.rr_dists_out[(size_t)r * p.rr_Q_total + qabs] = __uint_as_float(mine);        // [rank][Q] :999,1297
+    }
+  }
+  for (uint32_t r = n + (uint32_t)lane; r < p.rr_k; r += WAVE) {                      // CANON 8
+    p.rr_ids_out[qabs * p.rr_k + r] = ~0ull;
+    p.rr_dists_out[(size_t)r * p.rr_Q_total + qabs] = BIG_DIST;
+  }
+  wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------------------
 // Barrier among the `n` waves of a pacing group (a subset of the workgroup, so s_barrier cannot be used): arrival counter +
@@ -542,6 +613,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   FilterSummary<6> summ;
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
+  // speculative row request (self-paced form, a.spec): the row of the worklist's first unvisited entry as of the last merge -- the parent K4
+  // picks next unless a new neighbour is closer -- is requested right behind that merge and waits here
+  uint32_t spec_id = 0xFFFFFFFFu, spec_x0 = 0, spec_cnt = 0;
+  uint32_t spec_stat = 0;                          // diagnostic counter (d_qspec): speculative requests | those K4 then picked << 16
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -631,6 +706,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         evals = 0; fetched = 0; iter = 1;
         mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
+        spec_id = 0xFFFFFFFFu; spec_stat = 0;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
@@ -819,19 +895,36 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     PH(5);     // parent selection
 
     // ---------------- hand the parent over
-    uint32_t n_cnt = 0, n_x0 = 0;
+    // Where a node's adjacency ids start (graph-entry layout: the word in front of them is the degree).  ok = false: a harmless device line (the
+    // seed list) -- the speculative request below is issued UNCONDITIONALLY, so that the compiler's count of outstanding loads stays exact
+    // and the wait for the parent's row (older) never becomes a wait for the speculative row (younger).
+    auto row_ptr = [&](uint32_t id, bool ok) -> const uint32_t* {
+      if (!ok) return p.d_seed + 1;
+      if (p.row_layout) return (id < p.n_rows_hbm ? p.d_rows_hbm : (const uint32_t*)p.d_graph) + (uint64_t)id * 64u;
+      return (const uint32_t*)(p.d_graph + (uint64_t)id * p.entry_len + p.vec_bytes) + 1;
+    };
+    const bool spec_on = !HOST && a.spec != 0u;                                        // (uniform over the launch)
+    // the row requested speculatively an iteration ago is waited for HERE, once per iteration, where the wait is free -- it is older than the
+    // code rows the distance stage has just consumed, and loads return in order -- so that no load is in flight across more than one iteration
+    // (left pending on the paths that do not use it, the compiler's wait-count analysis flushes every load in the merge instead)
+    if (spec_on) asm volatile("" : "+v"(spec_x0), "+v"(spec_cnt));
+    const bool spec_hit = spec_on && want_row && parent == spec_id;                    // (uniform) that row is here, or on its way
     if (!HOST) {
-      // graph resident in HBM: the next adjacency row is requested NOW; it travels while the survivors are merged
-      if (want_row) {
+      // graph resident in HBM: the next adjacency row is requested NOW, straight into the registers the next iteration reads (no copy at the
+      // loop's end that would wait for it); it travels while the survivors are merged
+      if (spec_hit) {
+        x0 = spec_x0; cnt_in = p.row_layout ? 64u : spec_cnt;
+        spec_stat += 0x10000u;
+      } else if (want_row) {
         if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
           // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those
-          if (parent < p.n_rows_hbm) n_x0 = p.d_rows_hbm[(uint64_t)parent * 64u + lane];
-          else n_x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
-          n_cnt = 64u;                                       // counted when the row is consumed
+          if (parent < p.n_rows_hbm) x0 = p.d_rows_hbm[(uint64_t)parent * 64u + lane];
+          else x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
+          cnt_in = 64u;                                      // counted when the row is consumed
         } else {
           const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
-          n_cnt = nrow[0];
-          n_x0 = nrow[1 + lane];                             // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
+          cnt_in = nrow[0];
+          x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
         }
       }
     } else {
@@ -893,13 +986,30 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
           if (p.d_qiters) p.d_qiters[q] = iter;
           if (p.d_qskip) p.d_qskip[q] = probes_skipped;
+          if (!HOST && p.d_qspec) p.d_qspec[q] = spec_stat;
+          if (!HOST && a.spec != 0u && p.d_qskip) p.d_qskip[q] = spec_stat;      // EXPERIMENT: hit statistics through the skip counter
+        }
+        if (!HOST && p.rr_queries) {                                         // K6 + K7 on the spot (uniform)
+          const uint32_t nc = cc < cand_stride ? cc : cand_stride;
+          if (p.rr_dtype == BANG_I8) wave_rerank8<true>(p, q, nc, cand_stride, wbase, lane);
+          else wave_rerank8<false>(p, q, nc, cand_stride, wbase, lane);
         }
         active = false;
       } else {
         ++iter;
         have_row = found;
-        cnt_in = n_cnt; x0 = n_x0;
         if (!MERGE_LATE || first) head = worklist_head(s, w_n, lane);
+        if (HOST) { cnt_in = 0; x0 = 0; }                                    // (the walker's rows are read at the top of the next round)
+        if (spec_on) {
+          // the first unvisited entry is the next parent unless the coming iteration finds a closer neighbour (compute_parent2 :1425-1446):
+          // its row is requested now, a whole iteration ahead
+          const bool sp_ok = head.found && iter < cap_iter;
+          const uint32_t* sp = row_ptr(head.id, sp_ok);
+          spec_x0 = __builtin_nontemporal_load(sp + lane);
+          spec_cnt = __builtin_nontemporal_load(sp - (p.row_layout ? 0 : 1));  // (row layout: any word of the row -- the degree is counted on arrival)
+          spec_id = sp_ok ? head.id : 0xFFFFFFFFu;
+          spec_stat += sp_ok ? 1u : 0u;
+        }
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
         if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
       }
@@ -988,6 +1098,11 @@ static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t
   return (uint32_t)(w > most ? most : w);
 }
 
+extern "C" int bang_search_can_rerank(int dtype, uint32_t D, uint64_t vec_stride, uint32_t dim_adjust) {
+  const uint32_t G = D >> 4;
+  return (dtype == BANG_U8 || dtype == BANG_I8) && dim_adjust == 0 && D >= 16 && (D & 15u) == 0 && D <= 256 && (G & (G - 1u)) == 0 && (vec_stride & 3u) == 0;
+}
+
 extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
   if (psz == 0 || L == 0 || L > BANG_MAX_L) return 0;
   return (int)waves_that_fit(psz, mp, nhi, L, 1, false);            // (the self-paced form; the host-paced one may hold one wave less)
@@ -1038,6 +1153,13 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   }
   if (p->pq_nhi && (p->psz != 2 || p->pq_nhi > p->mp)) { bang_set_error("bad pq_nhi"); return BANG_ERR_ARG; }
   if (p->cap_iter == 0 || p->cap_iter > p->L + BANG_EXTRA_ITERS - 1) { bang_set_error("bad iteration cap"); return BANG_ERR_ARG; }
+  if (p->rr_queries) {
+    if (!p->d_graph) { bang_set_error("the fused re-rank belongs to the self-paced form"); return BANG_ERR_ARG; }
+    if (!p->rr_vec_base || !p->rr_ids_out || !p->rr_dists_out || p->rr_k == 0 || p->rr_Q_total < p->rr_q0 + p->Q ||
+        !bang_search_can_rerank((int)p->rr_dtype, p->rr_D, p->rr_vec_stride, 0) || (((uintptr_t)p->rr_vec_base) & 3u) || (((uintptr_t)p->rr_queries) & 3u)) {
+      bang_set_error("fused re-rank: bad arguments / unsupported vector layout"); return BANG_ERR_ARG;
+    }
+  }
   SearchArgs a;
   a.p = *p;
   a.lds_piv_floats = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
@@ -1059,6 +1181,8 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
     a.merge_late = (p->merge_late == 1u || (p->merge_late == 0u && (uint64_t)p->Q >= (uint64_t)grid_n * fit)) ? 1u : 0u;     // 0 = auto, 1 = on, 2 = off
   }
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
+  // the speculative row request needs the merge (and with it the worklist's new head) at the END of the iteration: launches without merge_late
+  a.spec = (p->d_graph && !a.merge_late && p->spec_rows == 1u) ? 1u : 0u;        // (0 = auto = off until measured; 2 = off)
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);

@@ -179,6 +179,7 @@ typedef struct {
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
+  uint64_t rerank_fused;      /* 1: K6 + K7 ran inside the search launch (the wave that finished a query re-ranked it), no re-rank launch followed */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
 /* Per-query counters of the last bang_query_e (arrays of num_queries words; any pointer may be NULL): PQ distance evaluations,
@@ -362,7 +363,25 @@ typedef struct {
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
   uint32_t merge_late;                 /* self-paced form: K3a + K3b of iteration i run behind the issue of iteration i + 1's filter probes (1) instead of behind
                                           the request for the next adjacency row (2); 0 = auto: 1 for launches that fill every wave slot of the chip */
+  /* K6 + K7 FUSED into the launch (self-paced form, 8-bit vectors; compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368): the wave
+   * that finishes a query re-ranks its candidate log on the spot -- exact distances to the full-precision vectors at rr_vec_base + id *
+   * rr_vec_stride, stable rank by (distance, expansion order) -- and writes the query's k results; no second launch behind the search, and
+   * the re-rank of all but the last queries runs under the search of the others.  rr_queries == NULL: not fused (bang_k_rerank* follows).
+   * Needs D % 16 == 0, D <= 256, D / 16 a power of two, rr_vec_stride % 4 == 0 (bang_search_can_rerank).  Same bits as bang_k_rerank. */
+  const void* rr_queries;              /* [rr_Q_total][D] raw queries (u8 / i8), row rr_q0 + q belongs to this launch's query q */
+  const uint8_t* rr_vec_base;
+  uint64_t rr_vec_stride;
+  uint64_t* rr_ids_out;                /* [rr_Q_total][k] */
+  float* rr_dists_out;                 /* [k][rr_Q_total] (rank-major, :999) */
+  uint32_t rr_dtype, rr_D, rr_k, rr_q0, rr_Q_total;
+  uint32_t spec_rows;                  /* self-paced form: the adjacency row of the worklist's first unvisited entry is requested SPECULATIVELY right behind the
+                                          merge -- K4 of the next iteration picks that entry whenever no new neighbour is closer (compute_parent2 :1425-1446), and its
+                                          row is then already on its way (or there).  A pure prefetch: same results.  1 = on, 2 = off, 0 = auto: on where the merge
+                                          runs behind the row request (merge_late off: launches that do not fill the chip -- a rank's shard) */
+  uint32_t* d_qspec;                   /* [Q] out, or NULL: speculative row requests of the query | those K4 then picked << 16 */
 } bang_search_params;
+/* 1 if a launch with these vectors can carry the fused re-rank (bang_search_params.rr_*) */
+int bang_search_can_rerank(int dtype, uint32_t D, uint64_t vec_stride, uint32_t dim_adjust);
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */
 int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);

@@ -65,3 +65,51 @@ def test_soak_slice(libbang):
     done, batches, bad = soak_random.run(n_cases=400, seed=int(os.environ.get("BANG_SOAK_SEED", "20261003")), budget_s=60.0, log=lines.append)
     assert bad == 0, "\n".join(l for l in lines if "MISMATCH" in l)
     assert done >= 5 and batches >= 30
+
+
+@pytest.mark.parametrize("L", [10, 152])
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("fixture", ["small_u8", "small_i8"])
+def test_fused_rerank_matches_oracle_and_the_rerank_launch(request, libbang, fixture, graph, L):
+    """K6 + K7 inside the search launch (8-bit vectors, self-paced form: compute_L2Dist bang_search.cu:1254-1299, compute_NearestNeighbours
+    :1312-1368 by the wave that finishes the query) against the oracle and against the separate re-rank launch: ids, distance bits, [rank][Q] layout."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    ids_o, dists_o = O.Oracle(ix).search(q, 10, L)
+    out = {}
+    for fuse in (1, 0):
+        with bang_amd.Engine(ix.dtype, graph=graph, search=1, fuse_rerank=fuse) as e:
+            e.load_index(ix)
+            e.set_searchparams(10, L)
+            e.alloc(q.shape[0])
+            e.init(q.shape[0])
+            out[fuse] = e.query(q)
+            assert e.stats()["rerank_fused"] == fuse
+            e.free(); e.unload()
+    for fuse in (1, 0):
+        assert np.array_equal(out[fuse][0], ids_o) and np.array_equal(out[fuse][1].view(np.uint32), dists_o.view(np.uint32)), fuse
+
+
+def test_fused_rerank_short_logs_many_lanes_and_big_k(libbang, small_u8):
+    """Fewer candidates than k (CANON 8: UINT64_MAX / BIG_DIST tail), k close to L, queries split over lanes (each lane's launch writes its
+    own rows of the [Q][k] / [k][Q] result block), a batch that is handed out from the queue."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    orc = O.Oracle(ix)
+    for (k, L, lanes, max_wgs) in ((30, 33, 1, "0"), (10, 48, 3, "0"), (64, 70, 2, "2"), (5, 5, 1, "1")):
+        ids_o, dists_o = orc.search(q, k, L)
+        os.environ["BANG_SEARCH_MAX_WGS"] = max_wgs
+        try:
+            with bang_amd.Engine(ix.dtype, graph=1, search=1, lanes=lanes) as e:
+                e.load_index(ix)
+                e.set_searchparams(k, L)
+                e.alloc(q.shape[0])
+                e.init(q.shape[0])
+                ids, dists = e.query(q)
+                assert e.stats()["rerank_fused"] == 1
+                e.free(); e.unload()
+        finally:
+            os.environ.pop("BANG_SEARCH_MAX_WGS", None)
+        assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), (k, L, lanes)

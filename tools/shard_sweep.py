@@ -52,10 +52,12 @@ def main():
         my_q = np.ascontiguousarray(wl["queries"][:q])
         ctx.Q_total = q
         for var in a.variants.split(","):
+            env_set = []
             for kv in ([] if var == "default" else var.split("+")):
                 key, val = kv.split("=")
-                if key.startswith("BANG_"):              # an environment switch (read when used)
+                if key.startswith("BANG_"):              # an environment switch (read when used; dropped again behind the variant)
                     os.environ[key] = val
+                    env_set.append(key)
                 else:
                     eng.set_option(key, int(val))
             eng.set_searchparams(ctx.k, L)
@@ -69,10 +71,12 @@ def main():
                 else:
                     ref_ids[q] = (res["ids"].copy(), res["dists"].copy())
             eng.free()
+            for key in env_set:
+                os.environ.pop(key, None)
             r = res["roofline"] or {}
             rows.append(dict(queries=q, variant=var, qps=res["queries_per_s"], ms=res["ms_per_step"], launch_us=r.get("avg_launch_us"),
                              qps_incl_init=res["qps_incl_init"],
-                             iters=int(st["iterations"]), step_ms=res["step_ms"], same_as_first=same))
+                             skip_ctr=int(st.get("filter_loads_skipped", 0)) // max(1, a.steps), iters=int(st["iterations"]), step_ms=res["step_ms"], same_as_first=same))
             print(json.dumps(rows[-1]), flush=True)
     eng.unload(); eng.close()
     wl["release"]()
