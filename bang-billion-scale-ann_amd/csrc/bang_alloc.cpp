@@ -86,7 +86,8 @@ int alloc_buffers(bang_engine* e, int Q) {         // (bang_alloc_e has validate
   e->pq_nhi = 0;
   // graph in HBM: the query-resident search kernel, with whichever pivot table (padded / exact-size) leaves LDS for more waves
   e->search_v2 = false;
-  if ((dev_graph || e->pull) && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
+  const bool walk_rows_want = !dev_graph && e->pull && e->walker_opt == 1;          // rows exist, but the walker team is to serve them
+  if ((dev_graph || (e->pull && !walk_rows_want)) && e->persistent != 0 && e->search_opt != 0 && e->psz != 0) {
     const int w_pad = bang_search_supported(e->psz, e->mp, 0, (uint32_t)e->L);
     const int w_rag = e->pq_nhi_avail ? bang_search_supported(e->psz, e->mp, e->pq_nhi_avail, (uint32_t)e->L) : 0;
     if (std::max(w_pad, w_rag) >= (e->search_opt == 1 ? 1 : 4)) {
@@ -104,9 +105,16 @@ int alloc_buffers(bang_engine* e, int Q) {         // (bang_alloc_e has validate
       e->pq_nhi = (w_rag > w_pad) ? e->pq_nhi_avail : 0;
     }
   }
+  // the walker team of the host-paced kernel reads the pull rows where they exist (vectors are resident then: nothing else of a graph entry
+  // is needed) -- the north-star data flow without a resident graph image
+  e->walker_rows = e->search_host && e->pull && e->h_adj && e->vec_on_device;
+  if (walk_rows_want && !e->walker_rows) {
+    bang_set_error("option walker = 1: the host-paced search kernel is not available here (needs CPU-writable device memory, persistent != 0, search != 0)");
+    return BANG_ERR_UNSUPPORTED;
+  }
   // a walker form on an index whose graph entries only passed through at load time: map the graph file now (a streamed load
   // from an entry source has nothing to map: error)
-  if (!dev_graph && !e->search_v2 && !e->graph) BANG_TRY(map_graph_file(e));
+  if (!dev_graph && !e->search_v2 && !e->walker_rows && !e->graph) BANG_TRY(map_graph_file(e));
   e->fp_direct = false;
   HIP_TRY_ALLOC(hipMalloc(&e->d_queries, nq * e->D * e->tsize + 16));
   if (e->psz) BANG_TRY(dmalloc(&e->d_qc, nq * e->mp * e->psz));

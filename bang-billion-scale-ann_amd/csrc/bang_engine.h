@@ -242,6 +242,8 @@ struct bang_engine {
   // pinned host memory mapped into the GPU's address space.  The self-paced search kernel fetches a parent's row over PCIe by
   // itself (one 256-B read, ~2 us; 57 GB/s of such rows measured) -- no walker thread, no publish / poll round trip.
   int pull_opt = -1;                   // -1 auto, 0 = walker (host-paced kernel), 1 = pull
+  int walker_opt = 0;                  // option "walker": 1 = the C++ walker threads serve the adjacency rows although the kernel could pull them itself
+  bool walker_rows = false;            // the walker team reads the 256-byte pull rows (h_adj) instead of graph entries (resolved at bang_alloc)
   bool pull = false;                   // resolved at load
   uint32_t* h_adj = nullptr;           // [N][64]
   size_t adj_bytes = 0;

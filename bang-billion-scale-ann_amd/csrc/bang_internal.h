@@ -30,6 +30,8 @@ int bang_k_init_state(uint32_t Q, uint32_t medoid, uint32_t cand_stride, uint32_
                       uint32_t* d_cand_cnt, uint32_t* d_wl_cnt, uint32_t* d_mark, uint32_t* d_parents, uint32_t* d_cnt,
                       void* stream);
 
+#define BANG_ADJ_PAD 0xFFFFFFFFu      /* unused slot of a 256-byte adjacency row (bang_search_params.row_layout = 1) */
+
 // bang_init in one launch: clears the visited filters, resets the per-query state (as bang_k_init_state) and the diagnostic counters
 typedef struct {
   uint32_t Q, medoid, cand_stride, n_active;

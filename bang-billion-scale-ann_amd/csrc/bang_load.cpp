@@ -76,7 +76,7 @@ static inline void pull_row_from_entry(const bang_engine* e, uint32_t* row, cons
   memcpy(&deg, adj, 4);
   if (deg > e->R) deg = e->R;
   memcpy(row, adj + 4, (size_t)deg * 4);
-  for (uint32_t k = deg; k < 64; ++k) row[k] = 0xFFFFFFFFu;
+  for (uint32_t k = deg; k < 64; ++k) row[k] = BANG_ADJ_PAD;
 }
 
 // Pull mode: the adjacency lists of the host graph, re-laid as 256-byte rows the GPU can fetch with one PCIe read each.

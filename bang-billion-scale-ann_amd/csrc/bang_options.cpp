@@ -47,6 +47,9 @@ static const OptionDef kOptions[] = {
     {"lanes", "BANG_LANES", &bang_engine::lanes_opt, 0, BANG_MAX_LANES, INT, BEFORE_ALLOC, "launch-per-iteration loop: independent query groups pipelined against each other (0 = auto)"},
     {"threads", "BANG_THREADS", &bang_engine::threads_opt, 0, 4096, INT, BEFORE_ALLOC, "host walker threads per lane (0 = auto from the CPU quota)"},
     {"persistent", "BANG_PERSISTENT", &bang_engine::persistent, -1, 1, INT, BEFORE_ALLOC, "1 = ONE search-kernel launch per batch, 0 = a front + back launch per iteration, -1 = auto"},
+    {"walker", "BANG_WALKER", &bang_engine::walker_opt, 0, 1, INT, BEFORE_ALLOC,
+     "host graph loaded in pull mode: 1 = the C++ walker threads serve the adjacency rows to the host-paced search kernel (the reference's data flow, "
+     "bang_search.cu:771-813) -- reading the same 256-byte pull rows the kernel would pull itself, so no resident graph image is needed; 0 = the kernel pulls (default)"},
     {"search", "BANG_SEARCH", &bang_engine::search_opt, -1, 1, INT, BEFORE_ALLOC, "1 = the query-resident search kernel (bang_k_search), 0 = the per-iteration kernels, -1 = auto"},
     {"stage_zero_copy", "BANG_STAGE_ZC", &bang_engine::stage_zero_copy, -1, 2, INT, BEFORE_ALLOC,
      "walker forms, where staged adjacency rows travel: 0 = H2D copy per iteration, 1 = kernels read mapped pinned memory, 2 = CPU stores through the PCIe BAR, -1 = auto"},
@@ -81,7 +84,6 @@ static const SwitchDef kSwitches[] = {
     {"BANG_SEARCH_MAX_WAVES", "search kernel: cap on waves per workgroup"},
     {"BANG_FILTER_MEM", "visited filters in 1 = uncached / 2 = fine-grained device memory instead of ordinary device memory (experiment, read at bang_alloc)"},
     {"BANG_SUMM_ITERS", "search kernel, self-paced form: the filter summary serves a query's first N iterations only (0 = auto: all, off for launches of <= 5 queries per CU; -1 = all)"},
-    {"BANG_SPEC_ROWS", "search kernel, self-paced form, launches without merge_late: 1 = the row of the worklist's first unvisited entry is requested speculatively behind the merge (experiment: measured no faster), 0 / 2 = off"},
     {"BANG_MERGE_LATE", "search kernel, self-paced form: 1 = sort/merge of an iteration behind the next iteration's probe issue, 2 = behind the row request, 0 = auto (1 for launches that fill the chip)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},

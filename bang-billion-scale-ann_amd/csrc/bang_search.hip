@@ -53,7 +53,6 @@ struct SearchArgs {
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
   uint32_t merge_late;       // self-paced form: 1 = K3 of iteration i runs behind the probe issue of iteration i + 1 (full launches)
-  uint32_t spec;             // self-paced form: 1 = the row of the worklist's first unvisited entry is requested speculatively behind the merge
 };
 
 // Code rows are fetched cooperatively (CoopFetch, bang_device.h) from three 16-byte pieces per row on (rows of 12+ code dwords,
@@ -410,16 +409,16 @@ __device__ __forceinline__ WlHead worklist_head(const WaveLds& s, uint32_t w_n, 
 // candidate's vector in one instruction (16 bytes each: one request per line), eight such instructions in flight.  The squared distance
 // is an INTEGER below 2^24 (256 x 255^2), so sum(a - b)^2 = sum a^2 - 2 sum a b + sum b^2 by v_dot4 is exact, and its float image is the
 // value the reference's ascending fmaf chain over float(a - b) produces (every partial sum of that chain is such an integer too:
-// rerank_kernel, bang_kernels.hip).  Distances go to LDS (the query's worklist and scratch are dead); rank = #{(distance bits, index)
-// pairs below mine} -- ties keep expansion order (:1330-1363); the first k land in ids_out [Q][k] / dists_out [rank][Q], a short log is
-// padded with UINT64_MAX / BIG_DIST (CANON 8).
+// rerank_kernel, bang_kernels.hip).  Distances go to LDS (the query's worklist and scratch are dead); the k smallest {distance bits, index}
+// keys -- ties keep expansion order (:1330-1363) -- land in ids_out [Q][k] / dists_out [rank][Q], a short log is padded with UINT64_MAX /
+// BIG_DIST (CANON 8).
 template <bool SIGNED>
 __device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
   if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
   return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
 }
 template <bool SIGNED>
-__device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n + 4 words */,
+__device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n words */,
                                              int lane) {
   constexpr int U = 8;                                            // vector fetches in flight per lane
   const uint32_t D = p.rr_D, G = D >> 4, per = 64u / G;           // lanes per candidate, candidates per wave instruction
@@ -449,21 +448,32 @@ __device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32
       if (i < n && sub == 0u) e[i] = __float_as_uint((float)vv);
     }
   }
-  if (lane < 4) e[n + (uint32_t)lane] = 0xFFFFFFFFu;              // padding of the last float4: below nobody, equal to nobody
   wave_sync();
-  for (uint32_t i = (uint32_t)lane; i < ((n + 63u) & ~63u); i += WAVE) {
-    const uint32_t mine = e[i < n ? i : 0u];
-    uint32_t r = 0;
-    for (uint32_t j = 0; j < n; j += 4) {
-      const uint4 o = *(const uint4*)(e + j);
-      r += (o.x < mine || (o.x == mine && j + 0u < i)) ? 1u : 0u;
-      r += (o.y < mine || (o.y == mine && j + 1u < i)) ? 1u : 0u;
-      r += (o.z < mine || (o.z == mine && j + 2u < i)) ? 1u : 0u;
-      r += (o.w < mine || (o.w == mine && j + 3u < i)) ? 1u : 0u;
+  // K7: the k smallest {distance bits, index} keys, in order, by repeated wave-wide arg-min -- k rounds of six DPP steps instead of n^2 / 64
+  // compares per lane.  Lane l keeps the minimum over ITS candidates (index = l mod 64); the round's winner is struck out by its owner, which
+  // re-reads its (<= 9) candidates.  Result r of a chunk of 64 waits in lane r until the chunk is written out.
+  uint32_t my_hi = 0xFFFFFFFFu, my_lo = 0xFFFFFFFFu;
+  auto own_min = [&]() {
+    my_hi = 0xFFFFFFFFu; my_lo = 0xFFFFFFFFu;
+    for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {          // ascending index, strict '<': ties keep expansion order (:1330-1363)
+      const uint32_t d = e[i];
+      if (d < my_hi) { my_hi = d; my_lo = i; }
     }
-    if (i < n && r < p.rr_k) {
-      p.rr_ids_out[qabs * p.rr_k + r] = (uint64_t)ld_bypass_l1(cand + i);             // [Q][k] u64 :1366
-      p.rr_dists_out[(size_t)r * p.rr_Q_total + qabs] = __uint_as_float(mine);        // [rank][Q] :999,1297
+  };
+  own_min();
+  const uint32_t kk = p.rr_k < n ? p.rr_k : n;
+  for (uint32_t r0 = 0; r0 < kk; r0 += WAVE) {                     // (uniform)
+    uint32_t res_i = 0, res_d = 0;
+    const uint32_t rn = kk - r0 < WAVE ? kk - r0 : WAVE;
+    for (uint32_t r = 0; r < rn; ++r) {
+      uint32_t hi = my_hi, lo = my_lo;
+      wave_min_key(hi, lo);                                          // (every lane gets the winner)
+      if ((uint32_t)lane == r) { res_i = lo; res_d = hi; }
+      if ((lo & 63u) == (uint32_t)lane) { e[lo] = 0xFFFFFFFFu; own_min(); }
+    }
+    if ((uint32_t)lane < rn) {
+      p.rr_ids_out[qabs * p.rr_k + r0 + lane] = (uint64_t)ld_bypass_l1(cand + res_i);               // [Q][k] u64 :1366
+      p.rr_dists_out[(size_t)(r0 + (uint32_t)lane) * p.rr_Q_total + qabs] = __uint_as_float(res_d);  // [rank][Q] :999,1297
     }
   }
   for (uint32_t r = n + (uint32_t)lane; r < p.rr_k; r += WAVE) {                      // CANON 8
@@ -613,10 +623,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   FilterSummary<6> summ;
   summ.clear();
   uint32_t probes_skipped = 0;                     // diagnostic counter (d_qskip): filter words not loaded thanks to the summary
-  // speculative row request (self-paced form, a.spec): the row of the worklist's first unvisited entry as of the last merge -- the parent K4
-  // picks next unless a new neighbour is closer -- is requested right behind that merge and waits here
-  uint32_t spec_id = 0xFFFFFFFFu, spec_x0 = 0, spec_cnt = 0;
-  uint32_t spec_stat = 0;                          // diagnostic counter (d_qspec): speculative requests | those K4 then picked << 16
   uint32_t started = 0;                            // bit c: context c has taken its first (statically assigned) query
   uint32_t dead_mask = 0;                          // HOST: bit c: context c of this WORKGROUP has no queries left (uniform across the workgroup)
   uint32_t rounds0 = 0, rounds1 = 0;               // HOST: rounds completed by context 0 / 1
@@ -706,7 +712,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         evals = 0; fetched = 0; iter = 1;
         mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
-        spec_id = 0xFFFFFFFFu; spec_stat = 0;
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
@@ -895,27 +900,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     PH(5);     // parent selection
 
     // ---------------- hand the parent over
-    // Where a node's adjacency ids start (graph-entry layout: the word in front of them is the degree).  ok = false: a harmless device line (the
-    // seed list) -- the speculative request below is issued UNCONDITIONALLY, so that the compiler's count of outstanding loads stays exact
-    // and the wait for the parent's row (older) never becomes a wait for the speculative row (younger).
-    auto row_ptr = [&](uint32_t id, bool ok) -> const uint32_t* {
-      if (!ok) return p.d_seed + 1;
-      if (p.row_layout) return (id < p.n_rows_hbm ? p.d_rows_hbm : (const uint32_t*)p.d_graph) + (uint64_t)id * 64u;
-      return (const uint32_t*)(p.d_graph + (uint64_t)id * p.entry_len + p.vec_bytes) + 1;
-    };
-    const bool spec_on = !HOST && a.spec != 0u;                                        // (uniform over the launch)
-    // the row requested speculatively an iteration ago is waited for HERE, once per iteration, where the wait is free -- it is older than the
-    // code rows the distance stage has just consumed, and loads return in order -- so that no load is in flight across more than one iteration
-    // (left pending on the paths that do not use it, the compiler's wait-count analysis flushes every load in the merge instead)
-    if (spec_on) asm volatile("" : "+v"(spec_x0), "+v"(spec_cnt));
-    const bool spec_hit = spec_on && want_row && parent == spec_id;                    // (uniform) that row is here, or on its way
     if (!HOST) {
       // graph resident in HBM: the next adjacency row is requested NOW, straight into the registers the next iteration reads (no copy at the
       // loop's end that would wait for it); it travels while the survivors are merged
-      if (spec_hit) {
-        x0 = spec_x0; cnt_in = p.row_layout ? 64u : spec_cnt;
-        spec_stat += 0x10000u;
-      } else if (want_row) {
+      if (want_row) {
         if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
           // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those
           if (parent < p.n_rows_hbm) x0 = p.d_rows_hbm[(uint64_t)parent * 64u + lane];
@@ -986,8 +974,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
           if (p.d_qiters) p.d_qiters[q] = iter;
           if (p.d_qskip) p.d_qskip[q] = probes_skipped;
-          if (!HOST && p.d_qspec) p.d_qspec[q] = spec_stat;
-          if (!HOST && a.spec != 0u && p.d_qskip) p.d_qskip[q] = spec_stat;      // EXPERIMENT: hit statistics through the skip counter
         }
         if (!HOST && p.rr_queries) {                                         // K6 + K7 on the spot (uniform)
           const uint32_t nc = cc < cand_stride ? cc : cand_stride;
@@ -1000,16 +986,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         have_row = found;
         if (!MERGE_LATE || first) head = worklist_head(s, w_n, lane);
         if (HOST) { cnt_in = 0; x0 = 0; }                                    // (the walker's rows are read at the top of the next round)
-        if (spec_on) {
-          // the first unvisited entry is the next parent unless the coming iteration finds a closer neighbour (compute_parent2 :1425-1446):
-          // its row is requested now, a whole iteration ahead
-          const bool sp_ok = head.found && iter < cap_iter;
-          const uint32_t* sp = row_ptr(head.id, sp_ok);
-          spec_x0 = __builtin_nontemporal_load(sp + lane);
-          spec_cnt = __builtin_nontemporal_load(sp - (p.row_layout ? 0 : 1));  // (row layout: any word of the row -- the degree is counted on arrival)
-          spec_id = sp_ok ? head.id : 0xFFFFFFFFu;
-          spec_stat += sp_ok ? 1u : 0u;
-        }
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
         if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
       }
@@ -1181,8 +1157,6 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
     a.merge_late = (p->merge_late == 1u || (p->merge_late == 0u && (uint64_t)p->Q >= (uint64_t)grid_n * fit)) ? 1u : 0u;     // 0 = auto, 1 = on, 2 = off
   }
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
-  // the speculative row request needs the merge (and with it the worklist's new head) at the END of the iteration: launches without merge_late
-  a.spec = (p->d_graph && !a.merge_late && p->spec_rows == 1u) ? 1u : 0u;        // (0 = auto = off until measured; 2 = off)
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);

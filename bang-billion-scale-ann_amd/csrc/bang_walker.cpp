@@ -162,6 +162,9 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
   const uint64_t elen = e->entry_len;
   const uint8_t* graph = e->graph;
   const bool ship_vec = !e->vec_on_device;
+  // vectors resident and pull rows built: the rows ARE the adjacency lists, 256-byte aligned, 64 ids, pad behind the ids -- nothing else of
+  // a graph entry is needed (option walker = 1; also what lets this form run on a streamed load, which keeps no graph image)
+  const uint32_t* adj_rows = e->walker_rows ? e->h_adj : nullptr;
   uint8_t* fp = ship_vec ? (e->fp_direct ? e->d_fp : e->h_fp) : nullptr;
   const uint32_t R = e->R, cstride = e->cand_stride;
   const uint64_t pf0 = ship_vec ? 0 : (vb & ~(uint64_t)63);  // resident vectors: only the adjacency part of an entry is touched
@@ -189,14 +192,31 @@ void swalk(bang_engine* e, Lane& ln, int t, int T) {
     for (uint32_t i = 0; i < W; ++i) {
       const uint32_t p_ = par[i];
       if (p_ < BANG_IDLE_PARENT) {
-        const uint8_t* ent = graph + (uint64_t)p_ * elen;
-        for (uint64_t o = pf0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+        if (adj_rows) {
+          const uint8_t* row = (const uint8_t*)(adj_rows + (uint64_t)p_ * 64u);
+          for (uint64_t o = 0; o < 256; o += 64) __builtin_prefetch(row + o, 0, 0);
+        } else {
+          const uint8_t* ent = graph + (uint64_t)p_ * elen;
+          for (uint64_t o = pf0; o < elen; o += 64) __builtin_prefetch(ent + o, 0, 0);
+        }
       }
     }
     uint32_t counts[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < W; ++i) {
       const uint32_t p_ = par[i];
       if (p_ >= BANG_IDLE_PARENT) continue;
+      if (adj_rows) {                                                   // (vectors resident: every published parent wants its row)
+        const uint32_t* row = adj_rows + (uint64_t)p_ * 64u;
+        uint32_t deg = R < 64u ? R : 64u;
+        while (deg > 0 && row[deg - 1] == BANG_ADJ_PAD) --deg;          // ids first, ascending, the pad value behind them
+        uint32_t* srow = e->d_srows + ((size_t)w * 16 + i) * 64;
+        const size_t nbytes = std::min<size_t>(((size_t)deg * 4 + 63) & ~(size_t)63, (size_t)R * 4);
+        if (nt_rows) wc_copy_nt(srow, row, nbytes);
+        else memcpy(srow, row, nbytes);
+        counts[i >> 2] |= deg << (8 * (i & 3u));
+        bytes += nbytes;
+        continue;
+      }
       const uint8_t* ent = graph + (uint64_t)p_ * elen;
       bool want_row = true;
       if (ship_vec) {

@@ -179,6 +179,7 @@ typedef struct {
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
+  uint64_t walker_rows;       /* host-paced search kernel: 1 = the walker threads read the 256-byte pull rows (option "walker"), not graph entries */
   uint64_t rerank_fused;      /* 1: K6 + K7 ran inside the search launch (the wave that finished a query re-ranked it), no re-rank launch followed */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
@@ -374,11 +375,6 @@ typedef struct {
   uint64_t* rr_ids_out;                /* [rr_Q_total][k] */
   float* rr_dists_out;                 /* [k][rr_Q_total] (rank-major, :999) */
   uint32_t rr_dtype, rr_D, rr_k, rr_q0, rr_Q_total;
-  uint32_t spec_rows;                  /* self-paced form: the adjacency row of the worklist's first unvisited entry is requested SPECULATIVELY right behind the
-                                          merge -- K4 of the next iteration picks that entry whenever no new neighbour is closer (compute_parent2 :1425-1446), and its
-                                          row is then already on its way (or there).  A pure prefetch: same results.  1 = on, 2 = off, 0 = auto: on where the merge
-                                          runs behind the row request (merge_late off: launches that do not fill the chip -- a rank's shard) */
-  uint32_t* d_qspec;                   /* [Q] out, or NULL: speculative row requests of the query | those K4 then picked << 16 */
 } bang_search_params;
 /* 1 if a launch with these vectors can carry the fused re-rank (bang_search_params.rr_*) */
 int bang_search_can_rerank(int dtype, uint32_t D, uint64_t vec_stride, uint32_t dim_adjust);

@@ -515,6 +515,36 @@ def test_streamed_load_matches_oracle(request, libbang, fixture):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_i8"])
+@pytest.mark.parametrize("threads", [0, 1, 3])
+def test_walker_serves_from_the_pull_rows(request, libbang, fixture, threads):
+    """Option walker = 1: the north-star data flow (C++ walker threads hand the parents' adjacency lists to the host-paced search kernel,
+    bang_search.cu:771-813) on an index loaded in pull mode -- the threads read the 256-byte pull rows, not graph entries, so the form also
+    runs on a STREAMED load, which keeps no graph image at all.  Same bits as the oracle, per query."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = request.getfixturevalue(fixture)
+    Q = q.shape[0]
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 48, with_stats=True)
+    for load in ("memory", "stream"):
+        with bang_amd.Engine(ix.dtype, graph=bang_amd.GRAPH_HOST, walker=1, threads=threads) as e:
+            if load == "stream":
+                e.load_stream(ix, _entry_source(ix))
+            else:
+                e.load_index(ix)
+            e.set_searchparams(10, 48)
+            e.alloc(Q)
+            for _ in range(2):
+                e.init(Q)
+                ids, dists = e.query(q)
+                st = e.stats()
+                assert st["walker_rows"] == 1 and st["search_kernel"] == 1 and st["graph_pull"] == 0 and st["pacing_groups"] > 0, (load, st)
+                assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), load
+                assert np.array_equal(e.query_counters(Q), st_o), load
+            e.free(); e.unload()
+
+
+@pytest.mark.gpu
 def test_streamed_load_needs_the_pull_mode(libbang, small_u8):
     """Without a resident graph nothing but the pull mode can run: a streamed load refuses configurations that exclude it, and a
     walker form asked for afterwards is an error (there is no file to map)."""

@@ -100,7 +100,8 @@ def test_offsets_beyond_4gib_match_oracle(libbang, shape, N):
         assert ix.N * ix.m > 2**32 and ix.N * ix.entry_len > 2**32 and ix.N * (ix.entry_len - 4 - 4 * ix.R) > 2**32
         ids_o, dists_o, st_o = O.Oracle(ix).search(q, k, L, with_stats=True)
         assert ids_o.max() > 2**32 // ix.entry_len                      # results do live beyond the 4 GiB mark
-        for opts in (dict(graph=0, pull=1), dict(graph=0, vectors=1, pull=0), dict(graph=0, vectors=0), dict(graph=0, persistent=0), dict(graph=1)):
+        for opts in (dict(graph=0, pull=1), dict(graph=0, pull=1, walker=1), dict(graph=0, vectors=1, pull=0), dict(graph=0, vectors=0),
+                     dict(graph=0, persistent=0), dict(graph=1)):
             with bang_amd.Engine(ix.dtype, **opts) as e:
                 e.load_index(ix)
                 e.set_searchparams(k, L)
