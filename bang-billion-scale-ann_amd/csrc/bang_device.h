@@ -73,8 +73,34 @@ struct QcRegs {
   }
 };
 
+// QcRow16: the centred query replicated per 16-lane row -- lane l of v[r] holds qc[16 r + (l & 15)] -- so that "pivot - query" is ONE
+// instruction, v_subrev_f32 with a DPP row broadcast of the query operand, instead of v_readlane + v_sub: two of the nine VALU instructions
+// a 2-dim chunk costs (bfe, shift, 2 readlane, 2 sub, mul, fma, add).  ceil(QW / 16) registers per query instead of ceil(QW / 64).
+// A DPP operand is fetched from ANOTHER lane: every lane of the wave must be executing (an inactive source lane yields 0).
+template <int NR>
+struct QcRow16 {
+  float v[NR];
+};
+template <int N>
+__device__ __forceinline__ float sub_row_bcast(float p, float qreg) {     // p - (lane N of qreg's 16-lane row)
+  float d;
+  asm("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(qreg), "v"(p), "n"(N));
+  return d;
+}
 template <class QC>
 __device__ __forceinline__ float qc_sub(const QC& qc, float p, uint32_t i) { return p - qc[i]; }
+template <int NR>
+__device__ __forceinline__ float qc_sub(const QcRow16<NR>& qc, float p, uint32_t i) {
+  const float r = qc.v[i >> 4];
+  switch (i & 15u) {                                   // i is a constant after unrolling: one case survives
+    case 0: return sub_row_bcast<0>(p, r);   case 1: return sub_row_bcast<1>(p, r);   case 2: return sub_row_bcast<2>(p, r);
+    case 3: return sub_row_bcast<3>(p, r);   case 4: return sub_row_bcast<4>(p, r);   case 5: return sub_row_bcast<5>(p, r);
+    case 6: return sub_row_bcast<6>(p, r);   case 7: return sub_row_bcast<7>(p, r);   case 8: return sub_row_bcast<8>(p, r);
+    case 9: return sub_row_bcast<9>(p, r);   case 10: return sub_row_bcast<10>(p, r); case 11: return sub_row_bcast<11>(p, r);
+    case 12: return sub_row_bcast<12>(p, r); case 13: return sub_row_bcast<13>(p, r); case 14: return sub_row_bcast<14>(p, r);
+    default: return sub_row_bcast<15>(p, r);
+  }
+}
 template <int PSZ, int NHI, class QC>
 __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, const QC& qc, uint32_t c, uint32_t code) {
   float t = 0.0f;

@@ -420,7 +420,7 @@ __device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
 template <bool SIGNED>
 __device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n words */,
                                              int lane) {
-  constexpr int U = 8;                                            // vector fetches in flight per lane
+  constexpr int U = 4;                                            // vector fetches in flight per lane
   const uint32_t D = p.rr_D, G = D >> 4, per = 64u / G;           // lanes per candidate, candidates per wave instruction
   const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
   const uint32_t* cand = p.d_cand_ids + (size_t)q * cand_stride;
@@ -606,15 +606,21 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   // the centred query of the current context, in registers (lane l of qc.v[r] = element 64 r + l; read with v_readlane): loaded
   // once per query instead of streamed through scalar loads in every iteration's distance stage
   constexpr int QW = NDW * 4 * PSZ;
-  constexpr int NV = (QW + 63) / 64;
-  QcRegs<NV> qc;
+#ifndef BANG_QC16
+#define BANG_QC16 1
+#endif
+  // the self-paced long-row instances (168 VGPRs) keep the query replicated per 16-lane row: "pivot - query" is then one DPP instruction
+  constexpr bool QC16 = (BANG_QC16 != 0) && !HOST && NDW == 18 && NHI != 0 && ALIGNED;
+  constexpr int NV = QC16 ? (QW + 15) / 16 : (QW + 63) / 64;
+  typedef typename std::conditional<QC16, QcRow16<NV>, QcRegs<NV>>::type Qc;
+  Qc qc;
 #pragma unroll
   for (int r = 0; r < NV; ++r) qc.v[r] = 0.0f;
   auto load_qc = [&](uint32_t qq) {
     const float* src = p.d_qc + (size_t)qq * QW;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
-      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+      const uint32_t i = QC16 ? (uint32_t)r * 16u + ((uint32_t)lane & 15u) : (uint32_t)r * 64u + (uint32_t)lane;
       qc.v[r] = src[i < (uint32_t)QW ? i : 0u];
     }
   };
@@ -845,16 +851,29 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           }
           filter_stores();
         }
-        if ((uint32_t)lane < n) {
-          if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
-          d0 = !HOST ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
-                     : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
-        }
-        if (n > 64) {                                          // survivor 64 (seed list only), lane 0
-          if (lane == 0) {
+        if (QC16) {
+          // every lane executes the reduce (the query operand of its subtractions comes from other lanes by DPP); a lane without a survivor
+          // reduces whatever row the cooperative fetch left it (row 0) and its distance is never looked at
+          const float dd = pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc);
+          if ((uint32_t)lane < n) d0 = dd;
+          if (n > 64) {                                        // survivor 64 (seed list only): every lane reduces that row, lane 0's counts
             PqRow<NDW, ALIGNED> r1;
-            pq_row_load(r1, p.d_codes, code_stride, sid1);
-            d1 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
+            pq_row_load(r1, p.d_codes, code_stride, uni(sid1));
+            const float d1v = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
+            if (lane == 0) d1 = d1v;
+          }
+        } else {
+          if ((uint32_t)lane < n) {
+            if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
+            d0 = !HOST ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
+                       : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
+          }
+          if (n > 64) {                                          // survivor 64 (seed list only), lane 0
+            if (lane == 0) {
+              PqRow<NDW, ALIGNED> r1;
+              pq_row_load(r1, p.d_codes, code_stride, sid1);
+              d1 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
+            }
           }
         }
       }
