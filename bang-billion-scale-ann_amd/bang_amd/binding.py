@@ -55,7 +55,8 @@ class SearchParams(C.Structure):
         ("d_qiters", C.c_void_p), ("d_next_query", C.c_void_p), ("d_ktime", C.c_void_p),
         ("d_rows", C.c_void_p), ("d_ctl", C.c_void_p), ("h_done", C.c_void_p), ("h_parents", C.c_void_p), ("h_pub_q", C.c_void_p),
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
-        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
+        ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p),
+        ("d_row_slices", C.c_void_p), ("n_slices", C.c_uint32), ("slice_rows", C.c_uint32), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
         ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32),
         ("rr_queries", C.c_void_p), ("rr_vec_base", C.c_void_p), ("rr_vec_stride", C.c_uint64), ("rr_ids_out", C.c_void_p), ("rr_dists_out", C.c_void_p),
         ("rr_dtype", C.c_uint32), ("rr_D", C.c_uint32), ("rr_k", C.c_uint32), ("rr_q0", C.c_uint32), ("rr_Q_total", C.c_uint32),
@@ -78,7 +79,7 @@ class Stats(C.Structure):
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
                 ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64),
-                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64), ("walker_rows", C.c_uint64), ("rerank_fused", C.c_uint64)]
+                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64), ("rows_from_peer", C.c_uint64), ("rows_from_own_hbm", C.c_uint64), ("walker_rows", C.c_uint64), ("rerank_fused", C.c_uint64)]
 
 
 ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source
@@ -245,6 +246,26 @@ class Engine:
         h = C.c_uint64()
         _check(lib().bang_get_rows_hash(self._h, C.byref(h)), "bang_get_rows_hash")
         return int(h.value)
+
+    # ---- peer rows (include/bang_c.h): the node's adjacency rows in the node's spare HBM
+    def rows_capacity(self) -> int:
+        n = C.c_uint64()
+        _check(lib().bang_rows_capacity_e(self._h, C.byref(n)), "bang_rows_capacity")
+        return int(n.value)
+
+    def rows_slice(self, first_row: int, rows: int):
+        _check(lib().bang_rows_slice_e(self._h, C.c_uint64(first_row), C.c_uint64(rows)), "bang_rows_slice")
+
+    def rows_export(self):
+        """-> (64-byte IPC handle (all zero: nothing to share), first row, rows)"""
+        h = (C.c_ubyte * 64)()
+        first, rows = C.c_uint64(), C.c_uint64()
+        _check(lib().bang_rows_export_e(self._h, h, C.byref(first), C.byref(rows)), "bang_rows_export")
+        return bytes(h), int(first.value), int(rows.value)
+
+    def rows_import(self, slot: int, n_slots: int, slice_rows: int, handle: bytes | None):
+        buf = (C.c_ubyte * 64).from_buffer_copy(handle) if handle is not None else None
+        _check(lib().bang_rows_import_e(self._h, C.c_uint32(slot), C.c_uint32(n_slots), C.c_uint64(slice_rows), buf), "bang_rows_import")
 
     def set_searchparams(self, recall: int, worklist_length: int, distfn: int = DIST_L2):
         _check(lib().bang_set_searchparams_e(self._h, recall, worklist_length, distfn), "bang_set_searchparams")

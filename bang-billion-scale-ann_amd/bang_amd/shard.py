@@ -70,3 +70,32 @@ class DeviceGather:
             a, b = shard_range(self.Q, r, self.world)
             out[a:b] = allv[r * self.pad: r * self.pad + (b - a)]
         return out
+
+
+def share_rows(eng, rank: int, world: int, n_nodes: int, group=None, slice_rows: int = 0) -> dict:
+    """PEER ROWS (include/bang_c.h): after the load, before bang_alloc.  Every rank of the node keeps one slice of the adjacency rows in the
+    HBM its index left over -- rank r the rows [r n, (r + 1) n), n = the smallest capacity among the ranks (or `slice_rows`) -- exports it
+    (hipIpcGetMemHandle), the 64-byte handles travel through ONE all_gather_object of the job's process group, and every rank maps the W - 1
+    others (hipIpcOpenMemHandle).  The search kernel then reads a parent's row from slice parent / n: its own HBM, a peer's over xGMI, or --
+    beyond W n rows -- pinned host memory over PCIe as before.  Returns {"slice_rows", "rows_in_node_hbm", "fraction"}."""
+    import torch.distributed as dist
+    cap = eng.rows_capacity()
+    caps = [None] * world
+    dist.all_gather_object(caps, int(cap), group=group)
+    n = int(slice_rows) if slice_rows else min(caps)
+    n = min(n, (n_nodes + world - 1) // world)              # (W n >= N: the whole graph sits in the node's HBM; no slice larger than needed)
+    if n <= 0:
+        return {"slice_rows": 0, "rows_in_node_hbm": 0, "fraction": 0.0}
+    first = min(rank * n, n_nodes)
+    eng.rows_slice(first, max(0, min(n, n_nodes - first)))
+    handle, _, rows = eng.rows_export()
+    handles = [None] * world
+    dist.all_gather_object(handles, (handle, rows), group=group)
+    for r in range(world):
+        h, rr = handles[r]
+        if r == rank:
+            eng.rows_import(r, world, n, None)
+        else:
+            eng.rows_import(r, world, n, h if rr else bytes(64))
+    total = min(n_nodes, world * n)
+    return {"slice_rows": n, "rows_in_node_hbm": total, "fraction": total / max(1, n_nodes)}

@@ -163,8 +163,12 @@ extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
   e->Qcur = 0;
   e->cand_stride = (uint32_t)e->L + BANG_EXTRA_ITERS;
   BANG_TRY(validate_pull_rows(e));       // a truncated / overwritten rows file is reported as such -- and never costs the HBM row cache below
+  if (e->n_slices > 1) {                 // peer rows: the slice table (biased base addresses: own HBM, peers' HBM) goes to the device
+    if (!e->d_slice_tab) BANG_TRY(dmalloc(&e->d_slice_tab, (size_t)BANG_MAX_ROW_SLICES));
+    HIP_TRY(hipMemcpy(e->d_slice_tab, e->slice_base, sizeof(e->slice_base), hipMemcpyHostToDevice));
+  }
   int rc = alloc_buffers(e, Q);
-  if (rc == BANG_ERR_NOMEM && e->d_rows_hbm) {
+  if (rc == BANG_ERR_NOMEM && e->d_rows_hbm && !e->rows_exported && e->n_slices == 0) {
     // the copy of the first adjacency rows took the HBM a batch of this size needs: the rows are in host memory anyway
     free_batch(e);
     dfree(e->d_rows_hbm);
@@ -356,14 +360,22 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     s.hops_max = cc.back();
     if (s.graph_pull) {                                  // one row per expansion (the seed list is on the device) ...
       uint64_t pulled = s.candidates - (uint64_t)e->Qcur;
-      if (e->n_rows_hbm) {                               // ... unless the expanded node's row sits in HBM: count the candidate log
+      if (e->n_rows_hbm || e->n_slices > 1) {            // ... unless the expanded node's row sits in HBM (this GPU's or a peer's): count the candidate log
         std::vector<uint32_t> ids((size_t)e->Qcur * e->cand_stride);
         HIP_TRY(hipMemcpy(ids.data(), e->d_cand_ids, ids.size() * 4, hipMemcpyDeviceToHost));
         pulled = 0;
         std::vector<uint32_t> cnt((size_t)e->Qcur);
         HIP_TRY(hipMemcpy(cnt.data(), e->d_cand_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
         for (size_t q = 0; q < (size_t)e->Qcur; ++q)
-          for (uint32_t i = 1; i < cnt[q] && i < e->cand_stride; ++i) pulled += ids[q * e->cand_stride + i] >= e->n_rows_hbm;
+          for (uint32_t i = 1; i < cnt[q] && i < e->cand_stride; ++i) {
+            const uint32_t id = ids[q * e->cand_stride + i];
+            if (e->n_slices > 1) {
+              const uint32_t sl = id / e->slice_rows;
+              if (sl < e->n_slices && e->slice_base[sl]) { if (sl == e->own_slot) ++s.rows_from_own_hbm; else ++s.rows_from_peer; }
+              else ++pulled;
+            } else if (id < e->n_rows_hbm) ++s.rows_from_own_hbm;
+            else ++pulled;
+          }
       }
       s.pulled_bytes = pulled * 256;
     }

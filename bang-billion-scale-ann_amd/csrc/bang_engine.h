@@ -258,8 +258,15 @@ struct bang_engine {
   const uint32_t* d_adj = nullptr;     // device address of h_adj
   int rows_hbm_opt = -1;               // option "rows_hbm": MB of HBM for a copy of the first adjacency rows (-1 = whatever the index leaves beyond
                                        // 12 GB -- where the rows do not all fit --, 0 = none): read from HBM instead of pulled over PCIe
-  uint32_t* d_rows_hbm = nullptr;      // [n_rows_hbm][64]
+  uint32_t* d_rows_hbm = nullptr;      // [n_rows_hbm][64]: the rows [rows_first, rows_first + n_rows_hbm)
   uint32_t n_rows_hbm = 0;
+  uint64_t rows_first = 0;             // first node of the HBM copy (0 unless bang_rows_slice_e moved it: peer rows)
+  bool rows_exported = false;          // an IPC handle of d_rows_hbm is out: never freed before bang_unload
+  // peer rows (bang_rows_import_e): slice s of the node's HBM-resident rows starts at node s * slice_rows
+  uint32_t n_slices = 0, slice_rows = 0, own_slot = 0xFFFFFFFFu;
+  void* peer_ptr[BANG_MAX_ROW_SLICES] = {nullptr};       // hipIpcOpenMemHandle mappings (closed at bang_unload); the own slot stays NULL
+  uint64_t slice_base[BANG_MAX_ROW_SLICES] = {0};        // biased addresses handed to the kernel (0: not available -> host rows)
+  uint64_t* d_slice_tab = nullptr;     // device copy of slice_base
   uint8_t* d_vecs = nullptr;           // [N][vec_bytes]
   bool vecs_owned = true;              // false: d_vecs is the caller's buffer (bang_index_desc.d_vectors), never freed here
   uint8_t* ext_vecs = nullptr;         // set for the duration of a load: the caller's vector buffer, and whether it is filled already

@@ -150,7 +150,8 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_graph = e->d_graph; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
     if (!dev_graph) {                                                        // pull mode
       sp.d_graph = (const uint8_t*)e->d_adj; sp.entry_len = 256; sp.vec_bytes = 0; sp.row_layout = 1;
-      sp.d_rows_hbm = e->d_rows_hbm; sp.n_rows_hbm = e->n_rows_hbm;
+      sp.d_rows_hbm = e->d_rows_hbm; sp.n_rows_hbm = e->rows_first == 0 ? e->n_rows_hbm : 0;      // (a moved slice is only reachable through the table)
+      if (e->n_slices > 1 && e->d_slice_tab) { sp.d_row_slices = e->d_slice_tab; sp.n_slices = e->n_slices; sp.slice_rows = e->slice_rows; }
     }
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1; sp.n_nodes = e->N;

@@ -297,6 +297,90 @@ static int cache_rows_in_hbm(bang_engine* e) {
   return BANG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- peer rows
+// (include/bang_c.h: the node's adjacency rows in the node's spare HBM, read over xGMI)
+static const size_t kRowsKeepBack = (size_t)6 << 30;     // HBM left to the per-batch state, as cache_rows_in_hbm does
+
+}  // namespace bang
+using namespace bang;
+
+extern "C" int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out) {
+  if (!e || !rows_out) return BANG_ERR_ARG;
+  if (!e->loaded || !e->pull || !e->h_adj) { bang_set_error("peer rows: the index is not loaded in pull mode"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t have = (size_t)e->n_rows_hbm * 256;
+  *rows_out = ((free_b > kRowsKeepBack ? free_b - kRowsKeepBack : 0) + have) / 256;
+  return BANG_OK;
+}
+
+extern "C" int bang_rows_slice_e(bang_engine_t* e, uint64_t first_row, uint64_t rows) {
+  if (!e) return BANG_ERR_ARG;
+  if (!e->loaded || !e->pull || !e->h_adj) { bang_set_error("peer rows: the index is not loaded in pull mode"); return BANG_ERR_ARG; }
+  if (e->allocated) { bang_set_error("peer rows: set the slice before bang_alloc"); return BANG_ERR_ARG; }
+  if (e->rows_exported || e->n_slices) { bang_set_error("peer rows: the slice has been exported / the slice table is set: unload first"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  if (first_row > e->N) first_row = e->N;
+  if (rows > e->N - first_row) rows = e->N - first_row;
+  dfree(e->d_rows_hbm);
+  e->n_rows_hbm = 0; e->rows_first = 0;
+  if (rows == 0) return BANG_OK;
+  BANG_TRY(dmalloc(&e->d_rows_hbm, (size_t)rows * 64));
+  const size_t step = (size_t)1 << 30, bytes = (size_t)rows * 256;
+  const uint8_t* src = (const uint8_t*)e->h_adj + (size_t)first_row * 256;
+  for (size_t off = 0; off < bytes; off += step) HIP_TRY(hipMemcpy((uint8_t*)e->d_rows_hbm + off, src + off, std::min(step, bytes - off), hipMemcpyHostToDevice));
+  e->n_rows_hbm = (uint32_t)rows; e->rows_first = first_row;
+  return BANG_OK;
+}
+
+extern "C" int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* first_row, uint64_t* rows) {
+  if (!e || !handle64 || !first_row || !rows) return BANG_ERR_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+  memset(handle64, 0, 64);
+  *first_row = e->rows_first; *rows = e->n_rows_hbm;
+  if (!e->d_rows_hbm || e->n_rows_hbm == 0) return BANG_OK;             // nothing to share: the peers read these rows from the host
+  BANG_TRY(ensure_device(e));
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, e->d_rows_hbm));
+  memcpy(handle64, &h, 64);
+  e->rows_exported = true;
+  return BANG_OK;
+}
+
+extern "C" int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, const void* handle64) {
+  if (!e) return BANG_ERR_ARG;
+  if (!e->loaded || !e->pull) { bang_set_error("peer rows: the index is not loaded in pull mode"); return BANG_ERR_ARG; }
+  if (e->allocated) { bang_set_error("peer rows: import before bang_alloc"); return BANG_ERR_ARG; }
+  if (n_slots == 0 || n_slots > BANG_MAX_ROW_SLICES || slot >= n_slots || slice_rows == 0 || slice_rows > 0xFFFFFFFFull) { bang_set_error("peer rows: bad slot / slice size"); return BANG_ERR_ARG; }
+  if (e->n_slices && (e->n_slices != n_slots || e->slice_rows != (uint32_t)slice_rows)) { bang_set_error("peer rows: every slot of one table has the same geometry"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  const uint64_t first = (uint64_t)slot * slice_rows;
+  uint64_t base = 0;
+  if (!handle64) {                                                         // this engine's own slice
+    if (e->d_rows_hbm && e->rows_first == first && e->n_rows_hbm >= std::min<uint64_t>(slice_rows, e->N > first ? e->N - first : 0)) base = (uint64_t)(uintptr_t)e->d_rows_hbm;
+    else if (e->d_rows_hbm) { bang_set_error("peer rows: slot %u is not the slice this engine holds (rows [%llu, +%u))", slot, (unsigned long long)e->rows_first, e->n_rows_hbm); return BANG_ERR_ARG; }
+    e->own_slot = slot;
+  } else {
+    bool any = false;
+    for (int i = 0; i < 64; ++i) any |= ((const uint8_t*)handle64)[i] != 0;
+    if (any) {                                                             // (an all-zero handle: that rank holds no rows -- host rows serve the slot)
+      hipIpcMemHandle_t h;
+      memcpy(&h, handle64, 64);
+      void* ptr = nullptr;
+      HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+      if (e->peer_ptr[slot]) (void)hipIpcCloseMemHandle(e->peer_ptr[slot]);
+      e->peer_ptr[slot] = ptr;
+      base = (uint64_t)(uintptr_t)ptr;
+    }
+  }
+  e->n_slices = n_slots; e->slice_rows = (uint32_t)slice_rows;
+  e->slice_base[slot] = base ? base - first * 256ull : 0;                  // biased: + p * 256 is node p's row
+  return BANG_OK;
+}
+
+namespace bang {
+
 // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501), from the medoid's graph entry
 static int stage_medoid(bang_engine* e, const uint8_t* me) {
   uint32_t deg;
@@ -841,8 +925,14 @@ void unload_index(bang_engine* e) {
   if (e->vecs_owned) dfree(e->d_vecs);
   e->d_vecs = nullptr; e->vecs_owned = true; e->ext_vecs = nullptr; e->ext_vecs_ready = false; e->rows_hash = 0;
   e->vec_on_device = false;
+  for (uint32_t s = 0; s < BANG_MAX_ROW_SLICES; ++s) {
+    if (e->peer_ptr[s]) (void)hipIpcCloseMemHandle(e->peer_ptr[s]);
+    e->peer_ptr[s] = nullptr; e->slice_base[s] = 0;
+  }
+  dfree(e->d_slice_tab);
+  e->n_slices = 0; e->slice_rows = 0; e->own_slot = 0xFFFFFFFFu;
   dfree(e->d_rows_hbm);
-  e->n_rows_hbm = 0;
+  e->n_rows_hbm = 0; e->rows_first = 0; e->rows_exported = false;
   if (e->h_adj) { (void)hipHostUnregister(e->h_adj); (void)munmap(e->h_adj, e->adj_bytes); }
   e->h_adj = nullptr; e->d_adj = nullptr; e->adj_bytes = 0; e->pull = false;
   e->rows_path.clear();

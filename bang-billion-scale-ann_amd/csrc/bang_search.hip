@@ -924,8 +924,15 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // loop's end that would wait for it); it travels while the survivors are merged
       if (want_row) {
         if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
-          // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those
-          if (parent < p.n_rows_hbm) x0 = p.d_rows_hbm[(uint64_t)parent * 64u + lane];
+          // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those.  Peer rows
+          // (n_slices > 1): slice parent / slice_rows of the node's HBM-resident rows -- this GPU's HBM or a peer's over xGMI; the table
+          // holds biased base addresses (0: that slice is not there), read through the scalar cache
+          const uint32_t* hb = nullptr;
+          if (p.n_slices > 1u) {
+            const uint32_t sl = parent / p.slice_rows;                       // (uniform: scalar)
+            if (sl < p.n_slices) hb = (const uint32_t*)(uintptr_t)p.d_row_slices[sl];
+          } else if (parent < p.n_rows_hbm) hb = p.d_rows_hbm;
+          if (hb) x0 = hb[(uint64_t)parent * 64u + lane];
           else x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
           cnt_in = 64u;                                      // counted when the row is consumed
         } else {

@@ -186,6 +186,11 @@ def main():
     m_primary, D_primary, dtype_primary = ix.m, ix.D, ix.dtype
     stride_primary = int(agg["code_stride"]) or ix.m           # the code-row layout the engine searched (K2 alone is measured on the same)
     out, cfg = None, {}
+    world_seen = None
+    if world > 1 or ctx.force_gather:                        # proof of the rank count in the record: an all-reduce of ones over the job's backend (every rank)
+        ones = torch.ones(1, dtype=torch.int64, device=ctx.cdev)
+        dist.all_reduce(ones)
+        world_seen = int(ones.item())
     if rank == 0:
         recall = prim["recall"]
         # the first ~30 keys are what the driver's record keeps: first the number the metric's WORDING describes -- recall-gated, on a structured
@@ -205,6 +210,8 @@ def main():
                "sift300m_hops_p50": None, "sift1m_qps": None, "sift1m_recall": None, "sift1m_parity_ok": None,
                "deep100m_shape_qps": None, "deep100m_shape_frac": None,
                "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "legs_skipped": None,
+               "peer_rows": getattr(ctx, "peer_rows", None),
+               "rows_from_peer_hbm_per_step": int(agg["rows_from_peer"] // args.steps), "rows_from_own_hbm_per_step": int(agg["rows_from_own_hbm"] // args.steps),
                "graph_placement": prim["placement_note"] or f"{graph} (requested)",
                "lanes": agg["lanes"], "walker_threads": agg["walker_threads"],
                "search_kernel_workgroups": agg["workgroups"], "queries_per_workgroup": agg["wg_queries"],
@@ -224,10 +231,7 @@ def main():
                "gathered_ids_equal_oracle_whole_batch": prim["gathered_ok"],
                "search_ms_per_step_max_over_ranks": res.get("search_ms"), "gather_ms_per_step_max_over_ranks": res.get("gather_ms"),
                "step_ms_min": min(res["step_ms"]), "step_ms_max": max(res["step_ms"]), "step_ms": res["step_ms"]}
-        if world > 1 or ctx.force_gather:                    # proof of the rank count in the record: an all-reduce of ones over RCCL
-            ones = torch.ones(1, dtype=torch.int64, device=ctx.cdev)
-            dist.all_reduce(ones)
-            cfg["rccl_world_seen"] = int(ones.item())
+        cfg["rccl_world_seen"] = world_seen
         shape_only = not prim["structured"]
         metric = ("queries/sec, 10K-query batch" + (f"; headline = SHAPE-ONLY index at L = {L}, cap-bound ({agg['iterations']} iterations per query: heavier per "
                   "query than real data at recall 0.9); the recall-gated figure (structured index, 10-recall@10 >= 0.9) is config.recall_gated_*" if shape_only

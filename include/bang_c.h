@@ -126,6 +126,20 @@ int bang_load_stream_e(bang_engine_t* e, const bang_index_desc* desc, bang_entry
 int bang_load_shared_e(bang_engine_t* e, const bang_index_desc* desc);
 int bang_get_rows_hash(bang_engine_t* e, uint64_t* out);
 
+/* PEER ROWS: the adjacency rows of a multi-GPU node in the NODE's spare HBM, read over xGMI, host DRAM only for the remainder.
+ * After bang_load* in pull mode every GPU has HBM left (SIFT1B: ~46 GB = 178 M rows of 256 B): rank r of W keeps the rows
+ * [r * n, (r + 1) * n) there (bang_rows_slice_e), exports that allocation (bang_rows_export_e: a 64-byte hipIpcMemHandle), and every rank
+ * imports the W - 1 others (bang_rows_import_e).  The search kernel then reads the row of parent p from slice p / n -- its own HBM, a
+ * peer's HBM through the IPC mapping, or, for p >= W * n, pinned host memory over PCIe as before.  W x 18 % of SIFT1B's rows: 72 % at
+ * W = 4, all of them at W = 8.  Call order: load -> slice -> export / (exchange handles) / import -> bang_alloc.  Results never change.
+ * bang_rows_slice_e replaces the default copy (rows [0, auto)); rows = 0 drops it.  A slice that has been exported is never freed before
+ * bang_unload (bang_alloc does not take it back when HBM is short: BANG_ERR_NOMEM instead). */
+#define BANG_MAX_ROW_SLICES 16
+int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out);   /* rows of 256 B this engine's free HBM holds now (6 GB kept back for the batch state) + what its row copy holds */
+int bang_rows_slice_e(bang_engine_t* e, uint64_t first_row, uint64_t rows);
+int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* first_row, uint64_t* rows);
+int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, const void* handle64 /* NULL: this engine's own slice */);
+
 int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn); /* bang.h:60 */
 int bang_alloc_e(bang_engine_t* e, int num_queries);                                        /* bang.h:53 */
 int bang_init_e(bang_engine_t* e, int num_queries);                                         /* bang.h:56 */
@@ -179,6 +193,8 @@ typedef struct {
   uint64_t code_stride;       /* bytes between PQ code rows in HBM (m = packed; 128 = rows padded to their own 128-byte line) */
   uint64_t filter_loads_skipped; /* search kernel, self-paced form: visited-filter word loads NOT issued because the wave's on-chip
                                  summary knew the word was still zero (of 2 x `fetched` probes) */
+  uint64_t rows_from_peer;    /* pull mode with peer rows: expansions of the last batch whose adjacency row came from ANOTHER GPU's HBM (over xGMI) */
+  uint64_t rows_from_own_hbm; /* ... from this GPU's own HBM copy / slice */
   uint64_t walker_rows;       /* host-paced search kernel: 1 = the walker threads read the 256-byte pull rows (option "walker"), not graph entries */
   uint64_t rerank_fused;      /* 1: K6 + K7 ran inside the search launch (the wave that finished a query re-ranked it), no re-rank launch followed */
 } bang_stats;
@@ -353,6 +369,11 @@ typedef struct {
   uint32_t code_stride;                /* bytes between code rows in d_codes; 0 = m (see bang_iter_params) */
   uint32_t n_rows_hbm;                 /* row_layout = 1: the adjacency rows of the nodes [0, n_rows_hbm) are ALSO in device memory at d_rows_hbm */
   const uint32_t* d_rows_hbm;          /* [n_rows_hbm][64] u32, or NULL */
+  /* row_layout = 1, n_slices > 1 (peer rows): node p's row is read from d_row_slices[p / slice_rows] + p * 256 when p / slice_rows <
+   * n_slices and that entry is not 0 (the entries are BIASED device addresses: slice s's first row is node s * slice_rows), else from
+   * d_graph.  n_rows_hbm / d_rows_hbm are ignored then. */
+  const uint64_t* d_row_slices;        /* [n_slices] device array of biased base addresses (this GPU's HBM or a peer's, hipIpcOpenMemHandle), or NULL */
+  uint32_t n_slices, slice_rows;
   unsigned long long go_timeout_ticks; /* host-paced form: a pacing group that has waited this many 100 MHz ticks for its rows sets *d_abort and
                                           leaves (the host is gone); 0 = 30 s */
   uint32_t* d_qskip;                   /* [Q] out, or NULL: filter-word loads the query did NOT issue because its on-chip summary knew the

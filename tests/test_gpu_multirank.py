@@ -130,3 +130,29 @@ def test_rccl_all_gather_from_device_buffers_single_rank(libbang):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["result_properties_ok"] is True and d["config"]["gather_ms_per_step_max_over_ranks"] > 0
+
+
+def test_two_ranks_peer_rows_over_ipc(libbang):
+    """PEER ROWS (include/bang_c.h, bang_amd/shard.py share_rows): two ranks -- two processes on GPU 0 -- each keep one slice of the adjacency
+    rows in HBM, export it with hipIpcGetMemHandle and map the sibling's allocation with hipIpcOpenMemHandle; the search kernel reads a
+    parent's row from its own slice, from the SIBLING's allocation, or (beyond the two slices) from the shared rows file in host memory.  The
+    gathered [Q][k] block equals the oracle's answer for the whole batch, rows did come from the peer, and some still came over PCIe."""
+    args = ["--shape-n", "3000000", "--queries", "512", "--host-codes"]
+    env_old = os.environ.get("BANG_BENCH_PEER_SLICE_ROWS")
+    os.environ["BANG_BENCH_PEER_SLICE_ROWS"] = "1000000"        # 2 x 1e6 of 3e6 rows in "the node's HBM", the last third on the host
+    try:
+        two = _bench(2, args, workload="sift1b_shape", L=40)
+    finally:
+        if env_old is None:
+            os.environ.pop("BANG_BENCH_PEER_SLICE_ROWS", None)
+        else:
+            os.environ["BANG_BENCH_PEER_SLICE_ROWS"] = env_old
+    c = two["config"]
+    assert c["peer_rows"] and c["peer_rows"].get("slice_rows") == 1000000 and abs(c["peer_rows"]["fraction"] - 2 / 3) < 1e-6, c["peer_rows"]
+    assert c["result_properties_ok"] is True and c["gathered_ids_equal_oracle_whole_batch"] is True, c
+    assert c["rows_from_peer_hbm_per_step"] > 0 and c["rows_from_own_hbm_per_step"] > 0 and c["pcie_pulled_bytes_per_step"] > 0, c
+    # the whole graph in the two slices: nothing is pulled over PCIe any more
+    two = _bench(2, args, workload="sift1b_shape", L=40)
+    c = two["config"]
+    assert c["peer_rows"]["fraction"] == 1.0 and c["gathered_ids_equal_oracle_whole_batch"] is True, c
+    assert c["rows_from_peer_hbm_per_step"] > 0 and c["pcie_pulled_bytes_per_step"] == 0, c

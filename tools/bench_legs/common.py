@@ -298,7 +298,7 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
     keys_max = ("iterations", "persistent", "vectors_on_device", "graph_mode", "lanes", "walker_threads", "wg_queries",
                 "workgroups", "hops_p50", "hops_p99", "hops_max", "graph_pull", "code_stride", "rows_in_hbm", "rerank_fused", "walker_rows")
     agg = dict(front_ms=0.0, front_busy_ms=0.0, walker_ms=0.0, sync_ms=0.0, enqueue_ms=0.0, dist_evals=0, front_launches=0,
-               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0)
+               fetched=0, candidates=0, h2d_bytes=0, pulled_bytes=0, filter_loads_skipped=0, rows_from_peer=0, rows_from_own_hbm=0)
     agg.update({kk: 0 for kk in keys_max})
     ids = dists = None
     for _ in range(steps):
@@ -468,6 +468,24 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     my_q = np.ascontiguousarray(queries[q0:q1])
     Qr = q1 - q0
     eng = make_engine(wl, graph, ctx, lanes=lanes, threads=threads, timing=0 if args.no_events else 1, pull=pull)
+    # N > 1, rows pulled: the node's adjacency rows go into the node's spare HBM -- rank r keeps slice r, every rank maps the others over IPC
+    # (bang_amd/shard.py share_rows; BANG_BENCH_NO_PEER_ROWS=1: every rank pulls from host DRAM as in rounds 2-4)
+    ctx.peer_rows = None
+    if ctx.world > 1 and graph != "device" and pull != 0 and not os.environ.get("BANG_BENCH_NO_PEER_ROWS"):
+        import torch.distributed as dist
+        from bang_amd import shard as _shard
+        ok_t = [None] * ctx.world
+        err = None
+        try:
+            ctx.peer_rows = _shard.share_rows(eng, ctx.rank, ctx.world, int(ix.N), slice_rows=int(os.environ.get("BANG_BENCH_PEER_SLICE_ROWS", "0")))
+        except Exception as ex:                              # noqa: BLE001  (no IPC here, not pull mode ...: host rows serve everything)
+            err = repr(ex)[:200]
+        dist.all_gather_object(ok_t, err)
+        if any(ok_t):
+            log(f"[bench] peer rows not available: {[e_ for e_ in ok_t if e_][0]}")
+            ctx.peer_rows = {"error": [e_ for e_ in ok_t if e_][0]}
+        else:
+            log(f"[bench] peer rows: {ctx.peer_rows['slice_rows']} rows per rank, {100 * ctx.peer_rows['fraction']:.1f} % of the adjacency rows in the node's HBM")
     # N > 1: the shard's ids stay in device memory (bang_query_dev_e) until the collective (BANG_BENCH_HOST_GATHER=1: the r02 host bounce)
     ctx.dgather = None
     if (ctx.world > 1 or getattr(ctx, "force_gather", False)) and not weak and not os.environ.get("BANG_BENCH_HOST_GATHER"):
