@@ -39,19 +39,31 @@ def _bench(nproc, extra, timeout=380, workload="tiny", L=46):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("graph", ["host", "host-walker", "device"])
-def test_two_ranks_one_gpu_one_host_graph(libbang, graph):
-    """host: the default of the host placement -- both ranks pull adjacency rows from ONE rows file in the shared directory (rank 0
-    builds it, rank 1 maps it: BANG_PULL_ROWS_DIR); host-walker: both ranks' walker threads read ONE mapped graph file."""
+@pytest.mark.parametrize("graph", ["host", "host-nopeer", "host-walker", "device"])
+def test_two_ranks_one_gpu_one_host_graph(libbang, graph, monkeypatch):
+    """host: the default of the host placement -- ONE rows file in the shared directory (rank 0 builds it, rank 1 maps it:
+    BANG_PULL_ROWS_DIR) and, N > 1, the rows of this small index entirely in the two ranks' HBM slices (peer rows: nothing is pulled over
+    PCIe any more); host-nopeer: both ranks pull every row from the shared file (rounds 2-4); host-walker: both ranks' walker threads
+    read ONE mapped graph file."""
     walker = graph == "host-walker"
-    graph = "host" if walker else graph
+    nopeer = graph == "host-nopeer"
+    if nopeer:
+        monkeypatch.setenv("BANG_BENCH_NO_PEER_ROWS", "1")
+    graph = "host" if (walker or nopeer) else graph
     extra = ["--graph", graph] + (["--pull", "0"] if walker else [])
     one = _bench(1, extra)
     two = _bench(2, extra)
     if graph == "host":
         for r in (one, two):
             assert ("pulled" in r["config"]["host_loop"]) == (not walker), r["config"]["host_loop"]
-            assert (r["config"]["pcie_pulled_bytes_per_step"] > 0) == (not walker)
+        assert (one["config"]["pcie_pulled_bytes_per_step"] > 0) == (not walker)
+        if walker:
+            assert two["config"]["pcie_pulled_bytes_per_step"] == 0 and not two["config"]["peer_rows"]
+        elif nopeer:
+            assert two["config"]["pcie_pulled_bytes_per_step"] > 0 and two["config"]["peer_rows"] is None
+        else:
+            assert two["config"]["peer_rows"]["fraction"] == 1.0 and two["config"]["rows_from_peer_hbm_per_step"] > 0, two["config"]["peer_rows"]
+            assert two["config"]["pcie_pulled_bytes_per_step"] == 0
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["config"]["parity_vs_oracle_first_64"] is True and two["config"]["parity_vs_oracle_first_64"] is True
     assert two["config"]["graph"] == graph and two["config"]["L"] == 46
