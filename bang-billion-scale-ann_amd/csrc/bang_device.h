@@ -382,6 +382,115 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t h
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// wave-level helpers of the search kernel
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wave-wide minimum of a 64-bit key {hi, lo} (lexicographic, unsigned), returned to every lane.  Six DPP steps (quad swaps, row
+// half-mirror / mirror, two row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar per operand.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(uint32_t& hi, uint32_t& lo) {
+  const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+  const bool take = ohi < hi || (ohi == hi && olo < lo);
+  if (take) { hi = ohi; lo = olo; }
+}
+__device__ __forceinline__ void wave_min_key(uint32_t& hi, uint32_t& lo) {
+  dpp_min_step<0xB1, 0xf>(hi, lo);      // quad_perm [1,0,3,2]
+  dpp_min_step<0x4E, 0xf>(hi, lo);      // quad_perm [2,3,0,1]
+  dpp_min_step<0x141, 0xf>(hi, lo);     // row_half_mirror
+  dpp_min_step<0x140, 0xf>(hi, lo);     // row_mirror            -> every lane of a 16-lane row holds the row's minimum
+  dpp_min_step<0x142, 0xa>(hi, lo);     // row_bcast15 into rows 1 and 3
+  dpp_min_step<0x143, 0xc>(hi, lo);     // row_bcast31 into rows 2 and 3 -> lane 63 holds the minimum of the wave
+  hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+  lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K6 + K7 by the wave that finished the query (compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368), 8-bit vectors
+// ---------------------------------------------------------------------------------------------------------------------
+// The candidate log of the query (n <= L + 50 expanded nodes, written by this wave) is read back, G = D / 16 adjacent lanes fetch one
+// candidate's vector in one instruction (16 bytes each: one request per line), eight such instructions in flight.  The squared distance
+// is an INTEGER below 2^24 (256 x 255^2), so sum(a - b)^2 = sum a^2 - 2 sum a b + sum b^2 by v_dot4 is exact, and its float image is the
+// value the reference's ascending fmaf chain over float(a - b) produces (every partial sum of that chain is such an integer too:
+// rerank_kernel, bang_kernels.hip).  Distances go to LDS (the query's worklist and scratch are dead); the k smallest {distance bits, index}
+// keys -- ties keep expansion order (:1330-1363) -- land in ids_out [Q][k] / dists_out [rank][Q], a short log is padded with UINT64_MAX /
+// BIG_DIST (CANON 8).
+template <bool SIGNED>
+__device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
+  if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+  return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
+}
+template <bool SIGNED>
+__device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n words */,
+                                             int lane) {
+  constexpr int U = 4;                                            // vector fetches in flight per lane
+  const uint32_t D = p.rr_D, G = D >> 4, per = 64u / G;           // lanes per candidate, candidates per wave instruction
+  const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
+  const uint32_t* cand = p.d_cand_ids + (size_t)q * cand_stride;
+  const size_t qabs = (size_t)p.rr_q0 + q;
+  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.rr_queries + qabs * D + 16u * sub);
+  const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
+  for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
+    uint32_t id[U];
+    u32x4a v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.rr_vec_base + (uint64_t)id[u] * p.rr_vec_stride + 16u * sub);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      int vv = dot4_8<SIGNED>(v[u].x, v[u].x, dot4_8<SIGNED>(v[u].y, v[u].y, dot4_8<SIGNED>(v[u].z, v[u].z, dot4_8<SIGNED>(v[u].w, v[u].w, qq))));
+      const int vq = dot4_8<SIGNED>(v[u].x, qw.x, dot4_8<SIGNED>(v[u].y, qw.y, dot4_8<SIGNED>(v[u].z, qw.z, dot4_8<SIGNED>(v[u].w, qw.w, 0))));
+      vv -= 2 * vq;
+      for (uint32_t off = 1; off < G; off <<= 1) vv += __shfl_xor(vv, (int)off);       // (the G lanes of a candidate are adjacent)
+      if (i < n && sub == 0u) e[i] = __float_as_uint((float)vv);
+    }
+  }
+  wave_sync();
+  // K7: the k smallest {distance bits, index} keys, in order, by repeated wave-wide arg-min -- k rounds of six DPP steps instead of n^2 / 64
+  // compares per lane.  Lane l keeps the minimum over ITS candidates (index = l mod 64); the round's winner is struck out by its owner, which
+  // re-reads its (<= 9) candidates.  Result r of a chunk of 64 waits in lane r until the chunk is written out.
+  uint32_t my_hi = 0xFFFFFFFFu, my_lo = 0xFFFFFFFFu;
+  auto own_min = [&]() {
+    my_hi = 0xFFFFFFFFu; my_lo = 0xFFFFFFFFu;
+    for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {          // ascending index, strict '<': ties keep expansion order (:1330-1363)
+      const uint32_t d = e[i];
+      if (d < my_hi) { my_hi = d; my_lo = i; }
+    }
+  };
+  own_min();
+  const uint32_t kk = p.rr_k < n ? p.rr_k : n;
+  for (uint32_t r0 = 0; r0 < kk; r0 += WAVE) {                     // (uniform)
+    uint32_t res_i = 0, res_d = 0;
+    const uint32_t rn = kk - r0 < WAVE ? kk - r0 : WAVE;
+    for (uint32_t r = 0; r < rn; ++r) {
+      uint32_t hi = my_hi, lo = my_lo;
+      wave_min_key(hi, lo);                                          // (every lane gets the winner)
+      if ((uint32_t)lane == r) { res_i = lo; res_d = hi; }
+      if ((lo & 63u) == (uint32_t)lane) { e[lo] = 0xFFFFFFFFu; own_min(); }
+    }
+    if ((uint32_t)lane < rn) {
+      p.rr_ids_out[qabs * p.rr_k + r0 + lane] = (uint64_t)ld_bypass_l1(cand + res_i);               // [Q][k] u64 :1366
+      p.rr_dists_out[(size_t)(r0 + (uint32_t)lane) * p.rr_Q_total + qabs] = __uint_as_float(res_d);  // [rank][Q] :999,1297
+    }
+  }
+  for (uint32_t r = n + (uint32_t)lane; r < p.rr_k; r += WAVE) {                      // CANON 8
+    p.rr_ids_out[qabs * p.rr_k + r] = ~0ull;
+    p.rr_dists_out[(size_t)r * p.rr_Q_total + qabs] = BIG_DIST;
+  }
+  wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host-side launcher helpers (per translation unit)
 // ---------------------------------------------------------------------------------------------------------------------
 #define HIP_TRY(x)                                                         \
