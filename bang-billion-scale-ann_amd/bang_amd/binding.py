@@ -267,6 +267,9 @@ class Engine:
         buf = (C.c_ubyte * 64).from_buffer_copy(handle) if handle is not None else None
         _check(lib().bang_rows_import_e(self._h, C.c_uint32(slot), C.c_uint32(n_slots), C.c_uint64(slice_rows), buf), "bang_rows_import")
 
+    def rows_close_peers(self):
+        _check(lib().bang_rows_close_peers_e(self._h), "bang_rows_close_peers")
+
     def set_searchparams(self, recall: int, worklist_length: int, distfn: int = DIST_L2):
         _check(lib().bang_set_searchparams_e(self._h, recall, worklist_length, distfn), "bang_set_searchparams")
         self.k, self.L = recall, worklist_length

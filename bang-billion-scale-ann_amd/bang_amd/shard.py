@@ -99,3 +99,11 @@ def share_rows(eng, rank: int, world: int, n_nodes: int, group=None, slice_rows:
             eng.rows_import(r, world, n, h if rr else bytes(64))
     total = min(n_nodes, world * n)
     return {"slice_rows": n, "rows_in_node_hbm": total, "fraction": total / max(1, n_nodes)}
+
+
+def unshare_rows(eng, group=None):
+    """Tear-down of share_rows in two phases (after eng.free(), before eng.unload()): every rank closes its mappings of the other ranks'
+    slices, the ranks meet, and only then may anyone free the slice the others had mapped."""
+    import torch.distributed as dist
+    eng.rows_close_peers()
+    dist.barrier(group=group)

@@ -379,6 +379,16 @@ extern "C" int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_sl
   return BANG_OK;
 }
 
+extern "C" int bang_rows_close_peers_e(bang_engine_t* e) {
+  if (!e) return BANG_ERR_ARG;
+  if (e->allocated) { bang_set_error("peer rows: bang_free first (a batch may still read the peers' rows)"); return BANG_ERR_ARG; }
+  BANG_TRY(ensure_device(e));
+  for (uint32_t s = 0; s < BANG_MAX_ROW_SLICES; ++s) {
+    if (e->peer_ptr[s]) { (void)hipIpcCloseMemHandle(e->peer_ptr[s]); e->peer_ptr[s] = nullptr; e->slice_base[s] = 0; }
+  }
+  return BANG_OK;
+}
+
 namespace bang {
 
 // seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489) and the medoid's vector (:492-501), from the medoid's graph entry

@@ -139,6 +139,9 @@ int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out);   /* rows of 256
 int bang_rows_slice_e(bang_engine_t* e, uint64_t first_row, uint64_t rows);
 int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* first_row, uint64_t* rows);
 int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, const void* handle64 /* NULL: this engine's own slice */);
+/* Tear-down in two phases: every rank closes its mappings of the OTHER ranks' slices (this call; after bang_free), the ranks meet (a barrier of
+ * the caller's process group), and only then does anyone bang_unload -- which frees the slice the others had mapped. */
+int bang_rows_close_peers_e(bang_engine_t* e);
 
 int bang_set_searchparams_e(bang_engine_t* e, int recall, int worklist_length, int distfn); /* bang.h:60 */
 int bang_alloc_e(bang_engine_t* e, int num_queries);                                        /* bang.h:53 */

@@ -64,3 +64,62 @@ def test_shard_ranges_cover_the_batch():
             cuts = [shard_range(Q, r, W) for r in range(W)]
             assert cuts[0][0] == 0 and cuts[-1][1] == Q
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+
+
+class _FakeEngine:
+    """Stands in for bang_amd.Engine in the peer-rows exchange (no GPU here): records what share_rows asks of an engine."""
+
+    def __init__(self, rank, capacity):
+        self.rank, self.capacity, self.slice, self.imports, self.closed = rank, capacity, None, [], False
+
+    def rows_capacity(self):
+        return self.capacity
+
+    def rows_slice(self, first, rows):
+        self.slice = (first, rows)
+
+    def rows_export(self):
+        first, rows = self.slice
+        return (bytes([self.rank + 1]) * 64 if rows else bytes(64)), first, rows
+
+    def rows_import(self, slot, n_slots, slice_rows, handle):
+        self.imports.append((slot, n_slots, slice_rows, handle))
+
+    def rows_close_peers(self):
+        self.closed = True
+
+
+def _peer_worker(rank, world, port, N, caps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
+    import json
+    import torch.distributed as dist
+    from bang_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine(rank, caps[rank])
+    info = shard.share_rows(eng, rank, world, N)
+    shard.unshare_rows(eng)
+    json.dump({"info": info, "slice": eng.slice, "closed": eng.closed,
+               "imports": [[s, w, n, (None if h is None else h[0])] for s, w, n, h in eng.imports]}, open(os.path.join(out_dir, f"p{rank}.json"), "w"))
+    dist.destroy_process_group()
+
+
+def test_peer_rows_exchange_two_ranks(tmp_path):
+    """share_rows (the host logic of the peer-rows feature, include/bang_c.h bang_rows_*_e) over gloo with two ranks: the slice size is the
+    smallest capacity among the ranks, rank r keeps the rows [r n, (r + 1) n), every rank imports its own slice (no handle) and the sibling's
+    handle into the right slot; an index smaller than the capacities is split in halves (W n >= N: everything in the node's HBM)."""
+    import json
+    for N, caps, n_want in ((1000, (300, 400), 300), (1000, (5000, 7000), 500), (1001, (5000, 7000), 501)):
+        d = tmp_path / f"n{N}_{caps[0]}"
+        d.mkdir()
+        mp.spawn(_peer_worker, args=(2, _free_port(), N, caps, str(d)), nprocs=2, join=True)
+        for r in range(2):
+            p = json.load(open(d / f"p{r}.json"))
+            assert p["info"]["slice_rows"] == n_want and p["info"]["rows_in_node_hbm"] == min(N, 2 * n_want) and p["closed"] is True
+            first = min(r * n_want, N)
+            assert p["slice"] == [first, min(n_want, N - first)]
+            assert sorted(i[0] for i in p["imports"]) == [0, 1] and all(i[1] == 2 and i[2] == n_want for i in p["imports"])
+            for slot, _, _, h in p["imports"]:
+                assert (h is None) == (slot == r) and (h is None or h == slot + 1)          # the sibling's handle went into the sibling's slot

@@ -535,7 +535,8 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
             ids_all, _ = orc.search(queries, k, L, nthreads=usable_cpus())
             gathered_ok = bool(np.array_equal(ctx.batch_ids, ids_all))
     out = dict(wl=wl, eng=eng, res=res, L=L, recall=recall, ok=ok, graph=graph, orc=orc, my_q=my_q, q0=q0, q1=q1, Qr=Qr,
-               placement_note=placement_note, structured=gt_i is not None, name=name, gathered_ok=gathered_ok)
+               placement_note=placement_note, structured=gt_i is not None, name=name, gathered_ok=gathered_ok,
+               peer_rows=bool(ctx.peer_rows and not ctx.peer_rows.get("error")))
     if not keep:
         release_config(out)
     return out
@@ -545,7 +546,11 @@ def release_config(rc):
     import torch
     if rc.get("eng") is not None:
         e = rc["eng"]
-        e.free(); e.unload(); e.close()
+        e.free()
+        if rc.get("peer_rows"):                              # (two phases: close the peers' mappings, meet, then free what they had mapped)
+            from bang_amd import shard as _shard
+            _shard.unshare_rows(e)
+        e.unload(); e.close()
         rc["eng"] = None
     if rc.get("wl") is not None:
         rc["wl"]["release"]()
