@@ -424,15 +424,18 @@ __device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
   if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
   return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
 }
+struct RerankArgs8 {                                    // bang_search_params.rr_*, as the kernel read them at the query's end
+  const void* queries; const uint8_t* vec_base; uint64_t vec_stride; uint64_t* ids_out; float* dists_out; const uint32_t* cand;
+  uint32_t D, k, q0, Q_total;
+};
 template <bool SIGNED>
-__device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32_t q, uint32_t n, uint32_t cand_stride, uint32_t* e /* LDS, n words */,
-                                             int lane) {
+__device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, uint32_t n, uint32_t* e /* LDS, n words */, int lane) {
   constexpr int U = 4;                                            // vector fetches in flight per lane
-  const uint32_t D = p.rr_D, G = D >> 4, per = 64u / G;           // lanes per candidate, candidates per wave instruction
+  const uint32_t D = p.D, G = D >> 4, per = 64u / G;              // lanes per candidate, candidates per wave instruction
   const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
-  const uint32_t* cand = p.d_cand_ids + (size_t)q * cand_stride;
-  const size_t qabs = (size_t)p.rr_q0 + q;
-  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.rr_queries + qabs * D + 16u * sub);
+  const uint32_t* cand = p.cand;
+  const size_t qabs = (size_t)p.q0 + q;
+  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.queries + qabs * D + 16u * sub);
   const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
   for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
@@ -444,7 +447,7 @@ __device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32
       id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.rr_vec_base + (uint64_t)id[u] * p.rr_vec_stride + 16u * sub);
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.vec_base + (uint64_t)id[u] * p.vec_stride + 16u * sub);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = i0 + (uint32_t)u * per + slot;
@@ -468,7 +471,7 @@ __device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32
     }
   };
   own_min();
-  const uint32_t kk = p.rr_k < n ? p.rr_k : n;
+  const uint32_t kk = p.k < n ? p.k : n;
   for (uint32_t r0 = 0; r0 < kk; r0 += WAVE) {                     // (uniform)
     uint32_t res_i = 0, res_d = 0;
     const uint32_t rn = kk - r0 < WAVE ? kk - r0 : WAVE;
@@ -479,13 +482,13 @@ __device__ __forceinline__ void wave_rerank8(const bang_search_params& p, uint32
       if ((lo & 63u) == (uint32_t)lane) { e[lo] = 0xFFFFFFFFu; own_min(); }
     }
     if ((uint32_t)lane < rn) {
-      p.rr_ids_out[qabs * p.rr_k + r0 + lane] = (uint64_t)ld_bypass_l1(cand + res_i);               // [Q][k] u64 :1366
-      p.rr_dists_out[(size_t)(r0 + (uint32_t)lane) * p.rr_Q_total + qabs] = __uint_as_float(res_d);  // [rank][Q] :999,1297
+      p.ids_out[qabs * p.k + r0 + lane] = (uint64_t)ld_bypass_l1(cand + res_i);               // [Q][k] u64 :1366
+      p.dists_out[(size_t)(r0 + (uint32_t)lane) * p.Q_total + qabs] = __uint_as_float(res_d);  // [rank][Q] :999,1297
     }
   }
-  for (uint32_t r = n + (uint32_t)lane; r < p.rr_k; r += WAVE) {                      // CANON 8
-    p.rr_ids_out[qabs * p.rr_k + r] = ~0ull;
-    p.rr_dists_out[(size_t)r * p.rr_Q_total + qabs] = BIG_DIST;
+  for (uint32_t r = n + (uint32_t)lane; r < p.k; r += WAVE) {                      // CANON 8
+    p.ids_out[qabs * p.k + r] = ~0ull;
+    p.dists_out[(size_t)r * p.Q_total + qabs] = BIG_DIST;
   }
   wave_sync();
 }

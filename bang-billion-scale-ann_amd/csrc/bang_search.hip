@@ -45,6 +45,18 @@
 #include "bang_internal.h"
 #include "bang_device.h"
 
+struct SearchArgs;
+// A kernel-argument field read WHERE IT IS USED (a scalar load from the kernarg segment through a pointer the optimiser cannot see through),
+// for arguments that are needed once per query (K1 at its start, the re-rank at its end): read the ordinary way they are loop-invariant, get
+// hoisted out of the search loop and occupy scalar registers the loop has none to spare of (106 of 106: they spill into VGPR lanes).
+template <class T>
+__device__ __forceinline__ T karg_at(size_t off) {
+  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  return *(const T __attribute__((address_space(4)))*)(ka + off);
+}
+#define KARG(field) karg_at<decltype(bang_search_params::field)>(offsetof(SearchArgs, p) + offsetof(bang_search_params, field))
+
 struct SearchArgs {
   bang_search_params p;
   uint32_t lds_piv_floats;
@@ -509,6 +521,32 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 #pragma unroll
   for (int r = 0; r < NV; ++r) qc.v[r] = 0.0f;
   auto load_qc = [&](uint32_t qq) {
+    const int32_t* dimmap = HOST ? nullptr : KARG(d_dimmap);
+    if (!HOST && dimmap) {
+      // K1 here (populate_pqDist_par :1099-1113: centre the query, chunk by chunk): position i of the padded layout holds dimension dimmap[i]
+      // (or nothing: -1); the raw element comes from device memory or straight from the caller's batch in mapped pinned host memory
+      const float* centroid = KARG(d_centroid);
+      const void* qraw = KARG(d_qraw);
+      const uint32_t q_dim = KARG(q_dim), q_dtype = KARG(q_dtype);
+      const size_t qoff = (size_t)qq * q_dim;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const uint32_t i = QC16 ? (uint32_t)r * 16u + ((uint32_t)lane & 15u) : (uint32_t)r * 64u + (uint32_t)lane;
+        const int j = dimmap[i < (uint32_t)QW ? i : 0u];
+        float v = 0.0f;
+        if (i < (uint32_t)QW && j >= 0) {
+          float qv = 0.0f;                                            // MIPS: the last dimension of the query is the zero pad (:1099-1113)
+          if ((uint32_t)j < q_dim) {
+            if (q_dtype == BANG_F32) qv = ((const float*)qraw)[qoff + (uint32_t)j];
+            else if (q_dtype == BANG_I8) qv = (float)((const int8_t*)qraw)[qoff + (uint32_t)j];
+            else qv = (float)((const uint8_t*)qraw)[qoff + (uint32_t)j];
+          }
+          v = qv - centroid[j];
+        }
+        qc.v[r] = v;
+      }
+      return;
+    }
     const float* src = p.d_qc + (size_t)qq * QW;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
@@ -600,11 +638,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       if (!((started >> c) & 1u)) q = c * total_waves + gw;
       else {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(p.d_next_query, 1u);
+        if (lane == 0) t = atomicAdd(KARG(d_next_query), 1u);
         q = nctx * total_waves + uni(t);
       }
       started |= 1u << c;
-      if (q < p.Q) {
+      if (q < KARG(Q)) {
         active = true;
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
@@ -613,7 +651,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
-        cnt_in = p.d_seed[0]; x0 = p.d_seed[1 + lane]; x1 = p.d_seed[65];
+        { const uint32_t* seed = KARG(d_seed); cnt_in = seed[0]; x0 = seed[1 + lane]; x1 = seed[65]; }
         have_row = true;
       } else exhausted = true;
     }
@@ -888,15 +926,26 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // a query is active while it has a parent or unmerged survivors (CANON 4); the loop ends at the cap (:950-956)
       if ((!found && n == 0) || iter == cap_iter) {
         if (lane == 0) {
-          p.d_cand_cnt[q] = cc;
-          if (p.d_qstats) *(uint2*)(p.d_qstats + (size_t)q * 2) = make_uint2(evals, fetched);
-          if (p.d_qiters) p.d_qiters[q] = iter;
-          if (p.d_qskip) p.d_qskip[q] = probes_skipped;
+          // (the once-per-query arguments are read where they are used: KARG)
+          KARG(d_cand_cnt)[q] = cc;
+          uint32_t* qstats = KARG(d_qstats);
+          uint32_t* qiters = KARG(d_qiters);
+          uint32_t* qskip = KARG(d_qskip);
+          if (qstats) *(uint2*)(qstats + (size_t)q * 2) = make_uint2(evals, fetched);
+          if (qiters) qiters[q] = iter;
+          if (qskip) qskip[q] = probes_skipped;
         }
-        if (!HOST && p.rr_queries) {                                         // K6 + K7 on the spot (uniform)
-          const uint32_t nc = cc < cand_stride ? cc : cand_stride;
-          if (p.rr_dtype == BANG_I8) wave_rerank8<true>(p, q, nc, cand_stride, wbase, lane);
-          else wave_rerank8<false>(p, q, nc, cand_stride, wbase, lane);
+        if (!HOST) {
+          RerankArgs8 rr;                                                      // (read here, once per query: KARG)
+          rr.queries = KARG(rr_queries);
+          if (rr.queries) {                                                    // K6 + K7 on the spot (uniform)
+            rr.vec_base = KARG(rr_vec_base); rr.vec_stride = KARG(rr_vec_stride); rr.ids_out = KARG(rr_ids_out); rr.dists_out = KARG(rr_dists_out);
+            rr.D = KARG(rr_D); rr.k = KARG(rr_k); rr.q0 = KARG(rr_q0); rr.Q_total = KARG(rr_Q_total);
+            rr.cand = p.d_cand_ids + (size_t)q * cand_stride;
+            const uint32_t nc = cc < cand_stride ? cc : cand_stride;
+            if (KARG(rr_dtype) == BANG_I8) wave_rerank8<true>(rr, q, nc, wbase, lane);
+            else wave_rerank8<false>(rr, q, nc, wbase, lane);
+          }
         }
         active = false;
       } else {
@@ -932,9 +981,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   }
 #endif
 #undef PH
-  if (p.d_ktime) {
+  if (KARG(d_ktime)) {
     __syncthreads();
-    if (threadIdx.x == 0) p.d_ktime[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) KARG(d_ktime)[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1040,7 +1089,8 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (p->Q == 0) return BANG_OK;
   if (p->R == 0 || p->R > BANG_MAX_R || p->L == 0 || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
   if (p->psz == 0 || p->mp < p->m || (p->mp & 3u)) { bang_set_error("the search kernel needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
-  if (!p->d_codes || !p->d_pivots_packed || !p->d_qc || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
+  if (p->d_dimmap && (!p->d_graph || !p->d_centroid || !p->d_qraw || p->q_dim == 0 || p->q_dtype > BANG_F32)) { bang_set_error("folded K1: bad arguments"); return BANG_ERR_ARG; }
+  if (!p->d_codes || !p->d_pivots_packed || (!p->d_qc && !p->d_dimmap) || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
       !p->d_next_query) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
   if (!p->d_graph && (!p->d_rows || !p->d_ctl || !p->h_done || !p->h_parents || (p->ship_vectors && (!p->h_pub_q || !p->h_pub_c)))) {
     bang_set_error("host-paced search kernel: null pacing buffer"); return BANG_ERR_ARG;
