@@ -58,7 +58,6 @@ class SearchParams(C.Structure):
         ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p),
         ("d_row_slices", C.c_void_p), ("n_slices", C.c_uint32), ("slice_rows", C.c_uint32), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
         ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32),
-        ("d_dimmap", C.c_void_p), ("d_centroid", C.c_void_p), ("d_qraw", C.c_void_p), ("q_dtype", C.c_uint32), ("q_dim", C.c_uint32),
         ("rr_queries", C.c_void_p), ("rr_vec_base", C.c_void_p), ("rr_vec_stride", C.c_uint64), ("rr_ids_out", C.c_void_p), ("rr_dists_out", C.c_void_p),
         ("rr_dtype", C.c_uint32), ("rr_D", C.c_uint32), ("rr_k", C.c_uint32), ("rr_q0", C.c_uint32), ("rr_Q_total", C.c_uint32),
     ]
@@ -80,7 +79,7 @@ class Stats(C.Structure):
                 ("graph_mode", C.c_uint64), ("lanes", C.c_uint64), ("walker_threads", C.c_uint64), ("wg_queries", C.c_uint64),
                 ("workgroups", C.c_uint64), ("hops_p50", C.c_uint64), ("hops_p99", C.c_uint64), ("hops_max", C.c_uint64),
                 ("search_kernel", C.c_uint64), ("pacing_groups", C.c_uint64), ("graph_pull", C.c_uint64), ("pulled_bytes", C.c_uint64),
-                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64), ("rows_from_peer", C.c_uint64), ("rows_from_own_hbm", C.c_uint64), ("walker_rows", C.c_uint64), ("k1_folded", C.c_uint64), ("direct_io", C.c_uint64), ("rerank_fused", C.c_uint64)]
+                ("rows_in_hbm", C.c_uint64), ("code_stride", C.c_uint64), ("filter_loads_skipped", C.c_uint64), ("rows_from_peer", C.c_uint64), ("rows_from_own_hbm", C.c_uint64), ("walker_rows", C.c_uint64), ("rerank_fused", C.c_uint64)]
 
 
 ENTRY_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)     # bang_entry_source

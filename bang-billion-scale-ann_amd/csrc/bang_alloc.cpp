@@ -29,8 +29,6 @@ void free_batch(bang_engine* e) {
   dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_fp); dfree(e->d_results);
   e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
   if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
-  if (e->h_q_pin) { (void)hipHostFree(e->h_q_pin); e->h_q_pin = nullptr; }
-  e->d_q_pin = nullptr; e->d_results_map = nullptr;
   dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_pub_q) (void)hipHostFree(e->h_pub_q);
@@ -148,15 +146,6 @@ int alloc_buffers(bang_engine* e, int Q) {         // (bang_alloc_e has validate
     e->res_bytes = (e->res_off_iters + (size_t)nq * 4 + BANG_MAX_LANES * 4 + a64) & ~a64;   // + the kernel's abort word, one per lane
     BANG_TRY(dmalloc(&e->d_results, e->res_bytes));
     HIP_TRY(hipHostMalloc((void**)&e->h_results, e->res_bytes, hipHostMallocDefault));
-    // direct I/O (self-paced search kernel with the fused re-rank): the kernel reads the raw queries from a pinned mirror and writes its results
-    // into the pinned result mirror -- both need a device address; without one the copies stay
-    {
-      void* dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, e->h_results, 0) == hipSuccess) e->d_results_map = (uint8_t*)dp; else (void)hipGetLastError();
-      const size_t qb = nq * e->D * e->tsize + 64;
-      if (hipHostMalloc((void**)&e->h_q_pin, qb, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dp, e->h_q_pin, 0) == hipSuccess) e->d_q_pin = (const uint8_t*)dp;
-      else { (void)hipGetLastError(); if (e->h_q_pin) { (void)hipHostFree(e->h_q_pin); e->h_q_pin = nullptr; } e->d_q_pin = nullptr; }
-    }
     e->d_ids_out = (uint64_t*)e->d_results;
     e->d_dists_out = (float*)(e->d_results + e->res_off_dists);
     e->d_qiters = (uint32_t*)(e->d_results + e->res_off_iters);

@@ -292,8 +292,6 @@ static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* 
   s.workgroups = e->search_host ? (uint64_t)e->sv_G : e->search_v2 ? (uint64_t)std::min(Q, bang_num_cus()) : 0;
   s.search_kernel = (e->search_v2 || e->search_host) ? 1 : 0;
   s.rerank_fused = e->rerank_fused ? 1 : 0;
-  s.direct_io = (e->search_v2 && e->direct_io_used) ? 1 : 0;
-  s.k1_folded = (e->search_v2 && e->psz != 0 && e->d_dimmap != nullptr && e->fold_k1 != 0) ? 1 : 0;
   s.walker_rows = (e->search_host && e->walker_rows) ? 1 : 0;
   s.code_stride = e->code_stride;
   s.rows_in_hbm = (s.graph_pull ? e->n_rows_hbm : 0);

@@ -144,7 +144,6 @@ struct bang_engine {
   float* d_pivots_packed = nullptr; // [mp][256][psz]
   float* d_centroid = nullptr;
   uint32_t* d_chunk_off = nullptr;
-  int32_t* d_dimmap = nullptr;         // [mp * psz] dimension of padded position i of a centred query, or -1 (K1 folded into the search launch)
   uint32_t* d_seed = nullptr;       // {count, MEDOID, adj(MEDOID)...}
   uint8_t* d_medoid_vec = nullptr;
   uint32_t psz = 0, mp = 0;
@@ -228,12 +227,6 @@ struct bang_engine {
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
   uint32_t* d_qskip = nullptr;         // [Q] filter-word loads saved by the on-chip summary (search kernel, self-paced)
   bool rerank_fused = false;           // the last bang_query re-ranked inside the search launch
-  bool direct_io_used = false;         // ... and read its queries from / wrote its results to pinned host memory itself (no copy engine, no K1 launch)
-  int fold_k1 = -1;                    // option "fold_k1": K1 (query centring) inside the search launch; -1 = auto = on
-  int direct_io = -1;                  // option "direct_io": queries read from / results written to mapped pinned host memory by the kernel; -1 = auto = on
-  uint8_t* h_q_pin = nullptr;          // pinned mirror of the batch's raw queries (direct I/O) and its device address
-  const uint8_t* d_q_pin = nullptr;
-  uint8_t* d_results_map = nullptr;    // device address of the pinned result mirror h_results
   int fuse_rerank = -1;                // option "fuse_rerank": K6 + K7 inside the search launch (self-paced form, 8-bit vectors); -1 = auto = on
   std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)

@@ -110,31 +110,23 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     fprintf(stderr, "[timeline lane %d] %-28s %8.1f us\n", ln.index, what, ms_since(tl_t) * 1000.0);
     tl_t = Clock::now();
   };
-  // What surrounds the search launch.  The self-paced search kernel can do K1 itself (fold_k1: the wave that takes a query centres it),
-  // K6 + K7 itself (fused_rerank: 8-bit vectors), and -- both given, the whole batch in one lane, results wanted on the host -- its own I/O
-  // (direct): it reads the raw queries from a pinned mirror of the caller's batch and writes ids / distances / iteration counts into the
-  // pinned result mirror, so nothing but the launch sits between the two host-side memcpys (no copy-engine transfer, no K1 launch).
+  // K6 + K7 inside the search launch (8-bit vectors, self-paced form): no launch behind it
   const bool fused_rerank = e->search_v2 && e->fuse_rerank != 0 && (dev_graph || e->vec_on_device) &&
                             bang_search_can_rerank(e->dtype, e->D, dev_graph ? e->entry_len : vb, dim_adjust) != 0;
-  const bool fold_k1 = e->search_v2 && e->psz != 0 && e->d_dimmap != nullptr && e->fold_k1 != 0;
   const bool whole = ln.q0 == 0 && (int)ln.nq == Q && (int)ln.nq == e->Qcur;
   const size_t mailbox_max = (size_t)env_long("BANG_MAILBOX_BYTES", BANG_RESULT_MAILBOX_BYTES);
   uint64_t* d_ids_user = e->pool.d_ids_user;
   float* d_dists_user = e->pool.d_dists_user;
   const bool to_device = d_ids_user != nullptr;               // bang_query_dev_e: no result leaves the device
   const bool mailbox = !to_device && whole && e->res_off_iters <= mailbox_max;
-  const bool direct = fused_rerank && fold_k1 && mailbox && e->direct_io != 0 && e->h_q_pin && e->d_q_pin && e->d_results_map;
-  e->direct_io_used = direct;
   // queries H2D (:612) + K1 (:623)
   uint8_t* dq = (uint8_t*)e->d_queries + (size_t)ln.q0 * qbytes;
-  if (direct) memcpy(e->h_q_pin, h_queries, (size_t)ln.nq * qbytes);         // (whole batch: q0 = 0)
-  else LANE_HIP(hipMemcpyAsync(dq, (const uint8_t*)h_queries + (size_t)ln.q0 * qbytes, (size_t)ln.nq * qbytes,
-                               hipMemcpyHostToDevice, ln.s_main));
-  if (e->psz) {
-    if (!fold_k1)
-      BANG_TRY(bang_k_center_queries(dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_qc, ln.nq, e->D, e->m,
-                                     e->mp, e->psz, dim_adjust, ln.s_main));
-  } else
+  LANE_HIP(hipMemcpyAsync(dq, (const uint8_t*)h_queries + (size_t)ln.q0 * qbytes, (size_t)ln.nq * qbytes,
+                          hipMemcpyHostToDevice, ln.s_main));
+  if (e->psz)
+    BANG_TRY(bang_k_center_queries(dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_qc, ln.nq, e->D, e->m,
+                                   e->mp, e->psz, dim_adjust, ln.s_main));
+  else
     BANG_TRY(bang_k_lut_build(e->d_pivots_T, dq, e->dtype, e->d_centroid, e->d_chunk_off, (float*)p.d_lut, ln.nq,
                               e->D, e->m, dim_adjust, ln.s_main));
 
@@ -175,20 +167,12 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_qskip = e->d_qskip + ln.q0;
     sp.merge_late = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_MERGE_LATE", 0)));
     e->rerank_fused = fused_rerank;
-    if (fold_k1) {                                                           // K1 by the wave that takes the query: no launch in front of this one
-      sp.d_dimmap = e->d_dimmap; sp.d_centroid = e->d_centroid; sp.q_dtype = (uint32_t)e->dtype; sp.q_dim = (uint32_t)qdim;
-      sp.d_qraw = direct ? (const void*)e->d_q_pin : (const void*)dq;
-    }
     if (fused_rerank) {                                                      // K6 + K7 by the wave that finishes the query: no launch behind this one
-      sp.rr_queries = direct ? (const void*)e->d_q_pin : (const void*)e->d_queries;
+      sp.rr_queries = e->d_queries;
       sp.rr_dtype = (uint32_t)e->dtype; sp.rr_D = e->D; sp.rr_k = (uint32_t)e->k; sp.rr_q0 = ln.q0; sp.rr_Q_total = (uint32_t)Q;
       sp.rr_vec_base = dev_graph ? e->d_graph : e->d_vecs; sp.rr_vec_stride = dev_graph ? e->entry_len : vb;
       sp.rr_ids_out = e->d_ids_out; sp.rr_dists_out = e->d_dists_out;
-      if (direct) {                                                          // results straight into the pinned mirror the caller's arrays are filled from
-        sp.rr_ids_out = (uint64_t*)e->d_results_map; sp.rr_dists_out = (float*)(e->d_results_map + e->res_off_dists);
-        sp.d_qiters = (uint32_t*)(e->d_results_map + e->res_off_iters);
-        sp.d_abort = (uint32_t*)(e->d_results_map + e->res_bytes - BANG_MAX_LANES * 4) + ln.index;
-      } else if (to_device && whole) {                                       // bang_query_dev_e: straight into the caller's device buffers
+      if (to_device && whole) {                                       // bang_query_dev_e: straight into the caller's device buffers
         sp.rr_ids_out = d_ids_user;
         if (d_dists_user) sp.rr_dists_out = d_dists_user;
       }
@@ -397,11 +381,9 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   // A copy into the caller's pageable arrays is staged by the runtime and costs ~20 us before the first byte moves, per copy.  The
   // results come back whole in ONE asynchronous copy into the pinned mirror and are handed out with memcpy (measured: 70 -> 17 us for
   // a 1 250-query shard, 92-107 -> 73-82 us for the 10 K batch); only a very large batch keeps the direct, runtime-pipelined copies.
-  if ((e->search_host || e->search_v2) && !direct) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
+  if (e->search_host || e->search_v2) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
   const bool iters = e->search_v2 || e->search_host;
-  if (direct) {
-    // nothing to copy: the kernel wrote ids, distances, iteration counts and its abort word into the pinned mirror itself
-  } else if (to_device) {
+  if (to_device) {
     const bool in_place = fused_rerank && whole;                // (the fused re-rank wrote into the caller's buffers)
     if (!in_place)
       LANE_HIP(hipMemcpyAsync(d_ids_user + (size_t)ln.q0 * e->k, e->d_ids_out + (size_t)ln.q0 * e->k, (size_t)ln.nq * e->k * sizeof(uint64_t),

@@ -804,14 +804,6 @@ int upload_index(bang_engine* e, const uint8_t* h_codes, const void* d_codes_ext
   HIP_TRY(hipMemcpy(e->d_centroid, centroid, (size_t)D * 4, hipMemcpyHostToDevice));
   BANG_TRY(dmalloc(&e->d_chunk_off, m + 1));
   HIP_TRY(hipMemcpy(e->d_chunk_off, chunk_off, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
-  if (e->psz) {                                          // which dimension sits at position i of the padded, chunk-packed query layout (center_queries_kernel)
-    std::vector<int32_t> dm((size_t)e->mp * e->psz, -1);
-    for (uint32_t c = 0; c < m; ++c)
-      for (uint32_t i = 0; i < e->psz; ++i)
-        if (chunk_off[c] + i < chunk_off[c + 1]) dm[(size_t)c * e->psz + i] = (int32_t)(chunk_off[c] + i);
-    BANG_TRY(dmalloc(&e->d_dimmap, dm.size()));
-    HIP_TRY(hipMemcpy(e->d_dimmap, dm.data(), dm.size() * 4, hipMemcpyHostToDevice));
-  }
   // 2-float layouts whose chunks are 2,..,2,1,..,1 dims wide also get the exact-size table (if a kernel instance exists for it);
   // bang_alloc picks it when only it leaves room for the persistent kernel's merge scratch at the requested L
   e->pq_nhi = 0; e->pq_nhi_avail = 0;
@@ -937,7 +929,6 @@ void unload_index(bang_engine* e) {
   e->pq_nhi = e->pq_nhi_avail = 0;
   dfree(e->d_centroid);
   dfree(e->d_chunk_off);
-  dfree(e->d_dimmap);
   dfree(e->d_seed);
   dfree(e->d_medoid_vec);
   dfree(e->d_graph);

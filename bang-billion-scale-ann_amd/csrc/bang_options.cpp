@@ -56,11 +56,6 @@ static const OptionDef kOptions[] = {
     {"numa", "BANG_NUMA", &bang_engine::numa_opt, -1, 1, INT, BEFORE_ALLOC, "1 = pin walker threads to the GPU's NUMA node, one physical core each; 0 / -1 = leave them to the scheduler"},
     {"timing", "BANG_TIMING", &bang_engine::timing, 0, 1, INT, BEFORE_ALLOC, "1 = stamp every search / front launch in-kernel (s_memrealtime) for bang_get_stats"},
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
-    {"fold_k1", "BANG_FOLD_K1", &bang_engine::fold_k1, -1, 1, INT, ANY,
-     "self-paced search kernel: 1 / -1 (auto) = the wave that takes a query centres it itself (K1 inside the search launch), 0 = a K1 launch in front.  Same results"},
-    {"direct_io", "BANG_DIRECT_IO", &bang_engine::direct_io, -1, 1, INT, ANY,
-     "self-paced search kernel with fused re-rank, whole-batch queries: 1 / -1 (auto) = the kernel reads the raw queries from and writes ids / distances to mapped "
-     "pinned host memory itself (no H2D / D2H copies, no K1 launch around the search launch), 0 = copies.  Same results"},
     {"fuse_rerank", "BANG_FUSE_RERANK", &bang_engine::fuse_rerank, -1, 1, INT, ANY,
      "self-paced search kernel, 8-bit vectors resident in HBM: 1 / -1 (auto) = the wave that finishes a query re-ranks it on the spot (K6 + K7 inside the search launch), "
      "0 = a re-rank launch behind the search.  Same results"},

@@ -47,7 +47,7 @@
 
 struct SearchArgs;
 // A kernel-argument field read WHERE IT IS USED (a scalar load from the kernarg segment through a pointer the optimiser cannot see through),
-// for arguments that are needed once per query (K1 at its start, the re-rank at its end): read the ordinary way they are loop-invariant, get
+// for arguments that are needed once per query (the seed list at its start, the counters and the re-rank at its end): read the ordinary way they are loop-invariant, get
 // hoisted out of the search loop and occupy scalar registers the loop has none to spare of (106 of 106: they spill into VGPR lanes).
 template <class T>
 __device__ __forceinline__ T karg_at(size_t off) {
@@ -521,32 +521,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 #pragma unroll
   for (int r = 0; r < NV; ++r) qc.v[r] = 0.0f;
   auto load_qc = [&](uint32_t qq) {
-    const int32_t* dimmap = HOST ? nullptr : KARG(d_dimmap);
-    if (!HOST && dimmap) {
-      // K1 here (populate_pqDist_par :1099-1113: centre the query, chunk by chunk): position i of the padded layout holds dimension dimmap[i]
-      // (or nothing: -1); the raw element comes from device memory or straight from the caller's batch in mapped pinned host memory
-      const float* centroid = KARG(d_centroid);
-      const void* qraw = KARG(d_qraw);
-      const uint32_t q_dim = KARG(q_dim), q_dtype = KARG(q_dtype);
-      const size_t qoff = (size_t)qq * q_dim;
-#pragma unroll
-      for (int r = 0; r < NV; ++r) {
-        const uint32_t i = QC16 ? (uint32_t)r * 16u + ((uint32_t)lane & 15u) : (uint32_t)r * 64u + (uint32_t)lane;
-        const int j = dimmap[i < (uint32_t)QW ? i : 0u];
-        float v = 0.0f;
-        if (i < (uint32_t)QW && j >= 0) {
-          float qv = 0.0f;                                            // MIPS: the last dimension of the query is the zero pad (:1099-1113)
-          if ((uint32_t)j < q_dim) {
-            if (q_dtype == BANG_F32) qv = ((const float*)qraw)[qoff + (uint32_t)j];
-            else if (q_dtype == BANG_I8) qv = (float)((const int8_t*)qraw)[qoff + (uint32_t)j];
-            else qv = (float)((const uint8_t*)qraw)[qoff + (uint32_t)j];
-          }
-          v = qv - centroid[j];
-        }
-        qc.v[r] = v;
-      }
-      return;
-    }
     const float* src = p.d_qc + (size_t)qq * QW;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
@@ -1089,8 +1063,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (p->Q == 0) return BANG_OK;
   if (p->R == 0 || p->R > BANG_MAX_R || p->L == 0 || p->L > BANG_MAX_L || p->m == 0) { bang_set_error("bad R/L/m"); return BANG_ERR_ARG; }
   if (p->psz == 0 || p->mp < p->m || (p->mp & 3u)) { bang_set_error("the search kernel needs the LDS-resident pivot layout"); return BANG_ERR_UNSUPPORTED; }
-  if (p->d_dimmap && (!p->d_graph || !p->d_centroid || !p->d_qraw || p->q_dim == 0 || p->q_dtype > BANG_F32)) { bang_set_error("folded K1: bad arguments"); return BANG_ERR_ARG; }
-  if (!p->d_codes || !p->d_pivots_packed || (!p->d_qc && !p->d_dimmap) || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
+  if (!p->d_codes || !p->d_pivots_packed || !p->d_qc || !p->d_seed || !p->d_bloom || !p->d_cand_ids || !p->d_cand_cnt ||
       !p->d_next_query) { bang_set_error("null buffer"); return BANG_ERR_ARG; }
   if (!p->d_graph && (!p->d_rows || !p->d_ctl || !p->h_done || !p->h_parents || (p->ship_vectors && (!p->h_pub_q || !p->h_pub_c)))) {
     bang_set_error("host-paced search kernel: null pacing buffer"); return BANG_ERR_ARG;

@@ -199,8 +199,6 @@ typedef struct {
   uint64_t rows_from_peer;    /* pull mode with peer rows: expansions of the last batch whose adjacency row came from ANOTHER GPU's HBM (over xGMI) */
   uint64_t rows_from_own_hbm; /* ... from this GPU's own HBM copy / slice */
   uint64_t walker_rows;       /* host-paced search kernel: 1 = the walker threads read the 256-byte pull rows (option "walker"), not graph entries */
-  uint64_t k1_folded;         /* 1: K1 (query centring) ran inside the search launch, no bang_k_center_queries launch in front */
-  uint64_t direct_io;         /* 1: the search launch read the raw queries from and wrote ids / distances to mapped pinned host memory itself (no H2D / D2H copies) */
   uint64_t rerank_fused;      /* 1: K6 + K7 ran inside the search launch (the wave that finished a query re-ranked it), no re-rank launch followed */
 } bang_stats;
 int bang_get_stats(bang_engine_t* e, bang_stats* out);
@@ -395,13 +393,6 @@ typedef struct {
    * rr_vec_stride, stable rank by (distance, expansion order) -- and writes the query's k results; no second launch behind the search, and
    * the re-rank of all but the last queries runs under the search of the others.  rr_queries == NULL: not fused (bang_k_rerank* follows).
    * Needs D % 16 == 0, D <= 256, D / 16 a power of two, rr_vec_stride % 4 == 0 (bang_search_can_rerank).  Same bits as bang_k_rerank. */
-  /* K1 FOLDED into the launch (populate_pqDist_par's query centring :1099-1113; self-paced form): the wave that takes a query computes its
-   * centred, chunk-packed form itself -- qc[i] = float(query[dim(i)]) - centroid[dim(i)] for the padded position i, 0 where dim(i) < 0 or the
-   * dimension is the MIPS pad -- instead of reading d_qc; no bang_k_center_queries launch in front.  d_dimmap == NULL: d_qc is read. */
-  const int32_t* d_dimmap;             /* [mp * psz] dimension of padded position i, or -1 */
-  const float* d_centroid;             /* [D] */
-  const void* d_qraw;                  /* raw queries of THIS launch [Q][q_dim] (element type q_dtype) -- device memory, or mapped pinned host memory */
-  uint32_t q_dtype, q_dim;
   const void* rr_queries;              /* [rr_Q_total][D] raw queries (u8 / i8), row rr_q0 + q belongs to this launch's query q */
   const uint8_t* rr_vec_base;
   uint64_t rr_vec_stride;

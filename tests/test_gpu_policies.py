@@ -113,37 +113,3 @@ def test_fused_rerank_short_logs_many_lanes_and_big_k(libbang, small_u8):
         finally:
             os.environ.pop("BANG_SEARCH_MAX_WGS", None)
         assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), (k, L, lanes)
-
-
-@pytest.mark.parametrize("fold,direct", [(1, 1), (1, 0), (0, 0)])
-@pytest.mark.parametrize("graph", [0, 1])
-@pytest.mark.parametrize("fixture", ["small_u8", "small_i8", "small_f32", "small_deep"])
-def test_folded_k1_and_direct_io_match_oracle(request, libbang, fixture, graph, fold, direct):
-    """What surrounds the search launch never changes results: K1 (populate_pqDist_par's query centring, bang_search.cu:1099-1113) by the wave that
-    takes the query instead of a launch in front (fold_k1), and -- 8-bit vectors -- the kernel reading the raw queries from / writing ids and
-    distances to mapped pinned host memory itself instead of H2D / D2H copies (direct_io).  Same bits as the oracle, per query."""
-    import bang_amd
-    from oracle import oracle as O
-    ix, q, _, _ = request.getfixturevalue(fixture)
-    Q = q.shape[0]
-    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 48, with_stats=True)
-    with bang_amd.Engine(ix.dtype, graph=graph, search=1, fold_k1=fold, direct_io=direct) as e:
-        e.load_index(ix)
-        e.set_searchparams(10, 48)
-        e.alloc(Q)
-        for rep in range(2):
-            e.init(Q)
-            ids, dists = e.query(q if rep == 0 else np.ascontiguousarray(q[::-1]))
-            st = e.stats()
-            assert st["k1_folded"] == fold, st
-            assert st["direct_io"] == (1 if (direct and fold and ix.dtype != "float") else 0), st
-            if rep == 0:
-                assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
-                assert np.array_equal(e.query_counters(Q), st_o)
-            else:                                                   # a second, different batch through the same pinned mirrors
-                assert np.array_equal(ids, ids_o[::-1]) and np.array_equal(dists.view(np.uint32), dists_o[:, ::-1].view(np.uint32))
-        # a smaller batch than the allocation: the [k][Q] distance block keeps its stride = the batch's Q
-        e.init(Q - 5)
-        ids, dists = e.query(np.ascontiguousarray(q[: Q - 5]))
-        assert np.array_equal(ids, ids_o[: Q - 5]) and np.array_equal(dists.view(np.uint32), dists_o[:, : Q - 5].view(np.uint32))
-        e.free(); e.unload()
