@@ -514,7 +514,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   // once per query instead of streamed through scalar loads in every iteration's distance stage
   constexpr int QW = NDW * 4 * PSZ;
   // the self-paced long-row instances (168 VGPRs) keep the query replicated per 16-lane row: "pivot - query" is then one DPP instruction
-  constexpr bool QC16 = !HOST && NDW == 18 && NHI != 0 && ALIGNED;   // (the one long-row instance whose register budget holds it: profiles/r05_kernel_usage.md)
+  constexpr bool QC16 = !HOST && ((NDW == 18 && NHI != 0) || NDW == 19);   // (the BASELINE long-row layouts: the instances whose register budget holds it, profiles/r05_kernel_usage.md)
   constexpr int NV = QC16 ? (QW + 15) / 16 : (QW + 63) / 64;
   typedef typename std::conditional<QC16, QcRow16<NV>, QcRegs<NV>>::type Qc;
   Qc qc;
