@@ -63,8 +63,20 @@ class DeviceGather:
         return self.dists.cpu().numpy()
 
     def batch_ids(self) -> np.ndarray:
-        """[Q][k] u64 on the host, from the gathered block (one D2H copy)."""
-        allv = self.all.cpu().numpy().view(np.uint64)
+        """[Q][k] u64 on the host, from the gathered block: ONE D2H copy into a pinned buffer allocated once; where the shards are even
+        (Q divisible by the rank count: the gathered block IS [Q][k]) the result is a view of that buffer, valid until the next call."""
+        import torch
+        if getattr(self, "_host", None) is None:
+            pin = self.all.is_cuda
+            self._host = torch.empty(self.all.shape, dtype=torch.int64, pin_memory=pin)
+        if self.all.is_cuda:
+            self._host.copy_(self.all, non_blocking=True)
+            torch.cuda.current_stream(self.all.device).synchronize()
+        else:
+            self._host.copy_(self.all)
+        allv = self._host.numpy().view(np.uint64)
+        if self.pad * self.world == self.Q:
+            return allv
         out = np.empty((self.Q, self.k), dtype=np.uint64)
         for r in range(self.world):
             a, b = shard_range(self.Q, r, self.world)

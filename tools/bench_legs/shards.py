@@ -11,8 +11,9 @@ from .common import check_properties, leg_summary, log, measure
 
 def gather_ms_world1(ctx, Q, k, reps=20):
     """The job's ONE collective -- all_gather_into_tensor of the [Q / W][k] int64 id blocks from device buffers (bang_amd/shard.py) -- executed
-    by RCCL with ONE rank: what the call itself costs (launch + completion), the floor of its cost on W ranks (the xGMI transfer of
-    <= 100 KB per rank is a few microseconds on top).  Returns (ms, note)."""
+    by RCCL with ONE rank, followed by what rank 0 of the N > 1 job does with it (one D2H copy of the [Q][k] block): what the tail of a
+    sharded step costs (launch + completion + copy), the floor of its cost on W ranks (the xGMI transfer of <= 100 KB per rank is a few
+    microseconds on top).  Returns (ms, note)."""
     import torch
     import torch.distributed as dist
     from bang_amd import shard
@@ -26,13 +27,15 @@ def gather_ms_world1(ctx, Q, k, reps=20):
         dg = shard.DeviceGather(Q, k, 0, 1, ctx.dev, coll_device=ctx.dev)
         for _ in range(3):
             dg.gather()
+            dg.batch_ids()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             dg.gather()
-            torch.cuda.synchronize()
+            dg.batch_ids()                                   # (rank 0 of the N > 1 job copies the gathered [Q][k] block to the host: part of its step)
         ms = 1e3 * (time.perf_counter() - t0) / reps
-        return round(ms, 4), "RCCL all_gather_into_tensor from device buffers, world size 1, launch to completion (mean of %d)" % reps
+        return round(ms, 4), ("RCCL all_gather_into_tensor from device buffers + the D2H copy of the gathered [Q][k] block, world size 1, "
+                              "launch to completion (mean of %d)" % reps)
     except Exception as ex:                                  # noqa: BLE001  (no RCCL here: the projection then says so)
         return None, "RCCL gather not measurable here: " + repr(ex)[:160]
     finally:
