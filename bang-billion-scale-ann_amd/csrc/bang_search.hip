@@ -622,7 +622,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         evals = 0; fetched = 0; iter = 1;
         mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
-        if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride] = medoid;
+        if (lane == 0) KARG(d_cand_ids)[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
         { const uint32_t* seed = KARG(d_seed); cnt_in = seed[0]; x0 = seed[1 + lane]; x1 = seed[65]; }
@@ -657,9 +657,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
       // a row that names a node the index does not have (rows overwritten behind the engine's back: the self-paced form has no host
       // thread that could notice) is not followed: the batch ends with BANG_ERR_HIP instead of a wild read of the code table
-      if (!HOST && p.n_nodes != 0u) {
-        if (__ballot((uint32_t)lane < ci && x0 >= p.n_nodes) != 0ull) {
-          if (lane == 0 && p.d_abort) *p.d_abort = 2u;
+      const uint32_t n_nodes = HOST ? 0u : KARG(n_nodes);
+      if (!HOST && n_nodes != 0u) {
+        if (__ballot((uint32_t)lane < ci && x0 >= n_nodes) != 0ull) {
+          if (lane == 0 && KARG(d_abort)) *KARG(d_abort) = 2u;
           ci = 0;
         }
       }
@@ -710,8 +711,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      if (COOP && EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-      else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, p.d_codes, code_stride, sid0);
+      const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
+      if (COOP && EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
-        if (COOP && !EARLY_ROWS) cf.issue(p.d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+        if (COOP && !EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
         if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if (EARLY_ROWS) {
           // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
@@ -762,20 +764,20 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if ((uint32_t)lane < n) d0 = dd;
           if (n > 64) {                                        // survivor 64 (seed list only): every lane reduces that row, lane 0's counts
             PqRow<NDW, ALIGNED> r1;
-            pq_row_load(r1, p.d_codes, code_stride, uni(sid1));
+            pq_row_load(r1, d_codes, code_stride, uni(sid1));
             const float d1v = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
             if (lane == 0) d1 = d1v;
           }
         } else {
           if ((uint32_t)lane < n) {
-            if (!COOP && !EARLY_ROWS) pq_row_load(row, p.d_codes, code_stride, sid0);
+            if (!COOP && !EARLY_ROWS) pq_row_load(row, d_codes, code_stride, sid0);
             d0 = !HOST ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
                        : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
           }
           if (n > 64) {                                          // survivor 64 (seed list only), lane 0
             if (lane == 0) {
               PqRow<NDW, ALIGNED> r1;
-              pq_row_load(r1, p.d_codes, code_stride, sid1);
+              pq_row_load(r1, d_codes, code_stride, sid1);
               d1 = pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(r1, piv_lds, qc);
             }
           }
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       parent = uni(parent);
       if (found) {
         if (from_best) mark = parent;
-        if (lane == 0) p.d_cand_ids[(size_t)q * cand_stride + cc] = parent;      // :1451-1458
+        if (lane == 0) KARG(d_cand_ids)[(size_t)q * cand_stride + cc] = parent;      // :1451-1458
         ++cc;
       }
     }
@@ -827,20 +829,22 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // graph resident in HBM: the next adjacency row is requested NOW, straight into the registers the next iteration reads (no copy at the
       // loop's end that would wait for it); it travels while the survivors are merged
       if (want_row) {
-        if (p.row_layout) {                                  // adjacency rows (pinned host memory, pull mode): 64 ids, padded
+        const uint8_t* gbase = KARG(d_graph);                // (the hand-over's arguments are read here, once per iteration: KARG)
+        if (KARG(row_layout)) {                              // adjacency rows (pinned host memory, pull mode): 64 ids, padded
           // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those.  Peer rows
           // (n_slices > 1): slice parent / slice_rows of the node's HBM-resident rows -- this GPU's HBM or a peer's over xGMI; the table
           // holds biased base addresses (0: that slice is not there), read through the scalar cache
           const uint32_t* hb = nullptr;
-          if (p.n_slices > 1u) {
-            const uint32_t sl = parent / p.slice_rows;                       // (uniform: scalar)
-            if (sl < p.n_slices) hb = (const uint32_t*)(uintptr_t)p.d_row_slices[sl];
-          } else if (parent < p.n_rows_hbm) hb = p.d_rows_hbm;
+          const uint32_t nsl = KARG(n_slices);
+          if (nsl > 1u) {
+            const uint32_t sl = parent / KARG(slice_rows);                   // (uniform: scalar)
+            if (sl < nsl) hb = (const uint32_t*)(uintptr_t)KARG(d_row_slices)[sl];
+          } else if (parent < KARG(n_rows_hbm)) hb = KARG(d_rows_hbm);
           if (hb) x0 = hb[(uint64_t)parent * 64u + lane];
-          else x0 = __builtin_nontemporal_load((const uint32_t*)p.d_graph + (uint64_t)parent * 64u + lane);
+          else x0 = __builtin_nontemporal_load((const uint32_t*)gbase + (uint64_t)parent * 64u + lane);
           cnt_in = 64u;                                      // counted when the row is consumed
         } else {
-          const uint32_t* nrow = (const uint32_t*)(p.d_graph + (uint64_t)parent * p.entry_len + p.vec_bytes);
+          const uint32_t* nrow = (const uint32_t*)(gbase + (uint64_t)parent * KARG(entry_len) + KARG(vec_bytes));
           cnt_in = nrow[0];
           x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
         }
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           if (rr.queries) {                                                    // K6 + K7 on the spot (uniform)
             rr.vec_base = KARG(rr_vec_base); rr.vec_stride = KARG(rr_vec_stride); rr.ids_out = KARG(rr_ids_out); rr.dists_out = KARG(rr_dists_out);
             rr.D = KARG(rr_D); rr.k = KARG(rr_k); rr.q0 = KARG(rr_q0); rr.Q_total = KARG(rr_Q_total);
-            rr.cand = p.d_cand_ids + (size_t)q * cand_stride;
+            rr.cand = KARG(d_cand_ids) + (size_t)q * cand_stride;
             const uint32_t nc = cc < cand_stride ? cc : cand_stride;
             if (KARG(rr_dtype) == BANG_I8) wave_rerank8<true>(rr, q, nc, wbase, lane);
             else wave_rerank8<false>(rr, q, nc, wbase, lane);
