@@ -26,8 +26,10 @@
 //
 //  * A launch of at most 5 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of every iteration and
 //    a lightly loaded chip is not short of requests); an adjacency id >= N is never followed (n_nodes: the batch ends with an error
-//    instead of a wild read).  Experiments that measured no faster (K2 pool, half-word summary, ...) live in git history and
-//    docs/HISTORY.md, not here.
+//    instead of a wild read).  Experiments that measured no faster live in git history and docs/HISTORY.md, not here.
+//  * Round 5: K6 + K7 by the wave that finishes a query (wave_rerank8, bang_device.h: 8-bit vectors); the query replicated per 16-lane row
+//    for the BASELINE long-row layouts (QcRow16: "pivot - query" is one DPP instruction); peer rows (a table of HBM slices of the adjacency
+//    rows, this GPU's or a peer's over xGMI); arguments a query needs once read from the kernarg segment where they are used (KARG).
 //
 // Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
 // canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
