@@ -58,6 +58,8 @@ def main():
                 if key.startswith("BANG_"):              # an environment switch (read when used; dropped again behind the variant)
                     os.environ[key] = val
                     env_set.append(key)
+                elif key == "rows_frac":                 # this fraction of the adjacency rows in HBM (bang_rows_slice_e: rows [0, frac N)) -- what peer rows
+                    eng.rows_slice(0, int(float(val) * wl["ix"].N))          # give a rank of a W-GPU node, with local HBM standing in for the peers'
                 else:
                     eng.set_option(key, int(val))
             eng.set_searchparams(ctx.k, L)
