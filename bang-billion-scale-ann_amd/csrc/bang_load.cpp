@@ -304,6 +304,13 @@ static const size_t kRowsKeepBack = (size_t)6 << 30;     // HBM left to the per-
 }  // namespace bang
 using namespace bang;
 
+extern "C" int bang_get_num_nodes(bang_engine_t* e, uint64_t* nodes_out) {
+  if (!e || !nodes_out) return BANG_ERR_ARG;
+  if (!e->loaded) { bang_set_error("bang_get_num_nodes: no index is loaded"); return BANG_ERR_ARG; }
+  *nodes_out = e->N;
+  return BANG_OK;
+}
+
 extern "C" int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out) {
   if (!e || !rows_out) return BANG_ERR_ARG;
   if (!e->loaded || !e->pull || !e->h_adj) { bang_set_error("peer rows: the index is not loaded in pull mode"); return BANG_ERR_ARG; }

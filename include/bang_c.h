@@ -135,6 +135,7 @@ int bang_get_rows_hash(bang_engine_t* e, uint64_t* out);
  * bang_rows_slice_e replaces the default copy (rows [0, auto)); rows = 0 drops it.  A slice that has been exported is never freed before
  * bang_unload (bang_alloc does not take it back when HBM is short: BANG_ERR_NOMEM instead). */
 #define BANG_MAX_ROW_SLICES 16
+int bang_get_num_nodes(bang_engine_t* e, uint64_t* nodes_out);    /* N of the loaded index (the reference reads it from <p>_disk_metadata.bin, bang_search.cu:176-189) */
 int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out);   /* rows of 256 B this engine's free HBM holds now (6 GB kept back for the batch state) + what its row copy holds */
 int bang_rows_slice_e(bang_engine_t* e, uint64_t first_row, uint64_t rows);
 int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* first_row, uint64_t* rows);

@@ -48,3 +48,32 @@ def test_file_flow_recall_column_equals_the_oracles(libbang, tmp_path):
         assert max(rec for L, _a, _b, rec in rows if L <= 70) >= 90.0
         seen += 1
     assert seen >= 1
+
+
+def test_multi_gpu_harness_on_the_c_abi(libbang, tmp_path, small_u8):
+    """bin/bang_search_multi: the harness over several GPUs of a node, written on the C-ABI alone -- one PROCESS per GPU, one shared rows file,
+    PEER ROWS (each rank's HBM slice exported / imported as a hipIpcMemHandle through a shared-memory mailbox), the shards' ids in one shared
+    [Q][k] block.  Here both ranks run on GPU 0 (`share`).  The printed recall is the oracle's for the same files, rows did come from the
+    sibling's allocation, and -- with the slices cut short -- from host memory too."""
+    import bang_amd
+    from bang_amd import formats
+    from oracle import oracle as O
+    ix, q, gt_i, gt_d = small_u8
+    prefix = str(tmp_path / "multi")
+    formats.write_index(prefix, ix)
+    formats.write_bin(prefix + "_query.bin", q)
+    formats.write_truthset(prefix + "_gt.bin", gt_i, gt_d)
+    ids_o, _ = O.Oracle(ix).search(q, 10, 48)
+    want = O.recall(gt_i, gt_d, ids_o, 10)
+    exe = os.path.join(os.path.dirname(os.path.dirname(bang_amd.lib_path())), "bin", "bang_search_multi")
+    args = [exe, prefix, prefix + "_query.bin", prefix + "_gt.bin", str(q.shape[0]), "10", "uint8", "48", "2", "share"]
+    for slice_rows, host_expected in ((None, False), (str(ix.N // 3), True)):
+        env = dict(os.environ)
+        env.pop("BANG_PULL_ROWS_DIR", None)
+        r = subprocess.run(args + ([f"slice={slice_rows}"] if slice_rows else []), capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        line = [l for l in r.stdout.splitlines() if l and l[0].isdigit()][-1].split("\t")
+        assert int(line[0]) == 2 and int(line[1]) == 48
+        assert abs(float(line[4]) - want) < 0.006, (line, want)
+        own, peer, host = (int(x) for x in line[5].split("/"))
+        assert own > 0 and peer > 0 and (host > 0) == host_expected, line
