@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "file_flow"))
     ap.add_argument("--graph", default="host")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--ranks", type=int, default=2, help="ranks of the bang_search_multi run (all on this box's GPU); 1 = skip it")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -103,6 +104,16 @@ def main():
         open(os.path.join(a.out, f"{name}_table.txt"), "w").write("$ BANG_GRAPH=" + a.graph + " " + os.path.basename(binary) + " " + " ".join(args) + "\n" + r.stdout + r.stderr[-2000:])
         rows = table(r.stdout)
         res[name] = {"rc": r.returncode, "wall_s": round(wall, 1), "rows": len(rows), "first_L_with_90": summarise(rows)}
+    # the same files through the multi-GPU harness on the C-ABI (two ranks sharing this box's GPU: one process each, one rows file, peer rows
+    # over hipIpc handles) at the L the single-GPU table reached 90 % with
+    multi = os.path.join(ROOT, "bang-billion-scale-ann_amd", "bin", "bang_search_multi")
+    first = (res.get("bang_search") or {}).get("first_L_with_90")
+    if os.path.exists(multi) and first and a.ranks > 1:
+        margs = [prefix, prefix + "_query.bin", prefix + "_gt.bin", str(a.queries), "10", "uint8", str(first["L"]), str(a.ranks), "share"]
+        r = subprocess.run([multi] + margs, capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "BANG_PULL_ROWS_DIR"}, timeout=3000)
+        open(os.path.join(a.out, "bang_search_multi_table.txt"), "w").write("$ bang_search_multi " + " ".join(margs) + "\n" + r.stdout + r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l[:1].isdigit()]
+        res["bang_search_multi"] = {"rc": r.returncode, "ranks_on_one_gpu": a.ranks, "line": line[-1].split("\t") if line else None}
     res["tables_identical_recall_column"] = ("rows" in res.get("bang_search", {}) and "rows" in res.get("ref_bang_search", {}) and
                                              [(r[0], r[3]) for r in table(open(os.path.join(a.out, "bang_search_table.txt")).read())] ==
                                              [(r[0], r[3]) for r in table(open(os.path.join(a.out, "ref_bang_search_table.txt")).read())])
