@@ -180,8 +180,9 @@ int run_anns(int argc, char** argv) {
         std::cout << "Groundtruth file could not be loaded:" << argv[3] << std::endl;
         exit(1);
       }
-      const double recall = calculate_recall((unsigned)numQueries, gt_ids.data(), gt_dists.data(), (unsigned)gt_dim,
-                                             ids.data(), (unsigned)k, (unsigned)k);
+      // (a float, as in the reference (:506): its double -> float step decides the second decimal at x.xx5 -- 88.535 prints as 88.54)
+      const float recall = (float)calculate_recall((unsigned)numQueries, gt_ids.data(), gt_dists.data(), (unsigned)gt_dim,
+                                                   ids.data(), (unsigned)k, (unsigned)k);
       std::cout.setf(std::ios_base::fixed, std::ios_base::floatfield);
       std::cout.precision(2);
       std::cout << L << "\t" << wall << "\t" << qps << "\t" << recall << std::endl;   // (:526)

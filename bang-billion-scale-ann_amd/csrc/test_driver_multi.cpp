@@ -213,7 +213,7 @@ int main(int argc, char** argv) {
   if (own_dir) { std::string cmd = std::string("rm -rf ") + dir; (void)!system(cmd.c_str()); }
   if (bad || sh->failed.load()) { fprintf(stderr, "bang_search_multi: a rank failed\n"); return 1; }
   const double ms = sh->ms[BANG_MAX_ROW_SLICES - 1];
-  const double recall = recall_of(gt_ids, gt_d, (size_t)gw, all_ids, Q, k);
+  const float recall = (float)recall_of(gt_ids, gt_d, (size_t)gw, all_ids, Q, k);      // (a float, as the reference harness prints it: test_driver.cpp:506)
   uint64_t peer = 0, own = 0, pulled = 0;
   for (uint32_t r = 0; r < W; ++r) { peer += sh->from_peer[r]; own += sh->from_own[r]; pulled += sh->pulled[r]; }
   printf("GPUs\tL\tTime \tQPS\t\t%u-r@%u\trows: own HBM / peer HBM / host\n", k, k);
