@@ -19,11 +19,16 @@ def test_bench_measures_hbm_traffic_in_the_same_run(libbang):
     if shutil.which("rocprofv3") is None:
         pytest.skip("rocprofv3 not installed")
     cmd = [sys.executable, "bench.py", "--workload", "small", "--L", "46", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--legs", "none"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     rf = d["roofline"]
-    assert "measured in THIS run" in rf["traffic_note"], rf.get("traffic_note")
+    if "did not finish" in str(rf.get("traffic_note")):            # (a cold box: the profiled child had to page the whole stack in; once more, warm)
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        rf = d["roofline"]
+    assert "measured in THIS run" in str(rf.get("traffic_note")), (rf.get("traffic_note"), r.stderr[-1500:])
     # every evaluation reads its code row and writes a distance: the HBM-side bytes cannot be fewer than ... well, they can be served by
     # L2 on a 100 K-point index; what must hold is that the counters saw the launches (> 0) and stay within a sane multiple
     assert 0 < rf["traffic"] < 200 * rf["algorithmic_bytes_per_launch"]

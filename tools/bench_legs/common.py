@@ -364,6 +364,8 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
                                 + (f" ({live['note']})" if live and not live.get("bytes") else ""))
             except Exception:
                 traffic = None
+        elif live and not live.get("bytes"):
+            traffic_note = "HBM traffic not measured in this run: " + str(live.get("note"))      # (why the live PMC passes gave nothing)
         # scalars first (the driver's record keeps the leading scalars of an object), prose and nested objects behind them
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,

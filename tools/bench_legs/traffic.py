@@ -45,11 +45,11 @@ def live_traffic(args, log):
             pr = subprocess.Popen(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
                                   cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                so, _ = pr.communicate(timeout=120)                 # (a pass takes ~30 s; the run must stay within minutes whatever the profiler does)
+                so, _ = pr.communicate(timeout=180)                 # (a pass takes ~30 s -- up to two minutes more on a box that has never imported torch; the run stays within minutes whatever the profiler does)
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, signal.SIGKILL)            # (the session this call started: nothing else is in it)
                 pr.communicate()
-                return {"bytes": None, "note": f"PMC pass {tag} did not finish in 120 s"}
+                return {"bytes": None, "note": f"PMC pass {tag} did not finish in 180 s"}
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for r in csv.DictReader(open(f[0]))] if f else []
             sel = [r for r in rows if "search_kernel" in r["Kernel_Name"]]
