@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.timeout(1500, method="thread")
 def test_bench_measures_hbm_traffic_in_the_same_run(libbang):
     if shutil.which("rocprofv3") is None:
         pytest.skip("rocprofv3 not installed")
@@ -23,7 +24,7 @@ def test_bench_measures_hbm_traffic_in_the_same_run(libbang):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     rf = d["roofline"]
-    if "did not finish" in str(rf.get("traffic_note")):            # (a cold box: the profiled child had to page the whole stack in; once more, warm)
+    if "measured in THIS run" not in str(rf.get("traffic_note")):   # (a cold box: the profiled child had to page the whole stack in and ran out of its time; once more, warm)
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
