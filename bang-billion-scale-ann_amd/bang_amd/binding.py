@@ -89,14 +89,29 @@ def lib_path() -> str:
     return _LIB
 
 
+def _newer(target: str, sources) -> bool:
+    return (not os.path.exists(target)) or any(os.path.getmtime(x) > os.path.getmtime(target) for x in sources)
+
+
 def build(force: bool = False) -> str:
-    """Compile libbang.so + bang_search for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
-    srcs += [os.path.join(_PKG, "..", "include", f) for f in ("bang.h", "bang_c.h")]
-    stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
-    if (force or stale) and not os.environ.get("BANG_AMD_LIB"):
-        if os.environ.get("BANG_NO_BUILD"):          # a profiled child must never start a compiler (bench.py build_everything)
+    """Compile libbang.so + bang_search + bang_search_multi for gfx950 (hipcc cross-compiles without a GPU).  What is stale is decided the
+    way the Makefile decides it: the library against ITS sources (kernels, engine, headers), each harness against its own source and the
+    library -- a harness edited after the last build must not make the library look stale (a profiled child, BANG_NO_BUILD, only needs the
+    library and must never start a compiler)."""
+    csrc = os.path.join(_PKG, "csrc")
+    harness = {"bang_search": "test_driver.cpp", "bang_search_multi": "test_driver_multi.cpp"}
+    lib_srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f not in harness.values()]
+    lib_srcs += [os.path.join(_PKG, "..", "include", f) for f in ("bang.h", "bang_c.h")]
+    lib_stale = _newer(_LIB, lib_srcs)
+    bins_stale = any(_newer(os.path.join(_PKG, "bin", exe), [os.path.join(csrc, src)] + ([_LIB] if os.path.exists(_LIB) else []))
+                     for exe, src in harness.items())
+    if os.environ.get("BANG_AMD_LIB"):
+        return _LIB
+    if os.environ.get("BANG_NO_BUILD"):              # a profiled child must never start a compiler (bench.py build_everything)
+        if lib_stale:
             raise RuntimeError(f"{_LIB} is missing or stale and BANG_NO_BUILD is set")
+        return _LIB
+    if force or lib_stale or bins_stale:
         subprocess.check_call(["make", "-C", _PKG, "-s", "-j4"])
     return _LIB
 
