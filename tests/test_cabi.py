@@ -219,3 +219,27 @@ def test_integration_md_carries_the_option_table_verbatim(libbang):
     lib.bang_describe_options(buf, need)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert buf.value.decode().rstrip() in doc
+
+
+def test_a_profiled_child_only_needs_an_up_to_date_library(monkeypatch):
+    """binding.build() under BANG_NO_BUILD (what a bench child under rocprofv3 --pmc runs with: it must never start a compiler) refuses a
+    stale LIBRARY -- but a harness source (csrc/test_driver*.cpp -> bin/*) edited after the last link of libbang.so does not make the library
+    stale (round 5: it did, and every live PMC pass of bench.py failed with rc 1 on the GPU box)."""
+    from bang_amd import binding
+    real = os.path.getmtime
+    newest = {"name": "test_driver.cpp"}
+
+    def fake(p):
+        return 4e9 if os.path.basename(p) == newest["name"] else real(p)
+    monkeypatch.setattr(binding.os.path, "getmtime", fake)
+    monkeypatch.setenv("BANG_NO_BUILD", "1")
+    monkeypatch.delenv("BANG_AMD_LIB", raising=False)
+    assert binding.build() == binding.lib_path()                    # a newer harness source: fine
+    newest["name"] = "test_driver_multi.cpp"
+    assert binding.build() == binding.lib_path()
+    newest["name"] = "bang_lane.cpp"                                # a newer ENGINE source: the library is stale
+    with pytest.raises(RuntimeError, match="stale"):
+        binding.build()
+    newest["name"] = "bang_c.h"
+    with pytest.raises(RuntimeError, match="stale"):
+        binding.build()
