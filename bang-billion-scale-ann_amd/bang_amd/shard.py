@@ -89,26 +89,66 @@ def share_rows(eng, rank: int, world: int, n_nodes: int, group=None, slice_rows:
     HBM its index left over -- rank r the rows [r n, (r + 1) n), n = the smallest capacity among the ranks (or `slice_rows`) -- exports it
     (hipIpcGetMemHandle), the 64-byte handles travel through ONE all_gather_object of the job's process group, and every rank maps the W - 1
     others (hipIpcOpenMemHandle).  The search kernel then reads a parent's row from slice parent / n: its own HBM, a peer's over xGMI, or --
-    beyond W n rows -- pinned host memory over PCIe as before.  Returns {"slice_rows", "rows_in_node_hbm", "fraction"}."""
+    beyond W n rows -- pinned host memory over PCIe as before.  Returns {"slice_rows", "rows_in_node_hbm", "fraction"}.
+
+    Every rank executes the same three collectives whatever happens locally: a failure on one rank (no pull mode, out of HBM, an IPC handle
+    that cannot be opened) travels WITH the collective, every rank then drops its slice table and raises the same error -- no rank is left
+    waiting in a collective the others never reach."""
     import torch.distributed as dist
-    cap = eng.rows_capacity()
-    caps = [None] * world
-    dist.all_gather_object(caps, int(cap), group=group)
-    n = int(slice_rows) if slice_rows else min(caps)
-    n = min(n, (n_nodes + world - 1) // world)              # (W n >= N: the whole graph sits in the node's HBM; no slice larger than needed)
+
+    def gather(x):
+        out = [None] * world
+        dist.all_gather_object(out, x, group=group)
+        return out
+
+    def first_error(items):
+        errs = [f"rank {r}: {it['err']}" for r, it in enumerate(items) if it.get("err")]
+        return errs[0] if errs else None
+
+    # 1. capacities
+    mine = {"err": None, "cap": 0}
+    try:
+        mine["cap"] = int(eng.rows_capacity())
+    except Exception as ex:                                  # noqa: BLE001
+        mine["err"] = repr(ex)[:200]
+    caps = gather(mine)
+    err = first_error(caps)
+    n = 0
+    if not err:
+        n = int(slice_rows) if slice_rows else min(c["cap"] for c in caps)
+        n = min(n, (n_nodes + world - 1) // world)          # (W n >= N: the whole graph sits in the node's HBM; no slice larger than needed)
+    # 2. slice + export
+    mine = {"err": err, "handle": bytes(64), "rows": 0}
+    if not err and n > 0:
+        try:
+            first = min(rank * n, n_nodes)
+            eng.rows_slice(first, max(0, min(n, n_nodes - first)))
+            h, _, rows = eng.rows_export()
+            mine["handle"], mine["rows"] = h, rows
+        except Exception as ex:                              # noqa: BLE001
+            mine["err"] = repr(ex)[:200]
+    handles = gather(mine)
+    err = first_error(handles)
+    # 3. import, then agree on the outcome
+    mine = {"err": err}
+    if not err and n > 0:
+        try:
+            for r in range(world):
+                if r == rank:
+                    eng.rows_import(r, world, n, None)
+                else:
+                    eng.rows_import(r, world, n, handles[r]["handle"] if handles[r]["rows"] else bytes(64))
+        except Exception as ex:                              # noqa: BLE001
+            mine["err"] = repr(ex)[:200]
+    err = first_error(gather(mine))
+    if err:
+        try:                                                 # (host rows serve everything: results are the same)
+            eng.rows_close_peers()
+        except Exception:                                    # noqa: BLE001
+            pass
+        raise RuntimeError("peer rows: " + err)
     if n <= 0:
         return {"slice_rows": 0, "rows_in_node_hbm": 0, "fraction": 0.0}
-    first = min(rank * n, n_nodes)
-    eng.rows_slice(first, max(0, min(n, n_nodes - first)))
-    handle, _, rows = eng.rows_export()
-    handles = [None] * world
-    dist.all_gather_object(handles, (handle, rows), group=group)
-    for r in range(world):
-        h, rr = handles[r]
-        if r == rank:
-            eng.rows_import(r, world, n, None)
-        else:
-            eng.rows_import(r, world, n, h if rr else bytes(64))
     total = min(n_nodes, world * n)
     return {"slice_rows": n, "rows_in_node_hbm": total, "fraction": total / max(1, n_nodes)}
 

@@ -69,13 +69,15 @@ def test_shard_ranges_cover_the_batch():
 class _FakeEngine:
     """Stands in for bang_amd.Engine in the peer-rows exchange (no GPU here): records what share_rows asks of an engine."""
 
-    def __init__(self, rank, capacity):
-        self.rank, self.capacity, self.slice, self.imports, self.closed = rank, capacity, None, [], False
+    def __init__(self, rank, capacity, fail_slice=False):
+        self.rank, self.capacity, self.slice, self.imports, self.closed, self.fail_slice = rank, capacity, None, [], False, fail_slice
 
     def rows_capacity(self):
         return self.capacity
 
     def rows_slice(self, first, rows):
+        if self.fail_slice:
+            raise RuntimeError("out of device memory (test)")
         self.slice = (first, rows)
 
     def rows_export(self):
@@ -87,6 +89,26 @@ class _FakeEngine:
 
     def rows_close_peers(self):
         self.closed = True
+
+
+def _peer_fail_worker(rank, world, port, out_dir):
+    """rank 1 cannot place its slice: BOTH ranks must come out of share_rows with the same error (no rank left in a collective)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
+    import torch.distributed as dist
+    from bang_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine(rank, 400, fail_slice=(rank == 1))
+    msg = "no error"
+    try:
+        shard.share_rows(eng, rank, world, 1000)
+    except RuntimeError as ex:
+        msg = str(ex)
+    open(os.path.join(out_dir, f"f{rank}.txt"), "w").write(msg + "|" + str(eng.closed))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _peer_worker(rank, world, port, N, caps, out_dir):
@@ -123,3 +145,10 @@ def test_peer_rows_exchange_two_ranks(tmp_path):
             assert sorted(i[0] for i in p["imports"]) == [0, 1] and all(i[1] == 2 and i[2] == n_want for i in p["imports"])
             for slot, _, _, h in p["imports"]:
                 assert (h is None) == (slot == r) and (h is None or h == slot + 1)          # the sibling's handle went into the sibling's slot
+
+
+def test_peer_rows_failure_on_one_rank_reaches_every_rank(tmp_path):
+    mp.spawn(_peer_fail_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg, closed = open(tmp_path / f"f{r}.txt").read().split("|")
+        assert "rank 1" in msg and "out of device memory" in msg and closed == "True", (r, msg)

@@ -476,22 +476,12 @@ def run_config(name, ctx, args, O, *, graph="", pull=-1, L=0, steps=5, warmup=1,
     if ctx.world > 1 and graph != "device" and pull != 0 and not os.environ.get("BANG_BENCH_NO_PEER_ROWS"):
         import torch.distributed as dist
         from bang_amd import shard as _shard
-        ok_t = [None] * ctx.world
-        err = None
-        try:
+        try:                                                 # (share_rows agrees on failure across the ranks by itself: all raise, or none)
             ctx.peer_rows = _shard.share_rows(eng, ctx.rank, ctx.world, int(ix.N), slice_rows=int(os.environ.get("BANG_BENCH_PEER_SLICE_ROWS", "0")))
-        except Exception as ex:                              # noqa: BLE001  (no IPC here, not pull mode ...: host rows serve everything)
-            err = repr(ex)[:200]
-        dist.all_gather_object(ok_t, err)
-        if any(ok_t):
-            log(f"[bench] peer rows not available: {[e_ for e_ in ok_t if e_][0]}")
-            ctx.peer_rows = {"error": [e_ for e_ in ok_t if e_][0]}
-        else:
             log(f"[bench] peer rows: {ctx.peer_rows['slice_rows']} rows per rank, {100 * ctx.peer_rows['fraction']:.1f} % of the adjacency rows in the node's HBM")
-    # N > 1: the shard's ids stay in device memory (bang_query_dev_e) until the collective (BANG_BENCH_HOST_GATHER=1: the r02 host bounce)
-    ctx.dgather = None
-    if (ctx.world > 1 or getattr(ctx, "force_gather", False)) and not weak and not os.environ.get("BANG_BENCH_HOST_GATHER"):
-        ctx.dgather = shard.DeviceGather(Qt, k, ctx.rank, ctx.world, ctx.dev, coll_device=ctx.cdev)
+        except Exception as ex:                              # noqa: BLE001  (no IPC here, not pull mode ...: host rows serve everything)
+            log(f"[bench] peer rows not available: {ex!r}")
+            ctx.peer_rows = {"error": repr(ex)[:200]}
     recall = float("nan")
     if L == 0 and gt_i is not None:
         for cand in range(k, 513, 12):                   # the harness's sweep grid, test_driver.cpp:376-417
