@@ -358,7 +358,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
     s.hops_p50 = cc[cc.size() / 2];
     s.hops_p99 = cc[std::min(cc.size() - 1, (cc.size() * 99) / 100)];
     s.hops_max = cc.back();
-    if (s.graph_pull) {                                  // one row per expansion (the seed list is on the device) ...
+    if (s.graph_pull || e->walker_self) {                // one row per expansion (the seed list is on the device) ...
       uint64_t pulled = s.candidates - (uint64_t)e->Qcur;
       if (e->n_rows_hbm || e->n_slices > 1) {            // ... unless the expanded node's row sits in HBM (this GPU's or a peer's): count the candidate log
         std::vector<uint32_t> ids((size_t)e->Qcur * e->cand_stride);
@@ -369,7 +369,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
         for (size_t q = 0; q < (size_t)e->Qcur; ++q)
           for (uint32_t i = 1; i < cnt[q] && i < e->cand_stride; ++i) {
             const uint32_t id = ids[q * e->cand_stride + i];
-            if (e->n_slices > 1) {
+            if (e->n_slices > 1 && s.graph_pull) {
               const uint32_t sl = id / e->slice_rows;
               if (sl < e->n_slices && e->slice_base[sl]) { if (sl == e->own_slot) ++s.rows_from_own_hbm; else ++s.rows_from_peer; }
               else ++pulled;
@@ -377,7 +377,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
             else ++pulled;
           }
       }
-      s.pulled_bytes = pulled * 256;
+      if (s.graph_pull) s.pulled_bytes = pulled * 256;   // (walker form: the threads' bytes are counted where they copy)
     }
   }
   *out = s;

@@ -244,6 +244,7 @@ struct bang_engine {
   int pull_opt = -1;                   // -1 auto, 0 = walker (host-paced kernel), 1 = pull
   int walker_opt = 0;                  // option "walker": 1 = the C++ walker threads serve the adjacency rows although the kernel could pull them itself
   bool walker_rows = false;            // the walker team reads the 256-byte pull rows (h_adj) instead of graph entries (resolved at bang_alloc)
+  bool walker_self = false;            // last launch of the walker-from-rows form: the kernel served the rows of this GPU's HBM copy itself
   bool pull = false;                   // resolved at load
   uint32_t* h_adj = nullptr;           // [N][64]
   size_t adj_bytes = 0;

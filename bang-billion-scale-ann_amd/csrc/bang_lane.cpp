@@ -227,6 +227,9 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_graph = nullptr; sp.entry_len = e->entry_len; sp.vec_bytes = (uint32_t)vb;
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1;
+    // walker-from-rows: parents whose row sits in this GPU's HBM copy of the first rows are served by the kernel itself
+    e->walker_self = e->walker_rows && e->d_rows_hbm && e->rows_first == 0 && env_long("BANG_WALKER_SELF_ROWS", 1) != 0;
+    if (e->walker_self) { sp.d_rows_hbm = e->d_rows_hbm; sp.n_rows_hbm = e->n_rows_hbm; }
     sp.d_ktime = ktime_slot(e, ln);
     sp.d_rows = e->d_srows; sp.d_ctl = e->d_sctl; sp.h_done = e->h_done_dev; sp.h_parents = e->d_parents_map;
     sp.h_pub_q = e->d_pub_q; sp.h_pub_c = e->d_pub_c; sp.ship_vectors = e->vec_on_device ? 0u : 1u;

@@ -507,6 +507,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   uint32_t q = 0, iter = 0, w_n = 0, cc = 0, mark = 0, evals = 0, fetched = 0;
   uint32_t cnt_in = 0, x0 = 0, x1 = 0;
   bool have_row = false;
+  bool self_row = false;                           // HOST: the parent's row sits in this GPU's HBM copy of the first rows -- the wave has asked for it itself,
+                                                   // the walker was told there is nothing to fetch (one context per wave only)
   bool mg_pending = false;                         // MERGE_LATE: the survivors of the previous iteration still wait for their merge
   uint32_t mg_n = 0, mg_iter = 0, mg_sid0 = 0;
   float mg_d0 = BIG_DIST;
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         group_barrier(wg_lds + 120, gsize, lane);
         PF_STAMP(pf_poll);
         if (wg_lds[0] == SRCH_GO_STOP) break;
-        if (active && have_row) {
+        if (active && have_row && !self_row) {
           // control line of the group: {go, count bytes x 16, ...}; rows: 64 ids each, 256-byte aligned
           const uint32_t cw = p.d_ctl[(size_t)grp * 16 + 1 + (gslot >> 2)];
           cnt_in = (cw >> (8 * (gslot & 3u))) & 0xFFu;
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
         { const uint32_t* seed = KARG(d_seed); cnt_in = seed[0]; x0 = seed[1 + lane]; x1 = seed[65]; }
         have_row = true;
+        self_row = false;
       } else exhausted = true;
     }
     if (!HOST && !active) break;
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     if (active) {
       // ---------------- K5: filter (neighbor_filtering_new :1140-1165) ----------------
       uint32_t ci = have_row ? uni(cnt_in) : 0u;
-      if (!HOST && p.row_layout && !first && have_row)       // ids ascending, padding behind them
+      if (((!HOST && p.row_layout) || (HOST && self_row)) && !first && have_row)       // a 256-byte adjacency row: ids ascending, padding behind them
         ci = (uint32_t)__popcll(__ballot(x0 != 0xFFFFFFFFu));
       PH(0);   // the adjacency row has arrived (and: query hand-out, loop overhead)
       {
@@ -853,11 +856,18 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
     } else {
       uint32_t* cnt_act = wg_lds + 1 + (tick % 3u);
+      // a parent whose row this GPU holds itself (the HBM copy of the first rows: walker-from-rows form) is not the walker's business: the wave
+      // asks for the row now -- it travels during the sort/merge, as in the self-paced form -- and publishes "nothing to fetch"
+      self_row = false;
+      if (nctx == 1u && want_row && !p.ship_vectors) {
+        const uint32_t nh = KARG(n_rows_hbm);
+        if (parent < nh) { self_row = true; x0 = KARG(d_rows_hbm)[(uint64_t)parent * 64u + lane]; cnt_in = 64u; }
+      }
       if (lane == 0) {
         // parents travel to the host in one coalesced store per workgroup.  A parent whose vector the walker must ship (vectors
         // not resident) is published even when no row is needed any more (the one chosen at the iteration cap, CANON 6).
         const bool tell = active && found && (want_row || p.ship_vectors);
-        wg_lds[4 + 48 * c + gslot] = tell ? parent : BANG_NO_PARENT;
+        wg_lds[4 + 48 * c + gslot] = tell ? (self_row ? BANG_IDLE_PARENT : parent) : BANG_NO_PARENT;
         wg_lds[20 + 48 * c + gslot] = q | (want_row ? 0x80000000u : 0u);
         wg_lds[36 + 48 * c + gslot] = cc - 1u;
         if (active) (void)__hip_atomic_fetch_add(cnt_act, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         ++iter;
         have_row = found;
         if (!MERGE_LATE || first) head = worklist_head(s, w_n, lane);
-        if (HOST) { cnt_in = 0; x0 = 0; }                                    // (the walker's rows are read at the top of the next round)
+        if (HOST && !self_row) { cnt_in = 0; x0 = 0; }                       // (the walker's rows are read at the top of the next round)
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
         if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
       }

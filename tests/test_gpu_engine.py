@@ -545,6 +545,35 @@ def test_walker_serves_from_the_pull_rows(request, libbang, fixture, threads):
 
 
 @pytest.mark.gpu
+def test_walker_form_serves_the_rows_it_holds_in_hbm_itself(libbang, small_u8, monkeypatch):
+    """Walker-from-rows with part of the rows also in HBM (bang_rows_slice_e: rows [0, N/2)): a wave whose parent's row is there loads it
+    itself and tells the walker threads there is nothing to fetch for it; the other rows still come from the threads.  Same bits either
+    way (BANG_WALKER_SELF_ROWS=0 sends every row through the threads), and the stats say how many rows stayed on the GPU."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    Q = q.shape[0]
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 48, with_stats=True)
+    own = {}
+    for self_rows in ("1", "0"):
+        monkeypatch.setenv("BANG_WALKER_SELF_ROWS", self_rows)
+        with bang_amd.Engine(ix.dtype, graph=bang_amd.GRAPH_HOST, walker=1, threads=4) as e:
+            e.load_index(ix)
+            e.rows_slice(0, ix.N // 2)
+            e.set_searchparams(10, 48)
+            e.alloc(Q)
+            e.init(Q)
+            ids, dists = e.query(q)
+            st = e.stats()
+            assert st["walker_rows"] == 1 and st["graph_pull"] == 0, st
+            assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), self_rows
+            assert np.array_equal(e.query_counters(Q), st_o), self_rows
+            own[self_rows] = st["rows_from_own_hbm"]
+            e.free(); e.unload()
+    assert own["0"] == 0 and 0 < own["1"] < int(st["candidates"]), own
+
+
+@pytest.mark.gpu
 def test_streamed_load_needs_the_pull_mode(libbang, small_u8):
     """Without a resident graph nothing but the pull mode can run: a streamed load refuses configurations that exclude it, and a
     walker form asked for afterwards is an error (there is no file to map)."""
