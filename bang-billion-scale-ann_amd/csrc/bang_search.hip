@@ -73,6 +73,9 @@ struct SearchArgs {
 // m > 44): two-piece rows (m = 32) gain nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging
 // area.  The host-paced instances do so for the long-row layouts only (12 waves x 168 VGPRs, with the filter summary).
 __host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return ndw >= 12 && (!host_paced || ndw >= 16); }
+// self-paced instances with the speculative row request (SPEC) exist for the 70-chunk layout (SIFT1B); the 74-chunk one (DEEP100M, graph in HBM)
+// measured 6-17 % slower with it at every batch size
+__host__ __device__ constexpr bool search_has_spec(int ndw) { return ndw == 18; }
 // per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots; 256 where the scratch has them) and the
 // summary's transposition area alias both, and so does the staging area of the cooperative code-row fetch (256 words: one wave
 // instruction's worth of 16-byte pieces)
@@ -437,7 +440,7 @@ __device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lan
 // VGPRs each; 12 waves run the request-bound layouts as fast as 15 or 16: DESIGN 4.6)
 __host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? 768 : 1024; }
 
-template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST>
+template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST, bool SPEC>
 __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bang_search_params& p = a.p;
@@ -500,6 +503,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   constexpr bool EARLY_ROWS = !HOST;                           // code rows requested before the filter update (host-paced instances: behind it --
                                                                // 60-100 B of scratch per lane otherwise)
   constexpr bool COOP = search_coop(NDW, HOST);                // ... by P adjacent lanes per row, one 16-byte piece each
+  // SPEC (instances of the long-row layouts, chosen per launch: spec_rows): the code rows of ALL ids of the adjacency row are requested
+  // together with their filter probes, one memory latency earlier; the distances of the ids the filter then drops are computed and thrown
+  // away (every lane runs the reduce anyway), the survivors' are compacted behind it.  Same distances for the same ids: same results.
+  static_assert(!SPEC || !HOST, "the speculative row request belongs to the self-paced form");
   const uint32_t code_stride = p.code_stride ? p.code_stride : p.m;
 
   // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     // bang_k_search) K3a + K3b of iteration i run in iteration i + 1, behind the issue of its filter probes -- the one wait of an iteration
     // that had nothing to cover it -- instead of behind the request for the next adjacency row
     constexpr bool SET_LATE = !HOST;
-    const bool MERGE_LATE = !HOST && a.merge_late != 0u;                      // (uniform)
+    const bool MERGE_LATE = !HOST && !SPEC && a.merge_late != 0u;             // (uniform; SPEC instances serve launches that do not fill the chip: no late merge in them)
     bool sl_a = false, sl_b = false;                  // summary marks of this iteration's survivors, applied behind the merge
     uint32_t sl_ua = 0, sl_ub = 0;
     float d0 = BIG_DIST, d1 = BIG_DIST;
@@ -689,6 +696,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         h1a = hash1(x1); h1b = hash2(x1);
         if (lane == 0) { w1a = ld_bypass_l1(&bloom[h1a >> 5]); w1b = ld_bypass_l1(&bloom[h1b >> 5]); }
       }
+      PqRow<NDW, ALIGNED> row;
+      CoopFetch<NDW, ALIGNED> cf;
+      const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
+      if (SPEC && COOP) cf.issue(d_codes, code_stride, x0, ci < 64u ? ci : 64u, lane);
+      else if (SPEC && v0) pq_row_load(row, d_codes, code_stride, x0);
       if (MERGE_LATE && !first) {
         // ---------------- K3a + K3b of the PREVIOUS iteration, while this one's filter words travel (nothing below needs the worklist
         // before the parent decision; the scratch is free until the compaction)
@@ -714,10 +726,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       PH(2);   // compaction
 
       // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
-      PqRow<NDW, ALIGNED> row;
-      CoopFetch<NDW, ALIGNED> cf;
-      const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
-      if (COOP && EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+      if (SPEC) {}
+      else if (COOP && EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
       else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, d_codes, code_stride, sid0);
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
       {
         if (COOP && !EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-        if (COOP) cf.collect(row, scratch, code_stride, sid0, lane);     // (all lanes: the pieces change hands through LDS)
+        if (COOP) cf.collect(row, scratch, code_stride, SPEC ? x0 : sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if (EARLY_ROWS) {
           // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
           // for them): now the filter stores -- their acknowledgements are not waited for until the next row is needed
@@ -766,7 +776,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
           // every lane executes the reduce (the query operand of its subtractions comes from other lanes by DPP); a lane without a survivor
           // reduces whatever row the cooperative fetch left it (row 0) and its distance is never looked at
           const float dd = pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc);
-          if ((uint32_t)lane < n) d0 = dd;
+          if (SPEC) {                                          // lane i evaluated id i of the row: the survivors' distances move up, in input order
+            if ((m0 >> lane) & 1ull) sc[lanes_below(m0)] = __float_as_uint(dd);
+            wave_sync();
+            if ((uint32_t)lane < n0) d0 = __uint_as_float(sc[lane]);
+            wave_sync();
+          } else if ((uint32_t)lane < n) d0 = dd;
           if (n > 64) {                                        // survivor 64 (seed list only): every lane reduces that row, lane 0's counts
             PqRow<NDW, ALIGNED> r1;
             pq_row_load(r1, d_codes, code_stride, uni(sid1));
@@ -774,7 +789,14 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
             if (lane == 0) d1 = d1v;
           }
         } else {
-          if ((uint32_t)lane < n) {
+          if (SPEC) {
+            float dd = BIG_DIST;
+            if (v0) dd = pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc);
+            if ((m0 >> lane) & 1ull) sc[lanes_below(m0)] = __float_as_uint(dd);
+            wave_sync();
+            if ((uint32_t)lane < n0) d0 = __uint_as_float(sc[lane]);
+            wave_sync();
+          } else if ((uint32_t)lane < n) {
             if (!COOP && !EARLY_ROWS) pq_row_load(row, d_codes, code_stride, sid0);
             d0 = !HOST ? pq_row_reduce_pipe<PSZ, NDW, ALIGNED, NHI>(row, piv_lds, qc)     // (host-paced instances: 12-24 B of scratch with it)
                        : pq_row_reduce<PSZ, NDW, ALIGNED, NHI, SB>(row, piv_lds, qc);
@@ -980,24 +1002,27 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 // ---------------------------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST>
+template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST, bool SPEC>
 static int launch_inst(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done[BANG_MAX_DEVICES] = {false};      // per kernel instance AND device
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)search_kernel<PSZ, NDW, ALIGNED, NHI, HOST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void*)search_kernel<PSZ, NDW, ALIGNED, NHI, HOST, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((search_kernel<PSZ, NDW, ALIGNED, NHI, HOST>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((search_kernel<PSZ, NDW, ALIGNED, NHI, HOST, SPEC>), grid, block, lds, st, a);
   HIP_TRY(hipGetLastError());
   return BANG_OK;
 }
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_hd(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  return a.p.d_graph ? launch_inst<PSZ, NDW, ALIGNED, NHI, false>(a, grid, block, lds, st)
-                     : launch_inst<PSZ, NDW, ALIGNED, NHI, true>(a, grid, block, lds, st);
+  if constexpr (search_has_spec(NDW)) {
+    if (a.p.d_graph && a.p.spec_rows == 1u) return launch_inst<PSZ, NDW, ALIGNED, NHI, false, true>(a, grid, block, lds, st);
+  }
+  return a.p.d_graph ? launch_inst<PSZ, NDW, ALIGNED, NHI, false, false>(a, grid, block, lds, st)
+                     : launch_inst<PSZ, NDW, ALIGNED, NHI, true, false>(a, grid, block, lds, st);
 }
 
 template <int PSZ, int NDW>
@@ -1114,6 +1139,13 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
     a.merge_late = (p->merge_late == 1u || (p->merge_late == 0u && (uint64_t)p->Q >= (uint64_t)grid_n * fit)) ? 1u : 0u;     // 0 = auto, 1 = on, 2 = off
   }
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
+  // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain; the SPEC instances
+  // have no late merge (with it: 16 B of scratch and no gain).  Without / with, ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9
+  // random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
+  // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.
+  // auto: on where the rows are pulled, and up to 10 queries per CU where the graph is in HBM
+  const bool spec_auto = p->row_layout != 0u || (p->Q + grid_n - 1) / grid_n <= 10u;
+  a.p.spec_rows = (search_has_spec((int)(p->mp / 4u)) && p->d_graph && (p->spec_rows == 1u || (p->spec_rows == 0u && spec_auto))) ? 1u : 2u;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);

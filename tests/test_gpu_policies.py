@@ -34,15 +34,17 @@ def _big_batch(request, fixture, Q):
     return _big[fixture]
 
 
-@pytest.mark.parametrize("merge_late,summ_iters,max_wgs", [("1", "-1", "0"), ("2", "3", "0"), ("1", "3", "96"), ("2", "-1", "96"), ("0", "0", "0")])
+@pytest.mark.parametrize("merge_late,summ_iters,max_wgs,spec_rows", [("1", "-1", "0", "1"), ("2", "3", "0", "2"), ("1", "3", "96", "1"), ("2", "-1", "96", "1"),
+                                                                     ("0", "0", "0", "0"), ("1", "-1", "0", "2")])
 @pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
-def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, merge_late, summ_iters, max_wgs):
+def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, merge_late, summ_iters, max_wgs, spec_rows):
     import bang_amd
     ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: full for every instance
     monkeypatch.setenv("BANG_MERGE_LATE", merge_late)
     monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
     monkeypatch.setenv("BANG_SEARCH_MAX_WGS", max_wgs)
+    monkeypatch.setenv("BANG_SPEC_ROWS", spec_rows)          # (code rows requested with the filter probes: the 70-chunk fixture has the instance)
     with bang_amd.Engine(ix.dtype, graph=graph, search=1) as e:
         e.load_index(ix)
         e.set_searchparams(10, 64)
