@@ -57,7 +57,7 @@ class SearchParams(C.Structure):
         ("h_pub_c", C.c_void_p), ("d_abort", C.c_void_p), ("ship_vectors", C.c_uint32), ("nctx", C.c_uint32),
         ("group_waves", C.c_uint32), ("d_prof", C.c_void_p), ("code_stride", C.c_uint32), ("n_rows_hbm", C.c_uint32), ("d_rows_hbm", C.c_void_p),
         ("d_row_slices", C.c_void_p), ("n_slices", C.c_uint32), ("slice_rows", C.c_uint32), ("go_timeout_ticks", C.c_uint64), ("d_qskip", C.c_void_p),
-        ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("merge_late", C.c_uint32), ("spec_rows", C.c_uint32),
+        ("n_nodes", C.c_uint32), ("summ_iters", C.c_uint32), ("spec_rows", C.c_uint32),
         ("rr_queries", C.c_void_p), ("rr_vec_base", C.c_void_p), ("rr_vec_stride", C.c_uint64), ("rr_ids_out", C.c_void_p), ("rr_dists_out", C.c_void_p),
         ("rr_dtype", C.c_uint32), ("rr_D", C.c_uint32), ("rr_k", C.c_uint32), ("rr_q0", C.c_uint32), ("rr_Q_total", C.c_uint32),
     ]

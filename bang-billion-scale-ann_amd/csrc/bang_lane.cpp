@@ -165,7 +165,6 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
     sp.d_bloom = p.d_bloom; sp.d_cand_ids = p.d_cand_ids; sp.d_cand_cnt = p.d_cand_cnt; sp.d_qstats = p.d_qstats;
     sp.d_qiters = e->d_qiters + ln.q0; sp.d_next_query = ln.d_pcnt; sp.d_abort = ln.d_pcnt + 1; sp.n_nodes = e->N;
     sp.d_qskip = e->d_qskip + ln.q0;
-    sp.merge_late = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_MERGE_LATE", 0)));
     sp.spec_rows = (uint32_t)std::min(2L, std::max(0L, env_long("BANG_SPEC_ROWS", 0)));
     e->rerank_fused = fused_rerank;
     if (fused_rerank) {                                                      // K6 + K7 by the wave that finishes the query: no launch behind this one

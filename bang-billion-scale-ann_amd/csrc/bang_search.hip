@@ -67,16 +67,15 @@ struct SearchArgs {
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
   uint32_t nctx;             // query contexts per wave: 1, or 2 in the host-paced form
   uint32_t gs;               // host-paced form: waves per pacing group (a workgroup's waves advance in lock-step per GROUP)
-  uint32_t merge_late;       // self-paced form: 1 = K3 of iteration i runs behind the probe issue of iteration i + 1 (full launches)
 };
 
 // Code rows are fetched cooperatively (CoopFetch, bang_device.h) from three 16-byte pieces per row on (rows of 12+ code dwords,
 // m > 44): two-piece rows (m = 32) gain nothing in the kernel (2.69 vs 2.70 ms on SIFT1M-like) and would only lose LDS to the staging
 // area.  The host-paced instances do so for the long-row layouts only (12 waves x 168 VGPRs, with the filter summary).
 __host__ __device__ constexpr bool search_coop(int ndw, bool host_paced) { return ndw >= 12 && (!host_paced || ndw >= 16); }
-// self-paced instances with the speculative row request (SPEC) exist for the 70-chunk layout (SIFT1B); the 74-chunk one (DEEP100M, graph in HBM)
-// measured 6-17 % slower with it at every batch size
-__host__ __device__ constexpr bool search_has_spec(int ndw) { return ndw == 18; }
+// self-paced instances with the speculative row request (SPEC) exist for the long-row layouts of the BASELINE configs (70 / 74 chunks: 168-VGPR
+// instances); the 128-VGPR instance of the 32-chunk layout measured 2-5 % slower with it
+__host__ __device__ constexpr bool search_has_spec(int ndw) { return ndw == 18 || ndw == 19; }
 // per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots; 256 where the scratch has them) and the
 // summary's transposition area alias both, and so does the staging area of the cooperative code-row fetch (256 words: one wave
 // instruction's worth of 16-byte pieces)
@@ -329,9 +328,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   bool have_row = false;
   bool self_row = false;                           // HOST: the parent's row sits in this GPU's HBM copy of the first rows -- the wave has asked for it itself,
                                                    // the walker was told there is nothing to fetch (one context per wave only)
-  bool mg_pending = false;                         // MERGE_LATE: the survivors of the previous iteration still wait for their merge
-  uint32_t mg_n = 0, mg_iter = 0, mg_sid0 = 0;
-  float mg_d0 = BIG_DIST;
   WlHead head;                                     // first unvisited worklist entry + last distance, as of the last merge (uniform)
   head.found = false; head.idx = 0; head.id = 0; head.d = 0.0f; head.tail = 0.0f;
   // the centred query of the current context, in registers (lane l of qc.v[r] = element 64 r + l; read with v_readlane): loaded
@@ -444,7 +440,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         active = true;
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
-        mg_pending = false;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
         if (lane == 0) KARG(d_cand_ids)[(size_t)q * cand_stride] = medoid;
         load_qc(q);
@@ -460,11 +455,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
     // self-paced form: the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting
-    // for the next adjacency row (nothing reads the summary in between); and in launches that fill every wave slot (a.merge_late,
-    // bang_k_search) K3a + K3b of iteration i run in iteration i + 1, behind the issue of its filter probes -- the one wait of an iteration
-    // that had nothing to cover it -- instead of behind the request for the next adjacency row
+    // for the next adjacency row (nothing reads the summary in between)
     constexpr bool SET_LATE = !HOST;
-    const bool MERGE_LATE = !HOST && !SPEC && a.merge_late != 0u;             // (uniform; SPEC instances serve launches that do not fill the chip: no late merge in them)
     bool sl_a = false, sl_b = false;                  // summary marks of this iteration's survivors, applied behind the merge
     uint32_t sl_ua = 0, sl_ub = 0;
     float d0 = BIG_DIST, d1 = BIG_DIST;
@@ -514,13 +506,6 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
       if (SPEC && COOP) cf.issue(d_codes, code_stride, x0, ci < 64u ? ci : 64u, lane);
       else if (SPEC && v0) pq_row_load(row, d_codes, code_stride, x0);
-      if (MERGE_LATE && !first) {
-        // ---------------- K3a + K3b of the PREVIOUS iteration, while this one's filter words travel (nothing below needs the worklist
-        // before the parent decision; the scratch is free until the compaction)
-        if (mg_pending) w_n = sort_and_merge(s, mg_n, mg_d0, mg_sid0, BIG_DIST, 0u, mg_iter, w_n, L, medoid, mark, head.tail, lane);
-        mg_pending = false;
-        head = worklist_head(s, w_n, lane);
-      }
       const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
@@ -739,8 +724,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
       if (n > 0 && iter < cap_iter) {
-        if (MERGE_LATE && !first) { mg_pending = true; mg_n = n; mg_iter = iter; mg_d0 = d0; mg_sid0 = sid0; }      // (n <= 64 behind the seed list)
-        else w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
+        w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
       }
       PH(6);   // (publish +) sort/merge
 #ifdef BANG_SEARCH_PHASE_PROF
@@ -776,7 +760,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       } else {
         ++iter;
         have_row = found;
-        if (!MERGE_LATE || first) head = worklist_head(s, w_n, lane);
+        head = worklist_head(s, w_n, lane);
         if (HOST && !self_row) { cnt_in = 0; x0 = 0; }                       // (the walker's rows are read at the top of the next round)
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
         if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
@@ -944,17 +928,9 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // 2 500 queries 4.68 / 2.37 instead of 4.99 / 2.71.  A lightly loaded one is short of nothing but the chain: 1 250 queries (5 waves per CU)
   // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto: off up to 5 waves per CU.
   const bool light = (p->Q + grid_n - 1) / grid_n <= 5u;
-  // the merge behind the NEXT iteration's probe issue instead of behind the row request: a full chip (every wave slot taken) has its longest
-  // uncovered wait there (10 000 queries 8.52 -> 8.26 ms, DEEP100M-shape 7.54 -> 7.26); a partly filled one gets its rows and filter words
-  // back sooner than a merge takes and loses 1-4 % (2 500 queries 2.38 -> 2.42 ms, 1 250: 1.71 -> 1.77)
-  {
-    const uint32_t fit = waves_that_fit(p->psz, p->mp, p->pq_nhi, p->L, 1, false);
-    a.merge_late = (p->merge_late == 1u || (p->merge_late == 0u && (uint64_t)p->Q >= (uint64_t)grid_n * fit)) ? 1u : 0u;     // 0 = auto, 1 = on, 2 = off
-  }
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
-  // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain; the SPEC instances
-  // have no late merge (with it: 16 B of scratch and no gain).  Without / with, ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9
-  // random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
+  // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,
+  // ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9 random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
   // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.
   // auto: on where the rows are pulled, and up to 10 queries per CU where the graph is in HBM
   const bool spec_auto = p->row_layout != 0u || (p->Q + grid_n - 1) / grid_n <= 10u;

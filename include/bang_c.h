@@ -387,12 +387,10 @@ typedef struct {
   uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
                                           (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 5 queries per CU, where its
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
-  uint32_t merge_late;                 /* self-paced form: K3a + K3b of iteration i run behind the issue of iteration i + 1's filter probes (1) instead of behind
-                                          the request for the next adjacency row (2); 0 = auto: 1 for launches that fill every wave slot of the chip */
-  uint32_t spec_rows;                  /* self-paced form, 70-chunk layout (the other instances ignore it): the PQ code rows of ALL ids of an adjacency row are
+  uint32_t spec_rows;                  /* self-paced form, 70- and 74-chunk layouts (the other instances ignore it): the PQ code rows of ALL ids of an adjacency row are
                                           requested together with their filter probes (1) -- one memory latency less per iteration, the rows of the ids the
                                           filter drops fetched in vain -- or behind the filter, survivors only (2); 0 = auto: 1 where the rows are pulled (row_layout), and
-                                          for launches of <= 10 queries per CU where the graph is in HBM.  The SPEC instances ignore merge_late (no late merge) */
+                                          for launches of <= 10 queries per CU where the graph is in HBM. */
   /* K6 + K7 FUSED into the launch (self-paced form, 8-bit vectors; compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368): the wave
    * that finishes a query re-ranks its candidate log on the spot -- exact distances to the full-precision vectors at rr_vec_base + id *
    * rr_vec_stride, stable rank by (distance, expansion order) -- and writes the query's k results; no second launch behind the search, and

@@ -1,5 +1,6 @@
-"""Launch policies of the search kernel never change results (bang_search.cu:1533-1715 is the merge whose POSITION in the iteration the
-`merge_late` policy moves; the filter summary only drops requests whose answer is known).
+"""Launch policies of the search kernel never change results (`spec_rows` moves the request for the PQ code rows in front of the filter,
+bang_search.cu:1140-1165 / :1201-1241: distances of ids the filter drops are computed and discarded; the filter summary only drops requests
+whose answer is known).
 
 The fixtures' own batches (40-64 queries) are far below a full chip, where both policies resolve to "off": here the batch is LARGE
 (more queries than wave slots, so the launch is full and queries are handed out from the queue) and the policies are forced both ways,
@@ -34,14 +35,12 @@ def _big_batch(request, fixture, Q):
     return _big[fixture]
 
 
-@pytest.mark.parametrize("merge_late,summ_iters,max_wgs,spec_rows", [("1", "-1", "0", "1"), ("2", "3", "0", "2"), ("1", "3", "96", "1"), ("2", "-1", "96", "1"),
-                                                                     ("0", "0", "0", "0"), ("1", "-1", "0", "2")])
+@pytest.mark.parametrize("summ_iters,max_wgs,spec_rows", [("-1", "0", "1"), ("3", "0", "2"), ("3", "96", "1"), ("-1", "96", "2"), ("0", "0", "0")])
 @pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
-def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, merge_late, summ_iters, max_wgs, spec_rows):
+def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, summ_iters, max_wgs, spec_rows):
     import bang_amd
     ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: full for every instance
-    monkeypatch.setenv("BANG_MERGE_LATE", merge_late)
     monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
     monkeypatch.setenv("BANG_SEARCH_MAX_WGS", max_wgs)
     monkeypatch.setenv("BANG_SPEC_ROWS", spec_rows)          # (code rows requested with the filter probes: the 70-chunk fixture has the instance)

@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="sift1b_shape")
     ap.add_argument("--queries", default="10000,5000,2500,1250")
-    ap.add_argument("--variants", default="default", help="comma list of option settings; '+' joins several options of one variant (BANG_MERGE_LATE=1+rows_hbm=0); 'default' = none")
+    ap.add_argument("--variants", default="default", help="comma list of option settings; '+' joins several options of one variant (BANG_SPEC_ROWS=1+rows_hbm=0); 'default' = none")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape-n", type=int, default=0)
