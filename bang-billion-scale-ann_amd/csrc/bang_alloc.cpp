@@ -28,7 +28,7 @@ void free_batch(bang_engine* e) {
   dfree(e->d_mark); dfree(e->d_parents_dev); dfree(e->d_cand_ids); dfree(e->d_cand_row); dfree(e->d_cand_cnt);
   dfree(e->d_active); dfree(e->d_qstats); dfree(e->d_qskip); dfree(e->d_fp); dfree(e->d_results);
   e->d_ids_out = nullptr; e->d_dists_out = nullptr; e->d_qiters = nullptr;             // (inside d_results)
-  if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; }
+  if (e->h_results) { (void)hipHostFree(e->h_results); e->h_results = nullptr; e->h_results_dev = nullptr; }
   dfree(e->d_done_count); dfree(e->d_stage); dfree(e->d_srows); dfree(e->d_sctl);
   if (e->h_parents) (void)hipHostFree(e->h_parents);
   if (e->h_pub_q) (void)hipHostFree(e->h_pub_q);
@@ -146,6 +146,7 @@ int alloc_buffers(bang_engine* e, int Q) {         // (bang_alloc_e has validate
     e->res_bytes = (e->res_off_iters + (size_t)nq * 4 + BANG_MAX_LANES * 4 + a64) & ~a64;   // + the kernel's abort word, one per lane
     BANG_TRY(dmalloc(&e->d_results, e->res_bytes));
     HIP_TRY(hipHostMalloc((void**)&e->h_results, e->res_bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->h_results_dev, e->h_results, 0));
     e->d_ids_out = (uint64_t*)e->d_results;
     e->d_dists_out = (float*)(e->d_results + e->res_off_dists);
     e->d_qiters = (uint32_t*)(e->d_results + e->res_off_iters);

@@ -186,6 +186,7 @@ struct bang_engine {
   // pinned host buffer (h_results): small batches come back in one asynchronous copy instead of three staged ones
   uint8_t* d_results = nullptr;
   uint8_t* h_results = nullptr;
+  uint8_t* h_results_dev = nullptr;    // the device's address of h_results: the fused re-rank writes a small batch's results there itself (no copy behind the launch)
   size_t res_off_dists = 0, res_off_iters = 0, res_bytes = 0;
   uint64_t* d_ids_out = nullptr;
   float* d_dists_out = nullptr;

@@ -119,6 +119,9 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   float* d_dists_user = e->pool.d_dists_user;
   const bool to_device = d_ids_user != nullptr;               // bang_query_dev_e: no result leaves the device
   const bool mailbox = !to_device && whole && e->res_off_iters <= mailbox_max;
+  // ... and with the re-rank fused into the search launch the kernel writes ids, distances, iteration counts and its abort word straight
+  // into that pinned mirror (posted PCIe writes, a query at a time as the queries finish): nothing is copied behind the launch
+  const bool results_direct = mailbox && fused_rerank && e->h_results_dev != nullptr && env_long("BANG_RESULTS_DIRECT", 1) != 0;
   // queries H2D (:612) + K1 (:623)
   uint8_t* dq = (uint8_t*)e->d_queries + (size_t)ln.q0 * qbytes;
   LANE_HIP(hipMemcpyAsync(dq, (const uint8_t*)h_queries + (size_t)ln.q0 * qbytes, (size_t)ln.nq * qbytes,
@@ -175,6 +178,11 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
       if (to_device && whole) {                                       // bang_query_dev_e: straight into the caller's device buffers
         sp.rr_ids_out = d_ids_user;
         if (d_dists_user) sp.rr_dists_out = d_dists_user;
+      }
+      if (results_direct) {
+        sp.rr_ids_out = (uint64_t*)e->h_results_dev; sp.rr_dists_out = (float*)(e->h_results_dev + e->res_off_dists);
+        sp.d_qiters = (uint32_t*)(e->h_results_dev + e->res_off_iters) + ln.q0;
+        sp.d_abort = (uint32_t*)(e->h_results_dev + e->res_bytes - BANG_MAX_LANES * 4) + ln.index;
       }
     }
     { const long si = env_long("BANG_SUMM_ITERS", 0); sp.summ_iters = si < 0 ? 0xFFFFFFFFu : (uint32_t)si; }     // 0 = auto, -1 = always
@@ -384,7 +392,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
   // A copy into the caller's pageable arrays is staged by the runtime and costs ~20 us before the first byte moves, per copy.  The
   // results come back whole in ONE asynchronous copy into the pinned mirror and are handed out with memcpy (measured: 70 -> 17 us for
   // a 1 250-query shard, 92-107 -> 73-82 us for the 10 K batch); only a very large batch keeps the direct, runtime-pipelined copies.
-  if (e->search_host || e->search_v2) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
+  if ((e->search_host || e->search_v2) && !results_direct) LANE_HIP(hipMemcpyAsync(h_abort, ln.d_pcnt + 1, 4, hipMemcpyDeviceToHost, ln.s_main));
   const bool iters = e->search_v2 || e->search_host;
   if (to_device) {
     const bool in_place = fused_rerank && whole;                // (the fused re-rank wrote into the caller's buffers)
@@ -396,6 +404,7 @@ int lane_run(bang_engine* e, Lane& ln, const void* h_queries, uint64_t* h_ids, f
                                 hipMemcpyDeviceToDevice, ln.s_main));
     if (iters) LANE_HIP(hipMemcpyAsync(e->h_results + e->res_off_iters + (size_t)ln.q0 * 4, e->d_qiters + ln.q0, (size_t)ln.nq * 4,
                                        hipMemcpyDeviceToHost, ln.s_main));
+  } else if (results_direct) {                                  // (already there)
   } else if (mailbox) {
     LANE_HIP(hipMemcpyAsync(e->h_results, e->d_results, iters ? e->res_off_iters + (size_t)ln.nq * 4 : e->res_off_iters,
                             hipMemcpyDeviceToHost, ln.s_main));

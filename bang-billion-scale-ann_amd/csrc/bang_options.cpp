@@ -88,6 +88,7 @@ static const SwitchDef kSwitches[] = {
     {"BANG_WALKER_SELF_ROWS", "host-paced search kernel, walker-from-rows form: 0 = every row comes from the walker threads, also those this GPU holds in its HBM copy (A/B)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},
+    {"BANG_RESULTS_DIRECT", "0 = the fused re-rank writes a small batch's results to device memory and they are copied back behind the launch (A/B; default: straight into the pinned mirror)"},
     {"BANG_MAILBOX_BYTES", "results up to this size return through the pinned mirror in one copy (default 8 MB)"},
     {"BANG_HELPER_GRACE_US", "walker helpers spin this long for the next batch before parking (default 4000)"},
     {"BANG_WALK_NT", "0 = walker threads copy staged rows with memcpy instead of 512-bit non-temporal stores"},

@@ -114,3 +114,28 @@ def test_fused_rerank_short_logs_many_lanes_and_big_k(libbang, small_u8):
         finally:
             os.environ.pop("BANG_SEARCH_MAX_WGS", None)
         assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), (k, L, lanes)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_fused_rerank_results_straight_into_the_pinned_mirror(request, libbang, monkeypatch, small_u8, graph, direct):
+    """With the re-rank fused, the kernel writes ids [Q][k], distances [rank][Q], the per-query iteration counts and its abort word straight
+    into the pinned host mirror of the results (no copy behind the launch); BANG_RESULTS_DIRECT=0 keeps them in device memory and copies
+    them back (compute_NearestNeighbours bang_search.cu:1312-1368 + the D2H at :997-999).  Same bits, same counters, twice in a row."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    monkeypatch.setenv("BANG_RESULTS_DIRECT", direct)
+    ids_o, dists_o, st_o = O.Oracle(ix).search(q, 10, 48, with_stats=True)
+    with bang_amd.Engine(ix.dtype, graph=graph, fuse_rerank=1) as e:
+        e.load_index(ix)
+        e.set_searchparams(10, 48)
+        e.alloc(q.shape[0])
+        for _ in range(2):
+            e.init(q.shape[0])
+            ids, dists = e.query(q)
+            assert e.stats()["rerank_fused"] == 1
+            assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32))
+            assert np.array_equal(e.query_counters(q.shape[0]), st_o.astype(np.int64))
+        e.free(); e.unload()
+
