@@ -504,6 +504,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
       const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
+      // SPEC: the code rows of every id of the row, behind the probes just issued (older loads are waited for first: the probes' answers
+      // are used while the rows still travel)
       if (SPEC && COOP) cf.issue(d_codes, code_stride, x0, ci < 64u ? ci : 64u, lane);
       else if (SPEC && v0) pq_row_load(row, d_codes, code_stride, x0);
       const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
@@ -523,10 +525,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       evals += n;
       PH(2);   // compaction
 
-      // the survivors' PQ code rows are requested NOW: they travel while the filter update below runs on LDS
-      if (SPEC) {}
-      else if (COOP && EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-      else if (!COOP && EARLY_ROWS && (uint32_t)lane < n) pq_row_load(row, d_codes, code_stride, sid0);
+      // the survivors' PQ code rows are requested NOW (unless they already travel: SPEC): under the filter update below, which runs on LDS
+      if (!SPEC && EARLY_ROWS) {
+        if (COOP) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
+        else if ((uint32_t)lane < n) pq_row_load(row, d_codes, code_stride, sid0);
+      }
 
       // ---------------- K5, second half: set the slots of the survivors (:1159-1160) ----------------
       // (before the distance arithmetic: the hashes and the probed words die here instead of living through the register-hungry K2)
