@@ -913,7 +913,7 @@ def test_candidate_log_hook(libbang, small_u8):
 @pytest.mark.parametrize("graph", [0, 1])
 def test_filter_summary_policy_does_not_change_results(libbang, small_u8, monkeypatch, summ_iters, graph):
     """The on-chip filter summary may serve all of a query's iterations (-1: what a full chip gets), none but the first (1: what
-    bang_k_search picks for launches of at most 5 queries per CU) or any prefix: a probe it does not answer is simply loaded."""
+    bang_k_search picks for launches of at most 6 queries per CU) or any prefix: a probe it does not answer is simply loaded."""
     from oracle import oracle as O
     ix, q, _, _ = small_u8
     monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
