@@ -50,6 +50,34 @@ def test_gpu_kernels_are_compiled_for_gfx950(libbang):
     assert b"gfx950" in blob and b"front_kernel" in blob and b"back_kernel" in blob and b"rerank_kernel" in blob
 
 
+def test_baseline_search_instances_run_without_scratch(libbang, tmp_path):
+    """The self-paced search-kernel instances of the BASELINE layouts (SIFT1B: 70 chunks, DEEP100M: 74, SIFT1M: 32; with and without the early
+    code-row request) sit within a few registers of their budget -- 168 VGPRs for 12 waves, 128 for 16 -- and one more live value becomes
+    scratch traffic inside the row reduce.  Read from the code object that was just built (kernel descriptors in the ELF notes)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    obj = os.path.join(ROOT, "bang-billion-scale-ann_amd", "lib", "bang_search.o")
+    if not all(os.path.exists(t) for t in tools) or not os.path.exists(obj):
+        pytest.skip("llvm binutils / the kernel object are not here")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", obj, str(tmp_path / "unused.o")], check=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
+    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    usage = {}
+    for blk in notes.split(".name:")[1:]:
+        name = blk.split()[0]
+        m = re.match(r"_Z13search_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])EEv10SearchArgs$", name)
+        if m:
+            key = tuple(int(x) for x in m.groups())                      # (PSZ, NDW, ALIGNED, NHI, HOST, SPEC)
+            usage[key] = (int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1)), int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)))
+    want = [(2, 18, 1, 58, 0, 0), (2, 18, 1, 58, 0, 1), (2, 19, 1, 22, 0, 0), (2, 19, 1, 22, 0, 1), (4, 8, 1, 0, 0, 0)]
+    for key in want:
+        assert key in usage, (key, sorted(usage)[:4])
+        scratch, vgprs = usage[key]
+        assert scratch == 0 and vgprs <= (168 if key[1] >= 16 else 128), (key, scratch, vgprs)
+    assert not any(k[4] == 1 and k[5] == 1 for k in usage)                 # (no SPEC instance of the host-paced form)
+
+
 def test_pq_layout_and_pivot_packing_host_side(libbang):
     from bang_amd import binding
     from bang_amd.synth import chunk_offsets

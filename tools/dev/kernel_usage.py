@@ -57,8 +57,8 @@ def main():
         with open(a.md, "w") as f:
             f.write(f"# Register budget per kernel instance: `{os.path.relpath(a.file, ROOT)}`\n\n")
             f.write("`python tools/dev/kernel_usage.py --md <this file>` (hipcc `-Rpass-analysis=kernel-resource-usage`, gfx950).  Template arguments of "
-                    "`search_kernel`: `<PSZ, NDW, ALIGNED, NHI, HOST>` -- `<2, 18, true, 58, false>` is the SIFT1B layout (m = 70, rows 128 B apart), self-paced; "
-                    "`<2, 19, *, 22, false>` DEEP100M (m = 74); `<4, 8, true, 0, false>` SIFT1M (m = 32).  Budget: 168 VGPRs for the 12-wave (768-thread) "
+                    "`search_kernel`: `<PSZ, NDW, ALIGNED, NHI, HOST, SPEC>` -- `<2, 18, true, 58, false, *>` is the SIFT1B layout (m = 70, rows 128 B apart), self-paced "
+                    "(SPEC = code rows requested with the filter probes); `<2, 19, *, 22, false, *>` DEEP100M (m = 74); `<4, 8, true, 0, false, false>` SIFT1M (m = 32).  Budget: 168 VGPRs for the 12-wave (768-thread) "
                     "instances, 128 for the 16-wave ones; 106 SGPRs (the compiler always reports the cap).  Dynamic LDS is sized at launch.\n\n")
             f.write("| kernel instance | VGPRs | AGPRs | SGPRs | scratch B/lane | waves/SIMD |\n|---|---|---|---|---|---|\n")
             for r in rs:
