@@ -278,9 +278,10 @@ class Engine:
         _check(lib().bang_rows_export_e(self._h, h, C.byref(first), C.byref(rows)), "bang_rows_export")
         return bytes(h), int(first.value), int(rows.value)
 
-    def rows_import(self, slot: int, n_slots: int, slice_rows: int, handle: bytes | None):
+    def rows_import(self, slot: int, n_slots: int, slice_rows: int, handle: bytes | None, rows: int = 0):
+        """rows: what the exporter's rows_export() reported (a peer slice shorter than the slot is refused)."""
         buf = (C.c_ubyte * 64).from_buffer_copy(handle) if handle is not None else None
-        _check(lib().bang_rows_import_e(self._h, C.c_uint32(slot), C.c_uint32(n_slots), C.c_uint64(slice_rows), buf), "bang_rows_import")
+        _check(lib().bang_rows_import_e(self._h, C.c_uint32(slot), C.c_uint32(n_slots), C.c_uint64(slice_rows), C.c_uint64(rows), buf), "bang_rows_import")
 
     def rows_close_peers(self):
         _check(lib().bang_rows_close_peers_e(self._h), "bang_rows_close_peers")

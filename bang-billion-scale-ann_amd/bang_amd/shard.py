@@ -62,9 +62,10 @@ class DeviceGather:
     def local_dists(self) -> np.ndarray:
         return self.dists.cpu().numpy()
 
-    def batch_ids(self) -> np.ndarray:
-        """[Q][k] u64 on the host, from the gathered block: ONE D2H copy into a pinned buffer allocated once; where the shards are even
-        (Q divisible by the rank count: the gathered block IS [Q][k]) the result is a view of that buffer, valid until the next call."""
+    def batch_ids(self, copy: bool = True) -> np.ndarray:
+        """[Q][k] u64 on the host, from the gathered block: ONE D2H copy into a pinned buffer allocated once.  The result is the caller's own
+        array whatever Q is (copy=True, default); copy=False may return a VIEW of the pinned buffer -- it does where the shards are even (Q
+        divisible by the rank count: the gathered block IS [Q][k]) -- which the next call overwrites."""
         import torch
         if getattr(self, "_host", None) is None:
             pin = self.all.is_cuda
@@ -76,7 +77,7 @@ class DeviceGather:
             self._host.copy_(self.all)
         allv = self._host.numpy().view(np.uint64)
         if self.pad * self.world == self.Q:
-            return allv
+            return allv.copy() if copy else allv
         out = np.empty((self.Q, self.k), dtype=np.uint64)
         for r in range(self.world):
             a, b = shard_range(self.Q, r, self.world)
@@ -137,7 +138,7 @@ def share_rows(eng, rank: int, world: int, n_nodes: int, group=None, slice_rows:
                 if r == rank:
                     eng.rows_import(r, world, n, None)
                 else:
-                    eng.rows_import(r, world, n, handles[r]["handle"] if handles[r]["rows"] else bytes(64))
+                    eng.rows_import(r, world, n, handles[r]["handle"] if handles[r]["rows"] else bytes(64), rows=handles[r]["rows"])
         except Exception as ex:                              # noqa: BLE001
             mine["err"] = repr(ex)[:200]
     err = first_error(gather(mine))

@@ -172,7 +172,7 @@ extern "C" int bang_alloc_e(bang_engine_t* e, int Q) {
     // the copy of the first adjacency rows took the HBM a batch of this size needs: the rows are in host memory anyway
     free_batch(e);
     dfree(e->d_rows_hbm);
-    e->n_rows_hbm = 0;
+    e->n_rows_hbm = 0; e->rows_first = 0;
     (void)hipGetLastError();
     rc = alloc_buffers(e, Q);
   }
@@ -294,7 +294,9 @@ static int query_impl(bang_engine_t* e, const void* h_queries, int Q, uint64_t* 
   s.rerank_fused = e->rerank_fused ? 1 : 0;
   s.walker_rows = (e->search_host && e->walker_rows) ? 1 : 0;
   s.code_stride = e->code_stride;
-  s.rows_in_hbm = (s.graph_pull ? e->n_rows_hbm : 0);
+  // what the kernel was GIVEN (bang_lane.cpp): without a slice table a slice moved off row 0 (bang_rows_slice_e(first > 0)) is not reachable
+  const uint32_t rows_direct = (e->rows_first == 0 ? e->n_rows_hbm : 0);
+  s.rows_in_hbm = (s.graph_pull ? (e->n_slices > 1 ? e->n_rows_hbm : rows_direct) : 0);
   return rc;
 }
 
@@ -373,7 +375,7 @@ extern "C" int bang_get_stats(bang_engine_t* e, bang_stats* out) {
               const uint32_t sl = id / e->slice_rows;
               if (sl < e->n_slices && e->slice_base[sl]) { if (sl == e->own_slot) ++s.rows_from_own_hbm; else ++s.rows_from_peer; }
               else ++pulled;
-            } else if (id < e->n_rows_hbm) ++s.rows_from_own_hbm;
+            } else if (id < (e->rows_first == 0 ? e->n_rows_hbm : 0)) ++s.rows_from_own_hbm;
             else ++pulled;
           }
       }

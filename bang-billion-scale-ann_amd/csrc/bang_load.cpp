@@ -355,7 +355,7 @@ extern "C" int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* fi
   return BANG_OK;
 }
 
-extern "C" int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, const void* handle64) {
+extern "C" int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, uint64_t rows, const void* handle64) {
   if (!e) return BANG_ERR_ARG;
   if (!e->loaded || !e->pull) { bang_set_error("peer rows: the index is not loaded in pull mode"); return BANG_ERR_ARG; }
   if (e->allocated) { bang_set_error("peer rows: import before bang_alloc"); return BANG_ERR_ARG; }
@@ -372,6 +372,10 @@ extern "C" int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_sl
     bool any = false;
     for (int i = 0; i < 64; ++i) any |= ((const uint8_t*)handle64)[i] != 0;
     if (any) {                                                             // (an all-zero handle: that rank holds no rows -- host rows serve the slot)
+      // the kernel reads base + p * 256 for EVERY p of the slot: a peer that exported fewer rows than the slot spans (a caller slicing by its own
+      // capacity instead of the node minimum) would be read past its allocation, over xGMI, undetected
+      const uint64_t need = std::min<uint64_t>(slice_rows, e->N > first ? e->N - first : 0);
+      if (rows < need) { bang_set_error("peer rows: slot %u was exported with %llu rows, its slice spans %llu", slot, (unsigned long long)rows, (unsigned long long)need); return BANG_ERR_ARG; }
       hipIpcMemHandle_t h;
       memcpy(&h, handle64, 64);
       void* ptr = nullptr;

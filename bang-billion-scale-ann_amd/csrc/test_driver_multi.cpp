@@ -28,6 +28,7 @@
 #include <fstream>
 #include <string>
 #include <vector>
+#include <csignal>
 
 #include "bang_c.h"
 
@@ -100,13 +101,16 @@ int run_rank(uint32_t rank, uint32_t W, bool share, uint64_t slice_cap, Shared* 
   CHECK(bang_set_option(e, "device", share ? 0 : (int)rank));
   CHECK(bang_set_option(e, "graph", BANG_GRAPH_HOST));           // the SIFT1B placement: rows in host memory, pulled by the kernel
   // rank 0 loads first: it builds the node's ONE rows file, the others map it
-  if (rank != 0) while (sh->loaded.load(std::memory_order_acquire) == 0) { if (sh->failed.load()) return 1; usleep(200); }
+  if (rank != 0) while (sh->loaded.load(std::memory_order_acquire) == 0) { if (sh->failed.load()) return 1; usleep(200); }   // (the parent sets `failed` when a rank dies)
   CHECK(bang_load_e(e, prefix));
   if (rank == 0) sh->loaded.store(1, std::memory_order_release);
   // ---- peer rows: capacities -> slice size -> slice + export -> import
   uint64_t cap = 0, n_nodes = 0;
   CHECK(bang_rows_capacity_e(e, &cap));
   sh->capacity[rank] = cap;
+  if (const char* kr = getenv("BANG_MULTI_TEST_KILL_RANK")) {       // test hook: this rank dies HERE without a word (as a GPU fault or the OOM killer would end it)
+    if ((uint32_t)atoi(kr) == rank) raise(SIGKILL);
+  }
   if (!barrier(sh, W)) return 1;
   CHECK(bang_get_num_nodes(e, &n_nodes));
   uint64_t n = *std::min_element(sh->capacity, sh->capacity + W);
@@ -119,7 +123,7 @@ int run_rank(uint32_t rank, uint32_t W, bool share, uint64_t slice_cap, Shared* 
     CHECK(bang_rows_export_e(e, sh->handle[rank], &f, &r));
     sh->rows[rank] = r;
     if (!barrier(sh, W)) return 1;
-    for (uint32_t r2 = 0; r2 < W; ++r2) CHECK(bang_rows_import_e(e, r2, W, n, r2 == rank ? nullptr : sh->handle[r2]));
+    for (uint32_t r2 = 0; r2 < W; ++r2) CHECK(bang_rows_import_e(e, r2, W, n, sh->rows[r2], r2 == rank ? nullptr : sh->handle[r2]));
   }
   if (!barrier(sh, W)) return 1;
   // ---- search: five timed runs, bang_init outside the timed region (test_driver.cpp:424-439)
@@ -208,8 +212,22 @@ int main(int argc, char** argv) {
     if (pid == 0) _exit(run_rank(r, W, share, slice_cap, sh, all_ids, prefix, dtype, queries, qbytes, Q, k, L));
     kids.push_back(pid);
   }
+  // Reap in the order the ranks END, not in rank order: a rank that dies without going through CHECK() (SIGSEGV, a GPU fault abort, the OOM
+  // killer) never sets `failed` itself -- the parent does it here, which releases the siblings from barrier() and the wait-for-loaded loop
+  // (they used to spin forever behind a dead rank, and the parent behind them).
   int bad = 0;
-  for (pid_t pid : kids) { int st = 0; waitpid(pid, &st, 0); bad |= !(WIFEXITED(st) && WEXITSTATUS(st) == 0); }
+  for (size_t left = kids.size(); left > 0; --left) {
+    int st = 0;
+    const pid_t pid = waitpid(-1, &st, 0);
+    if (pid < 0) { perror("waitpid"); sh->failed.store(1); bad = 1; break; }
+    if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+      const size_t r = (size_t)(std::find(kids.begin(), kids.end(), pid) - kids.begin());
+      if (WIFSIGNALED(st)) fprintf(stderr, "bang_search_multi: rank %zu was killed by signal %d\n", r, WTERMSIG(st));
+      else fprintf(stderr, "bang_search_multi: rank %zu exited with status %d\n", r, WIFEXITED(st) ? WEXITSTATUS(st) : -1);
+      sh->failed.store(1);
+      bad = 1;
+    }
+  }
   if (own_dir) { std::string cmd = std::string("rm -rf ") + dir; (void)!system(cmd.c_str()); }
   if (bad || sh->failed.load()) { fprintf(stderr, "bang_search_multi: a rank failed\n"); return 1; }
   const double ms = sh->ms[BANG_MAX_ROW_SLICES - 1];

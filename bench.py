@@ -5,7 +5,9 @@ kernel and of the PQ-distance stage (K2) alone, and the CPU baseline.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sift1b_shape|sift1m|sift10m|deep100m_shape|small|tiny]
                     [--graph host|device|auto] [--pull -1|0|1] [--batches B] [--no-legs] [--legs k2,sift1m,...]
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE).
+One process per GPU.  `--gpus N` IS the rank count: under a launcher (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE) WORLD_SIZE must equal N;
+without one, N > 1 makes this process start its N ranks itself (tools/bench_legs/launch.py: fresh children before anything touches the GPU,
+rank 0's line relayed, the children's status returned); fewer visible devices than N is an error, never a smaller run.
 
 * For EVERY N the workload is `sift1b_shape` = BASELINE.json configs[3] (N = 1) / configs[4] (N > 1): the configuration the target
   number is quoted on (BANG_Base/test_driver.cpp:433-439, Cost_Analysis.pdf p.3) -- uint8, D = 128, R = 64, m = 70, 10 000 queries,
@@ -53,7 +55,7 @@ from tools.bench_legs.common import (ARITH_DTYPE, T_PROCESS_START, WORKLOADS, Ct
 from tools.bench_legs.cpu import cpu_baseline_shape, cpu_baseline_structured  # noqa: E402
 from tools.bench_legs.k2 import k2_alone  # noqa: E402
 from tools.bench_legs.traffic import live_traffic  # noqa: E402
-from tools.bench_legs import legs as _legs, shards as _shards  # noqa: E402
+from tools.bench_legs import launch as _launch, legs as _legs, shards as _shards  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------------- build first
@@ -120,6 +122,17 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed PMC passes (profiles/) instead of two rocprofv3 passes of this run")
     args = ap.parse_args()
+
+    # --gpus N is the rank count, whoever starts the ranks (tools/bench_legs/launch.py).  Without a launcher and N > 1 this process starts the N
+    # ranks itself -- before it or anything it imported has touched the GPU --, relays rank 0's line and exits with their status; with a launcher
+    # a WORLD_SIZE that contradicts --gpus is an error; fewer visible devices than ranks is an error (never a silent N = 1 run).
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and not _launch.under_launcher():
+        raise SystemExit(_launch.self_launch(args.gpus, sys.argv[1:], os.path.abspath(__file__)))
+    _launch.check_world(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
+    if args.gpus > 1:
+        _launch.check_devices(args.gpus)
 
     ctx = Ctx()
     ctx.rank = rank = int(os.environ.get("RANK", "0"))
@@ -233,13 +246,20 @@ def main():
                "step_ms_min": min(res["step_ms"]), "step_ms_max": max(res["step_ms"]), "step_ms": res["step_ms"]}
         cfg["rccl_world_seen"] = world_seen
         shape_only = not prim["structured"]
-        metric = ("queries/sec, 10K-query batch" + (f"; headline = SHAPE-ONLY index at L = {L}, cap-bound ({agg['iterations']} iterations per query: heavier per "
-                  "query than real data at recall 0.9); the recall-gated figure (structured index, 10-recall@10 >= 0.9) is config.recall_gated_*" if shape_only
-                  else " @ 10-recall@10 >= 0.9"))
+        # (the driver's record keeps ~120 characters of a string: the facts first)
+        metric = (f"queries/sec, 10K-query batch; SHAPE-ONLY index, L={L}, {agg['iterations']} iterations/query (cap-bound), recall n/a; recall-gated: "
+                  "config.recall_gated_* (structured index, 10-recall@10 >= 0.9). A shape-only batch is heavier per query than real data at recall 0.9"
+                  if shape_only else "queries/sec @ 10-recall@10 >= 0.9, 10K-query batch")
         out = {"metric": metric, "value": res["queries_per_s"], "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": ARITH_DTYPE,
-               "data": "synthetic", "config": cfg, "roofline": res["roofline"], "cpu_baseline": None}
+               "data": "synthetic", "config": cfg, "roofline": res["roofline"], "cpu_baseline": None,
+               # who started the ranks ("self": plain `python bench.py --gpus N`; "launcher": torchrun) and what the collective's backend counted
+               "ranks_started_by": ("self" if os.environ.get("BANG_BENCH_SELF_LAUNCHED") else "launcher") if world > 1 else None,
+               "world_seen": world_seen,
+               # N > 1, rows pulled: True = the node's adjacency rows could NOT be shared over hipIpc and every rank pulls every row from host DRAM
+               "peer_rows_fallback": bool(isinstance(getattr(ctx, "peer_rows", None), dict) and ctx.peer_rows.get("error")) if world > 1 else None,
+               "search_ms_per_rank": res.get("search_ms_per_rank"), "gather_ms_per_rank": res.get("gather_ms_per_rank")}
 
     want = set(x for x in args.legs.split(",") if x)
     legs = world == 1 and not args.no_legs and not os.environ.get("BANG_BENCH_NO_LEGS")

@@ -139,7 +139,10 @@ int bang_get_num_nodes(bang_engine_t* e, uint64_t* nodes_out);    /* N of the lo
 int bang_rows_capacity_e(bang_engine_t* e, uint64_t* rows_out);   /* rows of 256 B this engine's free HBM holds now (6 GB kept back for the batch state) + what its row copy holds */
 int bang_rows_slice_e(bang_engine_t* e, uint64_t first_row, uint64_t rows);
 int bang_rows_export_e(bang_engine_t* e, void* handle64, uint64_t* first_row, uint64_t* rows);
-int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, const void* handle64 /* NULL: this engine's own slice */);
+int bang_rows_import_e(bang_engine_t* e, uint32_t slot, uint32_t n_slots, uint64_t slice_rows, uint64_t rows /* what the exporter's bang_rows_export_e
+                       * reported: a peer allocation shorter than the slot's rows min(slice_rows, N - slot * slice_rows) is refused -- the kernel reads
+                       * base + p * 256 for every p of the slot; ignored for the own slice */,
+                       const void* handle64 /* NULL: this engine's own slice */);
 /* Tear-down in two phases: every rank closes its mappings of the OTHER ranks' slices (this call; after bang_free), the ranks meet (a barrier of
  * the caller's process group), and only then does anyone bang_unload -- which frees the slice the others had mapped. */
 int bang_rows_close_peers_e(bang_engine_t* e);

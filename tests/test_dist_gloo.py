@@ -84,8 +84,8 @@ class _FakeEngine:
         first, rows = self.slice
         return (bytes([self.rank + 1]) * 64 if rows else bytes(64)), first, rows
 
-    def rows_import(self, slot, n_slots, slice_rows, handle):
-        self.imports.append((slot, n_slots, slice_rows, handle))
+    def rows_import(self, slot, n_slots, slice_rows, handle, rows=0):
+        self.imports.append((slot, n_slots, slice_rows, handle, rows))
 
     def rows_close_peers(self):
         self.closed = True
@@ -124,7 +124,7 @@ def _peer_worker(rank, world, port, N, caps, out_dir):
     info = shard.share_rows(eng, rank, world, N)
     shard.unshare_rows(eng)
     json.dump({"info": info, "slice": eng.slice, "closed": eng.closed,
-               "imports": [[s, w, n, (None if h is None else h[0])] for s, w, n, h in eng.imports]}, open(os.path.join(out_dir, f"p{rank}.json"), "w"))
+               "imports": [[s, w, n, (None if h is None else h[0]), rows] for s, w, n, h, rows in eng.imports]}, open(os.path.join(out_dir, f"p{rank}.json"), "w"))
     dist.destroy_process_group()
 
 
@@ -143,8 +143,10 @@ def test_peer_rows_exchange_two_ranks(tmp_path):
             first = min(r * n_want, N)
             assert p["slice"] == [first, min(n_want, N - first)]
             assert sorted(i[0] for i in p["imports"]) == [0, 1] and all(i[1] == 2 and i[2] == n_want for i in p["imports"])
-            for slot, _, _, h in p["imports"]:
+            for slot, _, _, h, rows in p["imports"]:
                 assert (h is None) == (slot == r) and (h is None or h == slot + 1)          # the sibling's handle went into the sibling's slot
+                if h is not None:                                                           # ... with the row count the sibling EXPORTED (the engine refuses a short slice)
+                    assert rows == min(n_want, N - min(slot * n_want, N))
 
 
 def test_peer_rows_failure_on_one_rank_reaches_every_rank(tmp_path):

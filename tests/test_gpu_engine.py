@@ -574,6 +574,42 @@ def test_walker_form_serves_the_rows_it_holds_in_hbm_itself(libbang, small_u8, m
 
 
 @pytest.mark.gpu
+def test_peer_slice_shorter_than_its_slot_is_refused_and_moved_slice_stats(libbang, small_u8):
+    """ADVICE r5.  (1) bang_rows_import_e takes the row count the exporter reported: a peer allocation shorter than the slot it is to serve is
+    refused before it is mapped (the kernel reads base + p * 256 for every p of the slot).  (2) A slice moved off row 0 without a slice table is
+    not reachable by the kernel: the stats say 0 rows in HBM / from own HBM, and every row counted as pulled."""
+    import bang_amd
+    from oracle import oracle as O
+    ix, q, _, _ = small_u8
+    Q = q.shape[0]
+    n = ix.N // 2
+    with bang_amd.Engine(ix.dtype, graph=bang_amd.GRAPH_HOST) as e:
+        e.load_index(ix)
+        e.rows_slice(0, n)
+        h, first, rows = e.rows_export()
+        assert (first, rows) == (0, n) and any(h)
+        e.rows_import(0, 2, n, None)
+        with pytest.raises(bang_amd.BangError, match="exported with"):
+            e.rows_import(1, 2, n, h, rows=n - 1)                     # (slot 1 spans rows [n, 2n): N - n >= n of them)
+        with pytest.raises(bang_amd.BangError, match="exported with"):
+            e.rows_import(1, 2, n, h)                                 # no count at all
+        e.unload()
+    ids_o, _ = O.Oracle(ix).search(q, 10, 48)
+    with bang_amd.Engine(ix.dtype, graph=bang_amd.GRAPH_HOST) as e:
+        e.load_index(ix)
+        e.rows_slice(n, n)                                            # rows [n, 2n) in HBM, no table: the kernel pulls everything
+        e.set_searchparams(10, 48)
+        e.alloc(Q)
+        e.init(Q)
+        ids, _ = e.query(q)
+        st = e.stats()
+        assert np.array_equal(ids, ids_o)
+        assert st["graph_pull"] == 1 and st["rows_in_hbm"] == 0 and st["rows_from_own_hbm"] == 0 and st["rows_from_peer"] == 0, st
+        assert st["pulled_bytes"] == 256 * (int(st["candidates"]) - Q), st
+        e.free(); e.unload()
+
+
+@pytest.mark.gpu
 def test_streamed_load_needs_the_pull_mode(libbang, small_u8):
     """Without a resident graph nothing but the pull mode can run: a streamed load refuses configurations that exclude it, and a
     walker form asked for afterwards is an error (there is no file to map)."""

@@ -77,3 +77,26 @@ def test_multi_gpu_harness_on_the_c_abi(libbang, tmp_path, small_u8):
         assert abs(float(line[4]) - want) < 0.006, (line, want)
         own, peer, host = (int(x) for x in line[5].split("/"))
         assert own > 0 and peer > 0 and (host > 0) == host_expected, line
+
+
+def test_multi_gpu_harness_ends_when_a_rank_dies_without_a_word(libbang, tmp_path, small_u8):
+    """a rank that dies abnormally (SIGKILL here, as the OOM killer or a GPU fault abort would end it) never sets the shared `failed`
+    word itself.  The parent reaps in the order the ranks end and sets it, so the sibling leaves its barrier and the harness returns 1 within
+    seconds instead of spinning until an outer time limit."""
+    import time
+    import bang_amd
+    from bang_amd import formats
+    ix, q, gt_i, gt_d = small_u8
+    prefix = str(tmp_path / "multi")
+    formats.write_index(prefix, ix)
+    formats.write_bin(prefix + "_query.bin", q)
+    formats.write_truthset(prefix + "_gt.bin", gt_i, gt_d)
+    exe = os.path.join(os.path.dirname(os.path.dirname(bang_amd.lib_path())), "bin", "bang_search_multi")
+    args = [exe, prefix, prefix + "_query.bin", prefix + "_gt.bin", str(q.shape[0]), "10", "uint8", "48", "2", "share"]
+    for victim in ("1", "0"):
+        env = dict(os.environ, BANG_MULTI_TEST_KILL_RANK=victim)
+        env.pop("BANG_PULL_ROWS_DIR", None)
+        t0 = time.time()
+        r = subprocess.run(args, capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 1 and time.time() - t0 < 90, (r.returncode, r.stderr[-800:])
+        assert f"rank {victim} was killed by signal 9" in r.stderr and "a rank failed" in r.stderr, r.stderr[-800:]

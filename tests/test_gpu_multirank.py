@@ -23,11 +23,15 @@ def _free_port():
     return p
 
 
-def _bench(nproc, extra, timeout=380, workload="tiny", L=46):
+def _bench(nproc, extra, timeout=380, workload="tiny", L=46, launcher=True):
+    """launcher=True: the ranks are started as the driver starts them (torch.distributed.run); False: plain `python bench.py --gpus N`,
+    which starts its N ranks itself (tools/bench_legs/launch.py)."""
     env = dict(os.environ, BANG_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for kk in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BANG_BENCH_SELF_LAUNCHED"):
+        env.pop(kk, None)
     base = ["bench.py", "--gpus", str(nproc), "--workload", workload, "--L", str(L), "--steps", "2", "--warmup", "1",
             "--no-cpu-baseline", "--no-legs", "--backend", "gloo"] + extra
-    if nproc == 1:
+    if nproc == 1 or not launcher:
         cmd = [sys.executable] + base
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
@@ -74,6 +78,33 @@ def test_two_ranks_one_gpu_one_host_graph(libbang, graph, monkeypatch):
     assert abs(two["config"]["recall_at_10"] - one["config"]["recall_at_10"]) < 2e-3
     assert two["value"] > 0 and two["ms_per_step"] > 0
     assert two["config"]["search_ms_per_step_max_over_ranks"] > 0 and two["config"]["gather_ms_per_step_max_over_ranks"] > 0
+
+
+def test_plain_bench_gpus_2_starts_its_two_ranks_itself(libbang):
+    """`python bench.py --gpus 2` with NO launcher (no RANK / WORLD_SIZE in the environment) used to run one rank and print
+    "n_gpus": 1.  Now the process starts two rank processes itself before touching the GPU: the line says 2 GPUs, the job's backend counted two
+    ranks (an all-reduce of ones), every rank reports its own search / gather time, and the gathered block equals the oracle's answer."""
+    two = _bench(2, ["--graph", "host"], launcher=False)
+    assert two["n_gpus"] == 2 and two["world_seen"] == 2 and two["config"]["rccl_world_seen"] == 2
+    assert two["ranks_started_by"] == "self" and two["scaling"] == "strong"
+    assert two["config"]["gathered_ids_equal_oracle_whole_batch"] is True and two["config"]["parity_vs_oracle_first_64"] is True
+    assert len(two["search_ms_per_rank"]) == 2 and len(two["gather_ms_per_rank"]) == 2 and min(two["search_ms_per_rank"]) > 0
+    assert two["peer_rows_fallback"] is False and two["config"]["peer_rows"]["fraction"] == 1.0
+    # the same job under the launcher says so
+    two_l = _bench(2, ["--graph", "host"])
+    assert two_l["ranks_started_by"] == "launcher" and two_l["world_seen"] == 2
+
+
+def test_plain_bench_gpus_2_refuses_a_one_gpu_box():
+    """Fewer visible devices than ranks, no BANG_BENCH_SHARE_GPU: exit status 2 and no line -- never a silent 1-rank run."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {kk: v for kk, v in os.environ.items() if kk not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BANG_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny", "--no-legs", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "only 1 HIP device" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_two_ranks_throughput_mode(libbang):

@@ -247,7 +247,7 @@ def run_once(eng, my_q, ctx, timed=False, gather=True):
         t_b = time.perf_counter()
         dg.gather()
         if ctx.rank == 0:
-            ctx.batch_ids = dg.batch_ids()               # the batch's answer reaches the host on one rank (one D2H copy)
+            ctx.batch_ids = dg.batch_ids(copy=False)               # the batch's answer reaches the host on one rank (one D2H copy)
         else:
             torch.cuda.synchronize()
         ids, dists = None, None
@@ -331,6 +331,12 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
                step_ms=[round(1e3 * float(t), 2) for t in times[0].tolist()][:64], ids=ids, dists=dists, agg=agg,
                search_ms=round(1e3 * float(times[2].sum().item()) / steps, 4),      # bang_query of the slowest rank, mean over the steps
                gather_ms=round(1e3 * float(times[3].sum().item()) / steps, 4))      # the collective (+ rank 0's copy of the batch to the host)
+    if ctx.world > 1:                                   # what every rank saw itself (means over the steps): bang_query of its shard, the collective
+        mine = torch.tensor([1e3 * sum(search_s) / steps, 1e3 * sum(gather_s) / steps], dtype=torch.float64, device=ctx.cdev)
+        every = [torch.zeros_like(mine) for _ in range(ctx.world)]
+        dist.all_gather(every, mine)
+        res["search_ms_per_rank"] = [round(float(t[0].item()), 4) for t in every]
+        res["gather_ms_per_rank"] = [round(float(t[1].item()), 4) for t in every]
     # ---- roofline of the search kernel of this measurement
     m = ix.m
     bpe = m + 8                                         # m code bytes + 4 B id + 4 B distance per evaluation
@@ -377,10 +383,9 @@ def measure(eng, wl, my_q, L, steps, warmup, ctx, graph, traffic_key=None, batch
                 "k2_alone_frac": None, "k2_alone_GBps": None,
                 "algorithmic_bytes_per_launch": round(evals_per_launch * bpe, 1),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches": launches, "bytes_per_distance_eval": bpe,
-                "kernel": ("search kernel, ONE launch per batch (K5 filter + K2 PQ distance + K4 parent + K3a sort + K3b merge for every "
-                           "iteration of every query)") if persistent else "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
-                "timer": "in-kernel s_memrealtime stamps (100 MHz) on every launch of the timed steps; cross-checked against "
-                         "rocprofv3 --kernel-trace in profiles/"}
+                "kernel": ("search_kernel: ONE launch per batch = every iteration of every query (K5 filter, K2 PQ distance, K4 parent, K3a sort, "
+                           "K3b merge; K6+K7 re-rank where fused)") if persistent else "front_kernel (K5 filter + K2 PQ distance + K4 parent, fused)",
+                "timer": "in-kernel s_memrealtime (100 MHz), every timed launch; rocprofv3 --kernel-trace agrees (profiles/)"}
         if traffic_note:
             roof["traffic_note"] = traffic_note
         if by_stream:

@@ -27,12 +27,12 @@ def gather_ms_world1(ctx, Q, k, reps=20):
         dg = shard.DeviceGather(Q, k, 0, 1, ctx.dev, coll_device=ctx.dev)
         for _ in range(3):
             dg.gather()
-            dg.batch_ids()
+            dg.batch_ids(copy=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             dg.gather()
-            dg.batch_ids()                                   # (rank 0 of the N > 1 job copies the gathered [Q][k] block to the host: part of its step)
+            dg.batch_ids(copy=False)                                   # (rank 0 of the N > 1 job copies the gathered [Q][k] block to the host: part of its step)
         ms = 1e3 * (time.perf_counter() - t0) / reps
         return round(ms, 4), ("RCCL all_gather_into_tensor from device buffers + the D2H copy of the gathered [Q][k] block, world size 1, "
                               "launch to completion (mean of %d)" % reps)

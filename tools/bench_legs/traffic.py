@@ -69,9 +69,7 @@ def live_traffic(args, log):
     io = int(got["TCC_EA0_RDREQ_IO_32B_sum"] * 32)
     return {"bytes": rd + wr, "hbm_read": rd, "hbm_write": wr, "pcie_read": io, "fetch_size_raw": int(got["FETCH_SIZE"] * 1024),
             "write_requests": int(got["TCC_EA0_WRREQ_sum"]),
-            "note": f"HBM bytes per launch measured in THIS run (rocprofv3 --pmc, one pass per counter group, the {steps} timed launches of the same "
-                    f"command): reads {rd / 1e9:.3f} GB = TCC_EA0_RDREQ_DRAM_32B x 32 (byte-exact on known byte counts: profiles/r04_traffic_calibration.md; "
-                    f"FETCH_SIZE tallies every 128-byte request at 64: raw {got['FETCH_SIZE'] * 1024 / 1e9:.3f} GB) + writes {wr / 1e9:.3f} GB = WRITE_SIZE "
-                    f"(32 B per scattered 4-byte store); {io / 1e9:.3f} GB more were read over PCIe (pulled adjacency rows)"}
-
-
+            "note": f"live rocprofv3 --pmc, {steps} launches: rd {rd / 1e9:.2f} GB (RDREQ_DRAM_32B x 32) + wr {wr / 1e9:.2f} GB (WRITE_SIZE); PCIe rd {io / 1e9:.2f} GB. "
+                    f"One pass per counter group on the same command; TCC_EA0_RDREQ_DRAM_32B is byte-exact on known byte counts "
+                    f"(profiles/r04_traffic_calibration.md), FETCH_SIZE tallies every 128-byte request at 64 (raw {got['FETCH_SIZE'] * 1024 / 1e9:.3f} GB); "
+                    f"a scattered 4-byte store counts 32 B"}

@@ -282,13 +282,14 @@ def make(name, dev, n_override=0, Q=10_000, seed=20240711, log=print, host_codes
                     codes=codes_host if host_codes else np.zeros((1, m), np.uint8), pivots=pivots, centroid=centroid,
                     chunk_off=chunk_offsets(D, m), _ptr=ptr, _bytes=gbytes, _codes=codes, _lib=lib, _cptr=cptr, _cbytes=N * m,
                     entry_source=((lib.shape_entry_source, source) if stream else None), code_stride=(0 if host_codes else cs))
+    # (the driver's record keeps ~120 characters of a string: N, layout and placement first, prose behind)
+    head = f"{name} N={N} {sh['dtype']} D={D} R={R} m={m} Q={Q} shape-only"
     if stream:
-        name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, STREAMED load: adjacency lists "
-                  f"{N * PULL_ROW_BYTES / 1e9:.0f} GB as pull rows in host RAM, vectors {N * D * isz / 1e9:.0f} GB + codes "
-                  f"{N * cs / 1e9:.0f} GB ({cs} B per row) in HBM{note}")
+        name_s = (f"{head} STREAMED: rows {N * PULL_ROW_BYTES / 1e9:.0f} GB host RAM (pull rows), vectors {N * D * isz / 1e9:.0f} GB + codes "
+                  f"{N * cs / 1e9:.0f} GB ({cs} B/row) HBM{note}")
     else:
-        name_s = (f"{name}: shape-only synthetic, {sh['dtype']} N={N} D={D} R={R} m={m} Q={Q}, graph+vectors "
-                  f"{gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, codes {N * cs / 1e9:.0f} GB ({cs} B per row) in HBM{note}")
+        name_s = (f"{head}: graph+vectors {gbytes / 1e9:.0f} GB in {'host RAM' if sh['graph'] == 'host' else 'HBM'}, "
+                  f"codes {N * cs / 1e9:.0f} GB ({cs} B/row) HBM{note}")
     return ix, queries, None, None, (codes.data_ptr() if codes is not None else None), name_s, sh["graph"]
 
 
