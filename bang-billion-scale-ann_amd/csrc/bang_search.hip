@@ -250,7 +250,10 @@ __device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lan
 // MAXT: threads per workgroup the instance is compiled for -- 1024 (16 waves, 128 VGPRs each) or, for the self-paced instances of
 // the long code rows (>= 64 chunks: the cooperative fetch holds a row's pieces and the row itself for a moment), 768 (12 waves, 168
 // VGPRs each; 12 waves run the request-bound layouts as fast as 15 or 16: DESIGN 4.6)
-__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? 768 : 1024; }
+#ifndef BANG_LONG_MAXT
+#define BANG_LONG_MAXT 768           // build switch (experiments): threads per workgroup the long-row instances are compiled for
+#endif
+__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? BANG_LONG_MAXT : 1024; }
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST, bool SPEC>
 __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const SearchArgs a) {
