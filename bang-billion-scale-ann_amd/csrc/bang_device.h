@@ -204,26 +204,40 @@ struct CoopFetch {
       // count of outstanding memory operations inexact, and every later wait for an OLDER load then becomes a wait for everything
       const uint64_t a = ok ? (uint64_t)rid[j] * stride : 0ull;
       const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + (ok ? piece : 0u);
-      v[j] = *p;
+      // non-temporal: a code row is read once and never again -- marked so, it does not push the resident queries' filter lines out of L2 / the
+      // Infinity Cache as fast (10 K SIFT1B-shape batch 8.15 -> 7.98 ms).  Round 3 had measured the hint slower with per-lane loads: an `nt` load
+      // by-passes L1, and a lane walking its own row then turned every one of its five loads into an L2 request; here the P lanes of a row ask
+      // for its pieces in ONE instruction and the address coalescer makes that one request per line with or without L1.
+      v[j] = __builtin_nontemporal_load(p);
     }
   }
-  __device__ __forceinline__ void collect(Row& r, uint32_t* buf /* LDS_WORDS words of the wave's LDS, 16-byte aligned */, uint32_t stride,
+  // BUF_WORDS: words of staging the wave has (>= LDS_WORDS: one wave instruction's pieces change hands at once; less: in ROUNDS rounds of RR rows --
+  // the same stores and reads per lane, only more hand-overs; what lets 16 waves share the LDS the pivot table leaves)
+  template <int BUF_WORDS = LDS_WORDS>
+  __device__ __forceinline__ void collect(Row& r, uint32_t* buf /* BUF_WORDS words of the wave's LDS, 16-byte aligned */, uint32_t stride,
                                           uint32_t id, int lane) {
+    constexpr int RR = (BUF_WORDS >= LDS_WORDS) ? RPI : BUF_WORDS / (P * 4);          // rows per round
+    constexpr int ROUNDS = (RPI + RR - 1) / RR;
+    static_assert(RR >= 1, "the staging area holds at least one row");
     r.sh = ((uint32_t)id * stride) & 3u;                // (low two bits of the 64-bit row offset)
     const uint32_t slot = (uint32_t)lane / (uint32_t)P;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      if (slot < (uint32_t)RPI) *(u32x4a*)(buf + 4 * lane) = v[j];                         // (lane = slot * P + piece: contiguous)
-      wave_sync();
-      const uint32_t k = (uint32_t)lane - (uint32_t)j * RPI;                             // my row within this instruction's batch
-      if (k < (uint32_t)RPI) {
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-          const u32x4a t = *(const u32x4a*)(buf + (k * P + q) * 4);
-          r.w[4 * q + 0] = t.x; r.w[4 * q + 1] = t.y; r.w[4 * q + 2] = t.z; r.w[4 * q + 3] = t.w;
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const uint32_t s0 = (uint32_t)rd * RR;                                           // first slot of this round
+        if (slot >= s0 && slot < s0 + (uint32_t)RR && slot < (uint32_t)RPI) *(u32x4a*)(buf + 4 * ((uint32_t)lane - s0 * P)) = v[j];   // (lane = slot * P + piece: contiguous)
+        wave_sync();
+        const uint32_t k = (uint32_t)lane - (uint32_t)j * RPI - s0;                      // my row within this round's batch
+        if (k < (uint32_t)RR && k + s0 < (uint32_t)RPI) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const u32x4a t = *(const u32x4a*)(buf + (k * P + q) * 4);
+            r.w[4 * q + 0] = t.x; r.w[4 * q + 1] = t.y; r.w[4 * q + 2] = t.z; r.w[4 * q + 3] = t.w;
+          }
         }
+        wave_sync();
       }
-      wave_sync();
     }
     r.w[Row::NX4 * 4] = 0;
     // every piece register is read once more by ALL lanes: the stores above sit behind `slot < RPI`, so on the other path the
@@ -428,37 +442,9 @@ struct RerankArgs8 {                                    // bang_search_params.rr
   const void* queries; const uint8_t* vec_base; uint64_t vec_stride; uint64_t* ids_out; float* dists_out; const uint32_t* cand;
   uint32_t D, k, q0, Q_total;
 };
-template <bool SIGNED>
-__device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, uint32_t n, uint32_t* e /* LDS, n words */, int lane) {
-  constexpr int U = 4;                                            // vector fetches in flight per lane
-  const uint32_t D = p.D, G = D >> 4, per = 64u / G;              // lanes per candidate, candidates per wave instruction
-  const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
+// K7 of the fused re-rank (compute_NearestNeighbours :1312-1368): e[0, n) = the exact distances' bit patterns in LDS, in expansion order
+__device__ __forceinline__ void wave_topk(const RerankArgs8& p, size_t qabs, uint32_t n, uint32_t* e, int lane) {
   const uint32_t* cand = p.cand;
-  const size_t qabs = (size_t)p.q0 + q;
-  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.queries + qabs * D + 16u * sub);
-  const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
-  for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
-    uint32_t id[U];
-    u32x4a v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = i0 + (uint32_t)u * per + slot;
-      id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.vec_base + (uint64_t)id[u] * p.vec_stride + 16u * sub);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = i0 + (uint32_t)u * per + slot;
-      int vv = dot4_8<SIGNED>(v[u].x, v[u].x, dot4_8<SIGNED>(v[u].y, v[u].y, dot4_8<SIGNED>(v[u].z, v[u].z, dot4_8<SIGNED>(v[u].w, v[u].w, qq))));
-      const int vq = dot4_8<SIGNED>(v[u].x, qw.x, dot4_8<SIGNED>(v[u].y, qw.y, dot4_8<SIGNED>(v[u].z, qw.z, dot4_8<SIGNED>(v[u].w, qw.w, 0))));
-      vv -= 2 * vq;
-      for (uint32_t off = 1; off < G; off <<= 1) vv += __shfl_xor(vv, (int)off);       // (the G lanes of a candidate are adjacent)
-      if (i < n && sub == 0u) e[i] = __float_as_uint((float)vv);
-    }
-  }
-  wave_sync();
   // K7: the k smallest {distance bits, index} keys, in order, by repeated wave-wide arg-min -- k rounds of six DPP steps instead of n^2 / 64
   // compares per lane.  Lane l keeps the minimum over ITS candidates (index = l mod 64); the round's winner is struck out by its owner, which
   // re-reads its (<= 9) candidates.  Result r of a chunk of 64 waits in lane r until the chunk is written out.
@@ -491,6 +477,93 @@ __device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, u
     p.dists_out[(size_t)r * p.Q_total + qabs] = BIG_DIST;
   }
   wave_sync();
+}
+
+template <bool SIGNED>
+__device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, uint32_t n, uint32_t* e /* LDS, n words */, int lane) {
+  constexpr int U = 4;                                            // vector fetches in flight per lane
+  const uint32_t D = p.D, G = D >> 4, per = 64u / G;              // lanes per candidate, candidates per wave instruction
+  const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
+  const uint32_t* cand = p.cand;
+  const size_t qabs = (size_t)p.q0 + q;
+  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.queries + qabs * D + 16u * sub);
+  const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
+  for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
+    uint32_t id[U];
+    u32x4a v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.vec_base + (uint64_t)id[u] * p.vec_stride + 16u * sub);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * per + slot;
+      int vv = dot4_8<SIGNED>(v[u].x, v[u].x, dot4_8<SIGNED>(v[u].y, v[u].y, dot4_8<SIGNED>(v[u].z, v[u].z, dot4_8<SIGNED>(v[u].w, v[u].w, qq))));
+      const int vq = dot4_8<SIGNED>(v[u].x, qw.x, dot4_8<SIGNED>(v[u].y, qw.y, dot4_8<SIGNED>(v[u].z, qw.z, dot4_8<SIGNED>(v[u].w, qw.w, 0))));
+      vv -= 2 * vq;
+      for (uint32_t off = 1; off < G; off <<= 1) vv += __shfl_xor(vv, (int)off);       // (the G lanes of a candidate are adjacent)
+      if (i < n && sub == 0u) e[i] = __float_as_uint((float)vv);
+    }
+  }
+  wave_sync();
+  wave_topk(p, qabs, n, e, lane);
+}
+
+// The same for FLOAT vectors (compute_L2Dist<float> :1254-1299): the ascending fmaf chain over the D dimensions is one serial chain per candidate
+// (float addition does not re-associate), so a lane runs the chain of ITS candidate -- 64 candidates per round -- over 16-byte loads of its
+// candidate's vector, RF in flight (a vector's lines are looked up once per 16 bytes: the L1 serves all but the first of a line; the standalone
+// rerank_kernel hands a vector over through LDS instead, which a wave at the end of its query has no room for).  The query sits in <= 4
+// registers of the wave (lane l of qr[t] = element 64 t + l), element j is read with v_readlane.  Same bits as rerank_kernel<float>.
+template <int RF>                                        // 16-byte vector loads in flight per lane
+__device__ __forceinline__ void wave_rerank_f32(const RerankArgs8& p, uint32_t q, uint32_t n, uint32_t* e /* LDS, n words */, int lane) {
+  const uint32_t D = p.D;                                         // a multiple of 4, <= 256
+  const uint32_t* cand = p.cand;
+  const size_t qabs = (size_t)p.q0 + q;
+  const float* qsrc = (const float*)p.queries + qabs * D;
+  float qr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const uint32_t j = (uint32_t)t * 64u + (uint32_t)lane; qr[t] = qsrc[j < D ? j : 0u]; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
+  for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {                     // (uniform)
+    const uint32_t i = i0 + (uint32_t)lane;
+    const uint32_t id = ld_bypass_l1(cand + (i < n ? i : 0u));
+    const uint8_t* v = p.vec_base + (uint64_t)id * p.vec_stride;
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                                 // the 64 dimensions whose query elements sit in qr[t]
+      const uint32_t jt = (uint32_t)t * 64u;
+      if (jt >= D) break;                                         // (uniform)
+      const uint32_t dt = D - jt < 64u ? D - jt : 64u;
+      for (uint32_t jl = 0; jl < dt; jl += 4u * RF) {             // (uniform) 4 RF dimensions = RF 16-byte loads in flight per lane and trip
+        u32x4a w[RF];
+#pragma unroll
+        for (int u = 0; u < RF; ++u) {
+          const uint32_t j = jl + 4u * (uint32_t)u;
+          w[u] = *(const u32x4a*)(v + 4u * (jt + (j < dt ? j : 0u)));       // (behind the vector's end: a piece again, never used)
+        }
+#pragma unroll
+        for (int u = 0; u < RF; ++u) {
+          const uint32_t j = jl + 4u * (uint32_t)u;
+          if (j < dt) {                                           // (uniform)
+            const uint32_t ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const float qv = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qr[t]), (int)(j + (uint32_t)d)));
+              const float diff = __uint_as_float(ww[d]) - qv;     // :1294
+              acc = __builtin_fmaf(diff, diff, acc);              // :1295, ascending dimension
+            }
+          }
+        }
+      }
+    }
+    if (i < n) e[i] = __float_as_uint(acc);
+  }
+  wave_sync();
+  wave_topk(p, qabs, n, e, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

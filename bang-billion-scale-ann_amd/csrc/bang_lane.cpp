@@ -56,9 +56,13 @@ static void print_phase_prof(const std::vector<unsigned long long>& pr, uint32_t
   for (uint32_t w = 0; w < G; ++w) for (int k = 0; k < 8; ++k) a[k] += (double)pr[(size_t)w * 16 + 8 + k];
   if (a[7] <= 0) return;
   const double n = a[7];
+  double x[3] = {0, 0, 0};                     // self-paced form: [0] hand-over (row request), [1] worklist head, [2] summary marks -- split off phases 6 / 0
+  for (uint32_t w = 0; w < G; ++w) for (int k = 0; k < 3; ++k) x[k] += (double)pr[(size_t)w * 16 + k];
   fprintf(stderr, "[search] phases of an iteration (wave 0 of %u workgroups, %.0f iterations each): row arrival + loop %.2f us, hashes + probes %.2f, "
-                  "compaction %.2f, filter update %.2f, code rows + distances %.2f, parent %.2f, publish + sort/merge %.2f\n", G, n / G,
-          a[0] * 0.01 / n, a[1] * 0.01 / n, a[2] * 0.01 / n, a[3] * 0.01 / n, a[4] * 0.01 / n, a[5] * 0.01 / n, a[6] * 0.01 / n);
+                  "compaction %.2f, filter update %.2f, code rows + distances %.2f, parent %.2f, publish + sort/merge %.2f (self-paced, split off: hand-over %.2f, "
+                  "worklist head %.2f, summary marks %.2f)\n", G, n / G,
+          a[0] * 0.01 / n, a[1] * 0.01 / n, a[2] * 0.01 / n, a[3] * 0.01 / n, a[4] * 0.01 / n, a[5] * 0.01 / n, a[6] * 0.01 / n, x[0] * 0.01 / n, x[1] * 0.01 / n,
+          x[2] * 0.01 / n);
 }
 
 static int g_dbg = -1;

@@ -59,9 +59,34 @@ __device__ __forceinline__ T karg_at(size_t off) {
   return *(const T __attribute__((address_space(4)))*)(ka + off);
 }
 #define KARG(field) karg_at<decltype(bang_search_params::field)>(offsetof(SearchArgs, p) + offsetof(bang_search_params, field))
+// a run of ADJACENT fields as one block (one or two wide scalar loads, one wait)
+template <class T>
+__device__ __forceinline__ T karg_block_at(size_t off) {
+  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const uint32_t __attribute__((address_space(4)))* src = (const uint32_t __attribute__((address_space(4)))*)(ka + off);
+  union { T t; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) u.w[i] = src[i];
+  return u.t;
+}
+#define KARG_BLOCK(type, member) karg_block_at<type>(offsetof(SearchArgs, member))
 
+// What the HAND-OVER of an iteration needs (where the next adjacency row is, where the candidate log is), laid out so that it is ONE block of the
+// kernarg segment: requested with back-to-back scalar loads once the parent is known, one wait.  Read one by one where the branches needed them
+// these were five dependent scalar round trips (~0.15 us each in a lightly loaded launch) between "the parent is known" and "its row is requested",
+// on the chain of every iteration (a 1 250-query SIFT1B-shape shard: 1.63 -> 1.53 ms).  Requested EARLIER -- in front of the parent selection, or,
+// for the arguments of the iteration's top, while the adjacency row arrives -- the launch got slower (16 more scalar registers across the arg-min:
+// docs/HISTORY.md, round 6).
+struct HotHand {                                                                                  // 64 B
+  uint32_t* d_cand_ids; const uint8_t* d_graph; uint64_t entry_len;
+  uint32_t vec_bytes, row_layout, n_rows_hbm, n_slices;
+  const uint32_t* d_rows_hbm; const uint64_t* d_row_slices;
+  uint32_t slice_rows, pad_;
+};
 struct SearchArgs {
   bang_search_params p;
+  HotHand hand __attribute__((aligned(64)));
   uint32_t lds_piv_floats;
   uint32_t wave_words;       // LDS words per wave: nctx worklists + 144 scratch (+ 32 parked context state when nctx == 2)
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
@@ -79,7 +104,8 @@ __host__ __device__ constexpr bool search_has_spec(int ndw) { return ndw == 18 |
 // per-wave scratch: sd/ti [72] + td/compaction [72]; the filter claim table (128 slots; 256 where the scratch has them) and the
 // summary's transposition area alias both, and so does the staging area of the cooperative code-row fetch (256 words: one wave
 // instruction's worth of 16-byte pieces)
-__host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) { return search_coop(ndw, host_paced) ? 256u : 144u; }
+__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced);
+__host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced);
 
 __host__ __device__ inline uint32_t search_wl_words(uint32_t L) { return (2u * L + (L + 3u) / 4u + 3u) & ~3u; }
 __host__ __device__ inline uint32_t search_wave_words(uint32_t L, uint32_t nctx, int ndw, bool host_paced) {
@@ -247,13 +273,20 @@ __device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lan
 #define SRCH_FIN 0xFFFFFFFFu        // h_done value: this context group of the workgroup has no queries left
 #define SRCH_CTX_WORDS 16u          // parked per-context state of a wave, in LDS
 
-// MAXT: threads per workgroup the instance is compiled for -- 1024 (16 waves, 128 VGPRs each) or, for the self-paced instances of
-// the long code rows (>= 64 chunks: the cooperative fetch holds a row's pieces and the row itself for a moment), 768 (12 waves, 168
-// VGPRs each; 12 waves run the request-bound layouts as fast as 15 or 16: DESIGN 4.6)
+// MAXT: threads per workgroup the instance is compiled for -- 1024 (16 waves, 128 VGPRs each) or, for the instances of the long code
+// rows (>= 64 chunks), 768 (12 waves, 168 VGPRs each).  Build switch BANG_LONG_MAXT=1024: the self-paced long-row instances as 16-wave
+// instances -- 120-127 VGPRs without scratch (LANE_FRESH below), 144 words of scratch per wave (the cooperative fetch hands its pieces over in
+// rounds, 128-slot claim table), 16 x (2L + L/4 + 144) words beside the 128 KB pivot table up to L = 161.  Measured (round 6, docs/HISTORY.md):
+// 16 waves run the 10 K SIFT1B-shape batch no faster than the 12 of the 168-VGPR build (8.31 vs 8.30 ms: the launch sits on the rate of requests
+// past L2, not on waves in flight) and the 128-VGPR code loses 3-9 % where fewer waves are resident: 768 stays the default.
 #ifndef BANG_LONG_MAXT
-#define BANG_LONG_MAXT 768           // build switch (experiments): threads per workgroup the long-row instances are compiled for
+#define BANG_LONG_MAXT 768
 #endif
-__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? BANG_LONG_MAXT : 1024; }
+__host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? (host_paced ? 768 : BANG_LONG_MAXT) : 1024; }
+// 256 words where 12 waves share the LDS beside the pivot table; the 16-wave instances hand the pieces of the cooperative fetch over in rounds (144)
+__host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) {
+  return search_coop(ndw, host_paced) ? ((ndw >= 16 && search_maxt(ndw, host_paced) >= 1024) ? 144u : 256u) : 144u;
+}
 
 template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST, bool SPEC>
 __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const SearchArgs a) {
@@ -279,7 +312,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
     }
   }
-  const int lane = lane_id();
+  const int lane0 = lane_id();
+  int lane = lane0;                                // (re-derived per phase inside the loop: LANE_FRESH)
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
   const uint32_t nctx = HOST ? a.nctx : 1u;
@@ -318,10 +352,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   constexpr bool EARLY_ROWS = !HOST;                           // code rows requested before the filter update (host-paced instances: behind it --
                                                                // 60-100 B of scratch per lane otherwise)
   constexpr bool COOP = search_coop(NDW, HOST);                // ... by P adjacent lanes per row, one 16-byte piece each
+  constexpr uint32_t SCR = search_scratch_words(NDW, HOST);    // words of per-wave scratch: 144, or 256 (12-wave instances)
   // SPEC (instances of the long-row layouts, chosen per launch: spec_rows): the code rows of ALL ids of the adjacency row are requested
   // together with their filter probes, one memory latency earlier; the distances of the ids the filter then drops are computed and thrown
   // away (every lane runs the reduce anyway), the survivors' are compacted behind it.  Same distances for the same ids: same results.
   static_assert(!SPEC || !HOST, "the speculative row request belongs to the self-paced form");
+
   const uint32_t code_stride = p.code_stride ? p.code_stride : p.m;
 
   // ---- state of the context this wave is working on (registers; parked in LDS between half-rounds when there are two)
@@ -370,13 +406,18 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 #ifdef BANG_SEARCH_PHASE_PROF
   // diagnostic build (make CXXFLAGS+=-DBANG_SEARCH_PHASE_PROF): wave 0 of every workgroup stamps the phase boundaries of its
   // iterations (no draining: a phase ends where the compiler had to wait for its results anyway) into p.d_prof[wg][8 + k]
-  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_n = 0;
+  unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_n = 0;
 #define PH(k) do { if (wave == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); ph_acc[k] += t_ - ph_t; ph_t = t_; } } while (0)
 #else
 #define PH(k) do {} while (0)
 #endif
 
+  // The lane number passes through an empty asm at the top of an iteration and in front of its register-hungry phases: whatever is derived from it
+  // (LDS addresses of the scratch areas, the worklist, the claim table ...) is re-derived there with one or two VALU instructions instead of living in a
+  // register across the whole loop -- hoisted out of the loop these invariants cost the 128-VGPR instances ~20 registers they do not have.
+#define LANE_FRESH() do { if (BANG_LONG_MAXT >= 1024) { lane = lane0; asm volatile("" : "+v"(lane)); } } while (0)
   for (uint32_t half = 0;; ++half) {
+    LANE_FRESH();
     const uint32_t c = HOST ? (nctx == 2 ? (half & 1u) : 0u) : 0u;
     if (HOST) {
       if (dead_mask == (nctx == 2 ? 3u : 1u)) break;
@@ -457,6 +498,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
+    HotHand hand;                                     // the hand-over's arguments
+    __builtin_memset(&hand, 0, sizeof(hand));
     // self-paced form: the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting
     // for the next adjacency row (nothing reads the summary in between)
     constexpr bool SET_LATE = !HOST;
@@ -539,11 +582,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // The claim rounds run now, on LDS, while the code rows travel; the stores they decide on are issued once the rows are here.
       bool pa = pass0, pb = pass0, st_a = false, st_b = false;
       uint32_t sv_a = 0, sv_b = 0;
-      filter_commit<COOP ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
+      filter_commit<SCR >= 256 ? 256 : 128>(tbl, lane, pa, h0a >> 5, 1u << (h0a & 31), w0a, pb, h0b >> 5, 1u << (h0b & 31), w0b, st_a, sv_a, st_b, sv_b);
       // the words about to be stored to are no longer zero (only those the summary did not know yet need marking)
       if (SUMM && summ_on) {
         if (SET_LATE && !first) { sl_a = pass0 && !la; sl_b = pass0 && !lb; sl_ua = h0a >> 5; sl_ub = h0b >> 5; }
-        else summ.template set<COOP ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
+        else summ.template set<SCR >= 256 ? 4 : 2>(tbl, lane, pass0 && !la, h0a >> 5, pass0 && !lb, h0b >> 5, pass1, h1a >> 5, h1b >> 5);
       }
       auto filter_stores = [&]() {
         asm volatile("" ::: "memory");
@@ -564,9 +607,10 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
 
       PH(3);   // filter update (claim table + stores issued)
       // ---------------- K2: PQ distances (compute_neighborDist_par :1201-1241) ----------------
+      LANE_FRESH();
       {
         if (COOP && !EARLY_ROWS) cf.issue(d_codes, code_stride, sid0, n < 64u ? n : 64u, lane);
-        if (COOP) cf.collect(row, scratch, code_stride, SPEC ? x0 : sid0, lane);     // (all lanes: the pieces change hands through LDS)
+        if (COOP) cf.template collect<(int)SCR>(row, scratch, code_stride, SPEC ? x0 : sid0, lane);     // (all lanes: the pieces change hands through LDS)
         if (EARLY_ROWS) {
           // the rows have arrived (per-lane loads: every row register passes through an empty asm, which is where the compiler waits
           // for them): now the filter stores -- their acknowledgements are not waited for until the next row is needed
@@ -616,6 +660,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
 
       // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ----------------
+      LANE_FRESH();
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
       const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
       PH(4);   // code rows returned + distances
@@ -648,34 +693,34 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       parent = uni(parent);
       if (found) {
         if (from_best) mark = parent;
-        if (lane == 0) KARG(d_cand_ids)[(size_t)q * cand_stride + cc] = parent;      // :1451-1458
-        ++cc;
+        ++cc;                                                  // (the candidate-log store :1451-1458 is issued behind the row request: it is not on the chain)
       }
     }
     const bool want_row = active && found && iter < cap_iter;
     PH(5);     // parent selection
 
     // ---------------- hand the parent over
+    if (active && found) hand = KARG_BLOCK(HotHand, hand);      // (the hand-over's arguments: one block of the kernarg segment, HotHand)
     if (!HOST) {
       // graph resident in HBM: the next adjacency row is requested NOW, straight into the registers the next iteration reads (no copy at the
       // loop's end that would wait for it); it travels while the survivors are merged
       if (want_row) {
-        const uint8_t* gbase = KARG(d_graph);                // (the hand-over's arguments are read here, once per iteration: KARG)
-        if (KARG(row_layout)) {                              // adjacency rows (pinned host memory, pull mode): 64 ids, padded
+        const uint8_t* gbase = hand.d_graph;
+        if (hand.row_layout) {                                // adjacency rows (pinned host memory, pull mode): 64 ids, padded
           // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those.  Peer rows
           // (n_slices > 1): slice parent / slice_rows of the node's HBM-resident rows -- this GPU's HBM or a peer's over xGMI; the table
           // holds biased base addresses (0: that slice is not there), read through the scalar cache
           const uint32_t* hb = nullptr;
-          const uint32_t nsl = KARG(n_slices);
+          const uint32_t nsl = hand.n_slices;
           if (nsl > 1u) {
-            const uint32_t sl = parent / KARG(slice_rows);                   // (uniform: scalar)
-            if (sl < nsl) hb = (const uint32_t*)(uintptr_t)KARG(d_row_slices)[sl];
-          } else if (parent < KARG(n_rows_hbm)) hb = KARG(d_rows_hbm);
+            const uint32_t sl = parent / hand.slice_rows;                      // (uniform: scalar)
+            if (sl < nsl) hb = (const uint32_t*)(uintptr_t)((const uint64_t __attribute__((address_space(4)))*)hand.d_row_slices)[sl];     // (s_load: a vector load here is waited for with vmcnt(0) -- behind every filter store in flight)
+          } else if (parent < hand.n_rows_hbm) hb = hand.d_rows_hbm;
           if (hb) x0 = hb[(uint64_t)parent * 64u + lane];
           else x0 = __builtin_nontemporal_load((const uint32_t*)gbase + (uint64_t)parent * 64u + lane);
           cnt_in = 64u;                                      // counted when the row is consumed
         } else {
-          const uint32_t* nrow = (const uint32_t*)(gbase + (uint64_t)parent * KARG(entry_len) + KARG(vec_bytes));
+          const uint32_t* nrow = (const uint32_t*)(gbase + (uint64_t)parent * hand.entry_len + hand.vec_bytes);
           cnt_in = nrow[0];
           x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
         }
@@ -686,8 +731,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // asks for the row now -- it travels during the sort/merge, as in the self-paced form -- and publishes "nothing to fetch"
       self_row = false;
       if (nctx == 1u && want_row && !p.ship_vectors) {
-        const uint32_t nh = KARG(n_rows_hbm);
-        if (parent < nh) { self_row = true; x0 = KARG(d_rows_hbm)[(uint64_t)parent * 64u + lane]; cnt_in = 64u; }
+        if (parent < hand.n_rows_hbm) { self_row = true; x0 = hand.d_rows_hbm[(uint64_t)parent * 64u + lane]; cnt_in = 64u; }
       }
       if (lane == 0) {
         // parents travel to the host in one coalesced store per workgroup.  A parent whose vector the walker must ship (vectors
@@ -727,8 +771,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       if (c) rounds1 = round; else rounds0 = round;
     }
 
+    PH(8);     // hand-over: the next row is requested
+    if (active && found && lane == 0) hand.d_cand_ids[(size_t)q * cand_stride + cc - 1u] = parent;      // :1451-1458 (cc counts it already)
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
+      LANE_FRESH();
       if (n > 0 && iter < cap_iter) {
         w_n = sort_and_merge(s, n, d0, sid0, d1, sid1, iter, w_n, L, medoid, mark, head.tail, lane);
       }
@@ -758,7 +805,9 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
             rr.D = KARG(rr_D); rr.k = KARG(rr_k); rr.q0 = KARG(rr_q0); rr.Q_total = KARG(rr_Q_total);
             rr.cand = KARG(d_cand_ids) + (size_t)q * cand_stride;
             const uint32_t nc = cc < cand_stride ? cc : cand_stride;
-            if (KARG(rr_dtype) == BANG_I8) wave_rerank8<true>(rr, q, nc, wbase, lane);
+            const uint32_t rdt = KARG(rr_dtype);
+            if (rdt == BANG_F32) wave_rerank_f32<4>(rr, q, nc, wbase, lane);
+            else if (rdt == BANG_I8) wave_rerank8<true>(rr, q, nc, wbase, lane);
             else wave_rerank8<false>(rr, q, nc, wbase, lane);
           }
         }
@@ -767,9 +816,11 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         ++iter;
         have_row = found;
         head = worklist_head(s, w_n, lane);
+        PH(9);   // worklist head
         if (HOST && !self_row) { cnt_in = 0; x0 = 0; }                       // (the walker's rows are read at the top of the next round)
         // the words this iteration's survivors stored to are no longer zero: marked now, under the latency of the row just requested
-        if (SUMM && SET_LATE) summ.template set<COOP ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
+        if (SUMM && SET_LATE) summ.template set<SCR >= 256 ? 4 : 2>(tbl, lane, sl_a, sl_ua, sl_b, sl_ub, false, 0u, 0u);
+        PH(10);  // summary marks
       }
     }
     if (HOST && nctx == 2) {                                             // park context c
@@ -793,6 +844,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     unsigned long long* o = p.d_prof + (size_t)blockIdx.x * 16 + 8;
     for (int k = 0; k < 7; ++k) o[k] = ph_acc[k];
     o[7] = ph_n;
+    if (!HOST) { unsigned long long* x = p.d_prof + (size_t)blockIdx.x * 16; x[0] = ph_acc[8]; x[1] = ph_acc[9]; x[2] = ph_acc[10]; }
   }
 #endif
 #undef PH
@@ -861,7 +913,9 @@ static uint32_t waves_that_fit(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t
 
 extern "C" int bang_search_can_rerank(int dtype, uint32_t D, uint64_t vec_stride, uint32_t dim_adjust) {
   const uint32_t G = D >> 4;
-  return (dtype == BANG_U8 || dtype == BANG_I8) && dim_adjust == 0 && D >= 16 && (D & 15u) == 0 && D <= 256 && (G & (G - 1u)) == 0 && (vec_stride & 3u) == 0;
+  if (dim_adjust != 0 || (vec_stride & 3u) != 0 || D > 256) return 0;
+  if (dtype == BANG_F32) return D >= 4 && (D & 3u) == 0;                       // (one lane per candidate: wave_rerank_f32)
+  return (dtype == BANG_U8 || dtype == BANG_I8) && D >= 16 && (D & 15u) == 0 && (G & (G - 1u)) == 0;
 }
 
 extern "C" int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L) {
@@ -924,6 +978,10 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   SearchArgs a;
   a.p = *p;
   a.lds_piv_floats = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
+  __builtin_memset(&a.hand, 0, sizeof(a.hand));
+  a.hand.d_cand_ids = p->d_cand_ids; a.hand.d_graph = p->d_graph; a.hand.entry_len = p->entry_len; a.hand.vec_bytes = p->vec_bytes;
+  a.hand.row_layout = p->row_layout; a.hand.n_rows_hbm = p->n_rows_hbm; a.hand.n_slices = p->n_slices; a.hand.d_rows_hbm = p->d_rows_hbm;
+  a.hand.d_row_slices = p->d_row_slices; a.hand.slice_rows = p->slice_rows;
   uint32_t grid_n = 0, waves = 0, nctx = p->nctx, gs = p->group_waves;
   const int rc = bang_search_geometry(p->psz, p->mp, p->pq_nhi, p->L, p->Q, p->max_wgs, p->max_waves, p->d_graph ? 0 : 1, &grid_n, &waves, &nctx, &gs);
   if (rc != BANG_OK) return rc;

@@ -55,7 +55,7 @@ from tools.bench_legs.common import (ARITH_DTYPE, T_PROCESS_START, WORKLOADS, Ct
 from tools.bench_legs.cpu import cpu_baseline_shape, cpu_baseline_structured  # noqa: E402
 from tools.bench_legs.k2 import k2_alone  # noqa: E402
 from tools.bench_legs.traffic import live_traffic  # noqa: E402
-from tools.bench_legs import launch as _launch, legs as _legs, shards as _shards  # noqa: E402
+from tools.bench_legs import ceiling as _ceiling, launch as _launch, legs as _legs, shards as _shards  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------------- build first
@@ -74,6 +74,7 @@ def build_everything(rank, world):
         bang_amd.build()
         O.build()
         shape_workload._lib()
+        _ceiling.build()
         if world > 1:
             os.makedirs(os.path.dirname(stamp), exist_ok=True)
             open(stamp, "w").write(str(time.time()))
@@ -112,7 +113,7 @@ def main():
                          "oracle can check the results -- parity runs of the sharded job at reduced N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the side measurements (other configs, K2 alone)")
-    ap.add_argument("--legs", default="", help="comma list of legs to run (default: shards,walker,k2,sift300m,sift1m,deep100m,sift10m; on request: sift100m, sift1b)")
+    ap.add_argument("--legs", default="", help="comma list of legs to run (default: shards,walker,ceiling,k2,sift300m,sift1m,deep100m,sift10m; on request: sift100m, sift1b)")
     ap.add_argument("--leg-budget-s", type=float, default=600.0,
                     help="a leg is skipped (and listed in config.legs_skipped) once the run -- counted from the start of the process -- has "
                          "taken this long: the default run stays within minutes")
@@ -214,6 +215,7 @@ def main():
                "graph": graph,
                "parity_vs_oracle_first_64" if prim["structured"] else "result_properties_ok": prim["ok"],
                "reduced_n_hip_ids_equal_oracle": None, "k2_alone_frac": None, "k2_alone_GBps": None,
+               "requests_G_per_s": None, "request_ceiling_G_per_s": None, "request_frac": None,
                "traffic_over_algorithmic": (res["roofline"] or {}).get("traffic_over_algorithmic"),
                "qps_incl_init": res["qps_incl_init"], "rerank_fused": int(agg.get("rerank_fused", 0)),
                "shard_ms_5000": None, "shard_ms_2500": None, "shard_ms_1250": None, "gather_ms_world1": None,
@@ -300,6 +302,18 @@ def main():
     if leg_on("walker") and pulled:
         guarded("at_sift1b_shape_walker", lambda: _shards.leg_walker_rows(run, prim, L))
     release_config(prim)
+
+    # ------------------------------------------------------------------ the request ceiling: what bounds a stream of random, never re-used requests past L2
+    if leg_on("ceiling") and out is not None and out["roofline"] is not None:
+        try:
+            ceil = _ceiling.request_ceiling()
+            rq = _ceiling.request_roofline(ctx.live_traffic, out["roofline"].get("avg_launch_us"), ceil)
+            out["roofline"]["requests"] = rq if rq else {"ceiling": ceil, "note": "no live PMC passes in this run: the launch's own request count is not known"}
+            cfg["request_ceiling_G_per_s"] = ceil.get("search_mix")
+            if rq:
+                cfg["requests_G_per_s"], cfg["request_frac"] = rq["achieved"], rq["frac"]
+        except Exception as ex:
+            out["roofline"]["requests"] = {"error": repr(ex)[:300]}
 
     # ------------------------------------------------------------------ K2 alone (the stage the BASELINE metric quotes an HBM figure for)
     if leg_on("k2") and out is not None and out["roofline"] is not None:

@@ -398,8 +398,9 @@ typedef struct {
    * that finishes a query re-ranks its candidate log on the spot -- exact distances to the full-precision vectors at rr_vec_base + id *
    * rr_vec_stride, stable rank by (distance, expansion order) -- and writes the query's k results; no second launch behind the search, and
    * the re-rank of all but the last queries runs under the search of the others.  rr_queries == NULL: not fused (bang_k_rerank* follows).
-   * Needs D % 16 == 0, D <= 256, D / 16 a power of two, rr_vec_stride % 4 == 0 (bang_search_can_rerank).  Same bits as bang_k_rerank. */
-  const void* rr_queries;              /* [rr_Q_total][D] raw queries (u8 / i8), row rr_q0 + q belongs to this launch's query q */
+   * 8-bit vectors: D % 16 == 0, D <= 256, D / 16 a power of two (D / 16 lanes per candidate, exact integers by v_dot4); float vectors: D % 4 == 0, D <= 256
+   * (one lane per candidate runs the ascending fmaf chain); rr_vec_stride % 4 == 0, no MIPS padding (bang_search_can_rerank).  Same bits as bang_k_rerank. */
+  const void* rr_queries;              /* [rr_Q_total][D] raw queries (u8 / i8 / f32), row rr_q0 + q belongs to this launch's query q */
   const uint8_t* rr_vec_base;
   uint64_t rr_vec_stride;
   uint64_t* rr_ids_out;                /* [rr_Q_total][k] */

@@ -70,10 +70,12 @@ def test_soak_slice(libbang):
 
 @pytest.mark.parametrize("L", [10, 152])
 @pytest.mark.parametrize("graph", [0, 1])
-@pytest.mark.parametrize("fixture", ["small_u8", "small_i8"])
+@pytest.mark.parametrize("fixture", ["small_u8", "small_i8", "small_f32", "small_deep"])
 def test_fused_rerank_matches_oracle_and_the_rerank_launch(request, libbang, fixture, graph, L):
-    """K6 + K7 inside the search launch (8-bit vectors, self-paced form: compute_L2Dist bang_search.cu:1254-1299, compute_NearestNeighbours
-    :1312-1368 by the wave that finishes the query) against the oracle and against the separate re-rank launch: ids, distance bits, [rank][Q] layout."""
+    """K6 + K7 inside the search launch (self-paced form: compute_L2Dist<T> bang_search.cu:1254-1299 -- one template over u8 / i8 / float --,
+    compute_NearestNeighbours :1312-1368, by the wave that finishes the query) against the oracle and against the separate re-rank launch: ids,
+    distance bits, [rank][Q] layout.  8-bit vectors: D / 16 lanes per candidate, exact integers; float vectors (round 6): one lane per candidate
+    runs the ascending fmaf chain."""
     import bang_amd
     from oracle import oracle as O
     ix, q, _, _ = request.getfixturevalue(fixture)
@@ -90,6 +92,29 @@ def test_fused_rerank_matches_oracle_and_the_rerank_launch(request, libbang, fix
             e.free(); e.unload()
     for fuse in (1, 0):
         assert np.array_equal(out[fuse][0], ids_o) and np.array_equal(out[fuse][1].view(np.uint32), dists_o.view(np.uint32)), fuse
+
+
+def test_fused_rerank_float_vectors_odd_dimension_counts_and_short_logs(libbang):
+    """Float vectors whose dimension count is no multiple of 16 (the last trip of a lane's chain loads fewer than four pieces) and one beyond
+    64 dimensions with a partial second register of query elements; k > candidates (CANON 8 tail); both placements."""
+    import bang_amd
+    from bang_amd import synth
+    from oracle import oracle as O
+    for (N, D, R, m, seed) in ((2000, 40, 32, 16, 5), (1500, 72, 64, 16, 6)):
+        ix, q, _, _ = synth.make_index(N, D, "float", R, m, 24, K=10, n_clusters=16, seed=seed, device="cpu", pq_iters=3)
+        orc = O.Oracle(ix)
+        for (k, L) in ((10, 30), (20, 21)):
+            ids_o, dists_o = orc.search(q, k, L)
+            for graph in (0, 1):
+                with bang_amd.Engine(ix.dtype, graph=graph, search=1) as e:
+                    e.load_index(ix)
+                    e.set_searchparams(k, L)
+                    e.alloc(q.shape[0])
+                    e.init(q.shape[0])
+                    ids, dists = e.query(q)
+                    assert e.stats()["rerank_fused"] == 1 and e.stats()["search_kernel"] == 1, (D, e.stats())
+                    e.free(); e.unload()
+                assert np.array_equal(ids, ids_o) and np.array_equal(dists.view(np.uint32), dists_o.view(np.uint32)), (D, k, L, graph)
 
 
 def test_fused_rerank_short_logs_many_lanes_and_big_k(libbang, small_u8):
