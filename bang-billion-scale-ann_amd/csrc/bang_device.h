@@ -11,6 +11,10 @@
 #include "bang_internal.h"
 
 #define WAVE 64
+// A pointer the kernel rebuilds from an integer (IterArgs, a slice-table entry, a kernarg field read with KARG) is a GENERIC pointer to the compiler and every
+// access through it a flat_ instruction -- which counts in lgkmcnt as well as vmcnt, so that every wait for an LDS result also waits for the loads in flight.
+// Typed as global (address space 1) it is a global_ instruction again (and may take its base from scalar registers).
+#define GAS __attribute__((address_space(1)))
 #define BIG_DIST ((float)3.402823E+38)  // bang_search.cu:1406,1484
 
 typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
@@ -150,6 +154,9 @@ __device__ __forceinline__ float lut_entry(const float* __restrict__ piv_lds, co
 // A code row is fetched with 16-byte loads from its 4-byte-aligned base (pq_row_load) and consumed by
 // straight-line code (pq_row_reduce) so that the compiler can batch the LDS reads and scalar loads;
 // splitting load from use lets the caller put another query's row in flight first.
+// reinterpret a byte pointer of either address space as a pointer to T of the same address space
+template <class T> __device__ __forceinline__ T* ptr_as(const uint8_t* q) { return (T*)q; }
+template <class T> __device__ __forceinline__ T GAS* ptr_as(const uint8_t GAS* q) { return (T GAS*)q; }
 template <int NDW, bool ALIGNED>
 struct PqRow {
   static constexpr int NLOAD = ALIGNED ? NDW : NDW + 1;   // dwords needed from the aligned base
@@ -158,12 +165,12 @@ struct PqRow {
   uint32_t sh;
 };
 
-template <int NDW, bool ALIGNED>
-__device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, const uint8_t* __restrict__ codes, uint32_t m,
-                                            uint32_t id) {
+// (CP: `const uint8_t*` or `const uint8_t GAS*`)
+template <int NDW, bool ALIGNED, class CP>
+__device__ __forceinline__ void pq_row_load(PqRow<NDW, ALIGNED>& r, CP codes, uint32_t m, uint32_t id) {
   const uint64_t a = (uint64_t)id * m;  // 64-bit row offset, :1232
   r.sh = (uint32_t)a & 3u;
-  const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull));
+  const auto p = ptr_as<const u32x4a>(codes + (a & ~3ull));
 #pragma unroll
   for (int i = 0; i < PqRow<NDW, ALIGNED>::NX4; ++i) {
     const u32x4a v = p[i];
@@ -189,7 +196,8 @@ struct CoopFetch {
   static constexpr int LDS_WORDS = RPI * P * 4;        // staging: one instruction's worth of pieces (<= 256 words)
   u32x4a v[NI];
   // id: the row this lane will evaluate (valid for lane < n); every lane of the wave must be executing
-  __device__ __forceinline__ void issue(const uint8_t* __restrict__ codes, uint32_t stride, uint32_t id, uint32_t n, int lane) {
+  template <class CP>                                  // `const uint8_t*` or `const uint8_t GAS*`
+  __device__ __forceinline__ void issue(CP codes, uint32_t stride, uint32_t id, uint32_t n, int lane) {
     const uint32_t slot = (uint32_t)lane / (uint32_t)P, piece = (uint32_t)lane % (uint32_t)P;
     // all the ids first (NI independent ds_bpermute in flight), then the loads: interleaved, every load waits for its own id's round
     // trip through the LDS crossbar
@@ -203,7 +211,7 @@ struct CoopFetch {
       // a lane with no row to fetch reads row 0 instead of sitting the instruction out: a load under a branch makes the compiler's
       // count of outstanding memory operations inexact, and every later wait for an OLDER load then becomes a wait for everything
       const uint64_t a = ok ? (uint64_t)rid[j] * stride : 0ull;
-      const u32x4a* p = (const u32x4a*)(codes + (a & ~3ull)) + (ok ? piece : 0u);
+      const auto p = ptr_as<const u32x4a>(codes + (a & ~3ull)) + (ok ? piece : 0u);
       // non-temporal: a code row is read once and never again -- marked so, it does not push the resident queries' filter lines out of L2 / the
       // Infinity Cache as fast (10 K SIFT1B-shape batch 8.15 -> 7.98 ms).  Round 3 had measured the hint slower with per-lane loads: an `nt` load
       // by-passes L1, and a lane walking its own row then turned every one of its five loads into an L2 request; here the P lanes of a row ask
@@ -401,6 +409,7 @@ __device__ __forceinline__ uint32_t upper_bound_lds(const float* arr, uint32_t h
 __device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t* p) {   // global_load_dword sc1: served by L2, never by a stale L1 line
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t ld_bypass_l1(const uint32_t GAS* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Wave-wide minimum of a 64-bit key {hi, lo} (lexicographic, unsigned), returned to every lane.  Six DPP steps (quad swaps, row
 // half-mirror / mirror, two row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar per operand.
@@ -438,13 +447,13 @@ __device__ __forceinline__ int dot4_8(uint32_t a, uint32_t b, int c) {
   if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
   return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
 }
-struct RerankArgs8 {                                    // bang_search_params.rr_*, as the kernel read them at the query's end
-  const void* queries; const uint8_t* vec_base; uint64_t vec_stride; uint64_t* ids_out; float* dists_out; const uint32_t* cand;
+struct RerankArgs8 {                                    // bang_search_params.rr_*, as the kernel read them at the query's end (global address space: GAS)
+  const uint8_t GAS* queries; const uint8_t GAS* vec_base; uint64_t vec_stride; uint64_t GAS* ids_out; float GAS* dists_out; const uint32_t GAS* cand;
   uint32_t D, k, q0, Q_total;
 };
 // K7 of the fused re-rank (compute_NearestNeighbours :1312-1368): e[0, n) = the exact distances' bit patterns in LDS, in expansion order
 __device__ __forceinline__ void wave_topk(const RerankArgs8& p, size_t qabs, uint32_t n, uint32_t* e, int lane) {
-  const uint32_t* cand = p.cand;
+  const uint32_t GAS* cand = p.cand;
   // K7: the k smallest {distance bits, index} keys, in order, by repeated wave-wide arg-min -- k rounds of six DPP steps instead of n^2 / 64
   // compares per lane.  Lane l keeps the minimum over ITS candidates (index = l mod 64); the round's winner is struck out by its owner, which
   // re-reads its (<= 9) candidates.  Result r of a chunk of 64 waits in lane r until the chunk is written out.
@@ -484,9 +493,9 @@ __device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, u
   constexpr int U = 4;                                            // vector fetches in flight per lane
   const uint32_t D = p.D, G = D >> 4, per = 64u / G;              // lanes per candidate, candidates per wave instruction
   const uint32_t sub = (uint32_t)lane & (G - 1u), slot = (uint32_t)lane / G;
-  const uint32_t* cand = p.cand;
+  const uint32_t GAS* cand = p.cand;
   const size_t qabs = (size_t)p.q0 + q;
-  const u32x4a qw = *(const u32x4a*)((const uint8_t*)p.queries + qabs * D + 16u * sub);
+  const u32x4a qw = *(const u32x4a GAS*)(p.queries + qabs * D + 16u * sub);
   const int qq = dot4_8<SIGNED>(qw.x, qw.x, dot4_8<SIGNED>(qw.y, qw.y, dot4_8<SIGNED>(qw.z, qw.z, dot4_8<SIGNED>(qw.w, qw.w, 0))));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the log's last word has reached L2 (it is read back past L1)
   for (uint32_t i0 = 0; i0 < n; i0 += per * U) {                  // (uniform)
@@ -498,7 +507,7 @@ __device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, u
       id[u] = ld_bypass_l1(cand + (i < n ? i : 0u));
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a*)(p.vec_base + (uint64_t)id[u] * p.vec_stride + 16u * sub);
+    for (int u = 0; u < U; ++u) v[u] = *(const u32x4a GAS*)(p.vec_base + (uint64_t)id[u] * p.vec_stride + 16u * sub);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = i0 + (uint32_t)u * per + slot;
@@ -521,9 +530,9 @@ __device__ __forceinline__ void wave_rerank8(const RerankArgs8& p, uint32_t q, u
 template <int RF>                                        // 16-byte vector loads in flight per lane
 __device__ __forceinline__ void wave_rerank_f32(const RerankArgs8& p, uint32_t q, uint32_t n, uint32_t* e /* LDS, n words */, int lane) {
   const uint32_t D = p.D;                                         // a multiple of 4, <= 256
-  const uint32_t* cand = p.cand;
+  const uint32_t GAS* cand = p.cand;
   const size_t qabs = (size_t)p.q0 + q;
-  const float* qsrc = (const float*)p.queries + qabs * D;
+  const float GAS* qsrc = (const float GAS*)p.queries + qabs * D;
   float qr[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { const uint32_t j = (uint32_t)t * 64u + (uint32_t)lane; qr[t] = qsrc[j < D ? j : 0u]; }
@@ -531,7 +540,7 @@ __device__ __forceinline__ void wave_rerank_f32(const RerankArgs8& p, uint32_t q
   for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {                     // (uniform)
     const uint32_t i = i0 + (uint32_t)lane;
     const uint32_t id = ld_bypass_l1(cand + (i < n ? i : 0u));
-    const uint8_t* v = p.vec_base + (uint64_t)id * p.vec_stride;
+    const uint8_t GAS* v = p.vec_base + (uint64_t)id * p.vec_stride;
     float acc = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {                                 // the 64 dimensions whose query elements sit in qr[t]
@@ -543,7 +552,7 @@ __device__ __forceinline__ void wave_rerank_f32(const RerankArgs8& p, uint32_t q
 #pragma unroll
         for (int u = 0; u < RF; ++u) {
           const uint32_t j = jl + 4u * (uint32_t)u;
-          w[u] = *(const u32x4a*)(v + 4u * (jt + (j < dt ? j : 0u)));       // (behind the vector's end: a piece again, never used)
+          w[u] = *(const u32x4a GAS*)(v + 4u * (jt + (j < dt ? j : 0u)));       // (behind the vector's end: a piece again, never used)
         }
 #pragma unroll
         for (int u = 0; u < RF; ++u) {

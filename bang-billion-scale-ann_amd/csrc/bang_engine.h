@@ -228,7 +228,7 @@ struct bang_engine {
   uint32_t* d_qiters = nullptr;        // [Q] iterations per query (search kernel)
   uint32_t* d_qskip = nullptr;         // [Q] filter-word loads saved by the on-chip summary (search kernel, self-paced)
   bool rerank_fused = false;           // the last bang_query re-ranked inside the search launch
-  int fuse_rerank = -1;                // option "fuse_rerank": K6 + K7 inside the search launch (self-paced form, 8-bit vectors); -1 = auto = on
+  int fuse_rerank = -1;                // option "fuse_rerank": K6 + K7 inside the search launch (self-paced form; 8-bit and float vectors); -1 = auto = on
   std::vector<uint32_t> h_qiters;
   bool stage_local = false;            // rows are staged in local device memory (BAR mode)
   int pq_ragged = 1;                   // 2-float PQ layouts: exact-size pivot table where possible (0 = always the padded table)

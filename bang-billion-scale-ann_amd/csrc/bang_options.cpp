@@ -57,7 +57,7 @@ static const OptionDef kOptions[] = {
     {"timing", "BANG_TIMING", &bang_engine::timing, 0, 1, INT, BEFORE_ALLOC, "1 = stamp every search / front launch in-kernel (s_memrealtime) for bang_get_stats"},
     {"front_wgs", "BANG_FRONT_WGS", &bang_engine::front_wgs_opt, -1, 1 << 20, INT, BEFORE_ALLOC, "launch-per-iteration loop: workgroups per front launch (-1 = auto, 0 = all CUs)"},
     {"fuse_rerank", "BANG_FUSE_RERANK", &bang_engine::fuse_rerank, -1, 1, INT, ANY,
-     "self-paced search kernel, 8-bit vectors resident in HBM: 1 / -1 (auto) = the wave that finishes a query re-ranks it on the spot (K6 + K7 inside the search launch), "
+     "self-paced search kernel, vectors resident in HBM (8-bit: D % 16 == 0; float: D % 4 == 0; D <= 256, no MIPS): 1 / -1 (auto) = the wave that finishes a query re-ranks it on the spot (K6 + K7 inside the search launch), "
      "0 = a re-rank launch behind the search.  Same results"},
     // ---- may change between queries
     {"use_flag", "BANG_USE_FLAG", &bang_engine::use_flag, 0, 1, FLAG, BEFORE_ALLOC, "0 = wait for the front kernel with runtime calls instead of its in-kernel completion flag (ablation)"},

@@ -58,35 +58,46 @@ __device__ __forceinline__ T karg_at(size_t off) {
   asm volatile("" : "+s"(ka));
   return *(const T __attribute__((address_space(4)))*)(ka + off);
 }
-#define KARG(field) karg_at<decltype(bang_search_params::field)>(offsetof(SearchArgs, p) + offsetof(bang_search_params, field))
-// a run of ADJACENT fields as one block (one or two wide scalar loads, one wait)
-template <class T>
-__device__ __forceinline__ T karg_block_at(size_t off) {
-  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
-  const uint32_t __attribute__((address_space(4)))* src = (const uint32_t __attribute__((address_space(4)))*)(ka + off);
-  union { T t; uint32_t w[sizeof(T) / 4]; } u;
-#pragma unroll
-  for (size_t i = 0; i < sizeof(T) / 4; ++i) u.w[i] = src[i];
-  return u.t;
+// One 64-bit word of a small device table through the SCALAR cache (uniform index).  Written as a plain load the compiler makes it a vector
+// load -- it cannot prove the index uniform under the hand-over's branches -- and waits for it with vmcnt(0): behind every filter store still in
+// flight, on the chain of every iteration (peer rows: the slice table).  The wait is inside the statement: nothing can be scheduled between the
+// request and it.
+__device__ __forceinline__ uint64_t scalar_load_u64(uint64_t tab, uint32_t idx) {
+  uint64_t v;
+  const uint64_t a = tab + 8ull * idx;                  // (uniform, but not provably so: made so)
+  const uint64_t at = ((uint64_t)uni((uint32_t)(a >> 32)) << 32) | uni((uint32_t)a);
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(at) : "memory");
+  return v;
 }
-#define KARG_BLOCK(type, member) karg_block_at<type>(offsetof(SearchArgs, member))
+#define KARG(field) karg_at<decltype(bang_search_params::field)>(offsetof(SearchArgs, p) + offsetof(bang_search_params, field))
+// ... a pointer field, as a pointer to global memory (bang_device.h GAS: a pointer read this way is generic to the compiler otherwise, its accesses flat_)
+#define KARGP(type, field) ((type GAS*)(uintptr_t)KARG(field))
 
-// What the HAND-OVER of an iteration needs (where the next adjacency row is, where the candidate log is), laid out so that it is ONE block of the
-// kernarg segment: requested with back-to-back scalar loads once the parent is known, one wait.  Read one by one where the branches needed them
-// these were five dependent scalar round trips (~0.15 us each in a lightly loaded launch) between "the parent is known" and "its row is requested",
-// on the chain of every iteration (a 1 250-query SIFT1B-shape shard: 1.63 -> 1.53 ms).  Requested EARLIER -- in front of the parent selection, or,
-// for the arguments of the iteration's top, while the adjacency row arrives -- the launch got slower (16 more scalar registers across the arg-min:
-// docs/HISTORY.md, round 6).
-struct HotHand {                                                                                  // 64 B
-  uint32_t* d_cand_ids; const uint8_t* d_graph; uint64_t entry_len;
-  uint32_t vec_bytes, row_layout, n_rows_hbm, n_slices;
-  const uint32_t* d_rows_hbm; const uint64_t* d_row_slices;
-  uint32_t slice_rows, pad_;
+// What an ITERATION needs of the launch's arguments (as opposed to a query: KARG) -- where the code table, the filters, the candidate log and the next
+// adjacency row are -- travels in the LANES OF ONE VECTOR REGISTER of the wave (lane k = dword k of this block, loaded once at the wave's start) and is
+// read with v_readlane where it is used: no memory round trip.  History of these ~24 dwords: as ordinary kernel arguments they are loop-invariant, get
+// hoisted and take scalar registers the search loop has none to spare of (106 of 106: spills, or re-loads from the kernarg segment the compiler places
+// where it pleases: d_bloom, summ_iters and cap_iter were re-read on the chain of every iteration); read from the kernarg segment one by one where the
+// branches need them (round 5: KARG) the hand-over alone was five dependent scalar-cache round trips between "the parent is known" and "its row is
+// requested" (as one block: 1 250-query SIFT1B-shape shard 1.63 -> 1.53 ms, 10 K batch 8.32 -> 8.15).  The register passes through an empty asm in front
+// of each use site so that the reads stay THERE (a v_readlane of a loop-invariant register is loop-invariant too and would be hoisted back into scalar
+// registers).  Pointers rebuilt from these dwords are typed GAS (bang_device.h): generic, every access through them is a flat_ instruction.
+struct IterArgs {
+  const uint8_t* d_codes; uint32_t n_nodes, pad0;                                               // dwords 0-1, 2, 3
+  uint32_t* d_cand_ids; const uint8_t* d_graph; uint64_t entry_len;                             // 4-5, 6-7, 8-9
+  uint32_t vec_bytes, row_layout, n_rows_hbm, n_slices;                                         // 10, 11, 12, 13
+  const uint32_t* d_rows_hbm; const uint64_t* d_row_slices;                                     // 14-15, 16-17
+  uint32_t slice_rows, summ_iters;                                                              // 18, 19
+  uint32_t* d_bloom; uint32_t cap_iter, pad1;                                                   // 20-21, 22, 23
 };
+enum { IA_CODES = 0, IA_N_NODES = 2, IA_CAND_IDS = 4, IA_GRAPH = 6, IA_ENTRY_LEN = 8, IA_VEC_BYTES = 10, IA_ROW_LAYOUT = 11, IA_N_ROWS_HBM = 12,
+       IA_N_SLICES = 13, IA_ROWS_HBM = 14, IA_ROW_SLICES = 16, IA_SLICE_ROWS = 18, IA_SUMM_ITERS = 19, IA_BLOOM = 20, IA_CAP_ITER = 22, IA_DWORDS = 24 };
+static_assert(sizeof(IterArgs) == 4 * IA_DWORDS && offsetof(IterArgs, d_cand_ids) == 4 * IA_CAND_IDS && offsetof(IterArgs, vec_bytes) == 4 * IA_VEC_BYTES &&
+              offsetof(IterArgs, d_rows_hbm) == 4 * IA_ROWS_HBM && offsetof(IterArgs, slice_rows) == 4 * IA_SLICE_ROWS && offsetof(IterArgs, d_bloom) == 4 * IA_BLOOM && offsetof(IterArgs, cap_iter) == 4 * IA_CAP_ITER,
+              "IterArgs dword map");
 struct SearchArgs {
   bang_search_params p;
-  HotHand hand __attribute__((aligned(64)));
+  IterArgs iter __attribute__((aligned(16)));
   uint32_t lds_piv_floats;
   uint32_t wave_words;       // LDS words per wave: nctx worklists + 144 scratch (+ 32 parked context state when nctx == 2)
   uint32_t wl_words;         // LDS words of one worklist (2L + ceil(L/4), rounded to 4)
@@ -282,6 +293,7 @@ __device__ __forceinline__ void group_barrier(uint32_t* bar, uint32_t n, int lan
 #ifndef BANG_LONG_MAXT
 #define BANG_LONG_MAXT 768
 #endif
+
 __host__ __device__ constexpr int search_maxt(int ndw, bool host_paced) { return (search_coop(ndw, host_paced) && ndw >= 16) ? (host_paced ? 768 : BANG_LONG_MAXT) : 1024; }
 // 256 words where 12 waves share the LDS beside the pivot table; the 16-wave instances hand the pieces of the cooperative fetch over in rounds (144)
 __host__ __device__ constexpr uint32_t search_scratch_words(int ndw, bool host_paced) {
@@ -316,8 +328,18 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
   int lane = lane0;                                // (re-derived per phase inside the loop: LANE_FRESH)
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t nwaves = blockDim.x >> 6;
+  // the iteration's arguments, one dword per lane (IterArgs)
+  uint32_t iav;
+  {
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    iav = ((const uint32_t __attribute__((address_space(4)))*)(ka + offsetof(SearchArgs, iter)))[lane0 < IA_DWORDS ? lane0 : 0];
+  }
+#define IA_FRESH() asm volatile("" : "+v"(iav))
+#define IA32(k) ((uint32_t)__builtin_amdgcn_readlane((int)iav, (k)))
+#define IA64(k) (((uint64_t)IA32((k) + 1) << 32) | (uint64_t)IA32(k))
+#define IAPTR(type, k) ((type GAS*)IA64(k))        // (global address space: bang_device.h GAS)
   const uint32_t nctx = HOST ? a.nctx : 1u;
-  const uint32_t L = p.L, medoid = p.medoid, cap_iter = p.cap_iter;
+  const uint32_t L = p.L, medoid = p.medoid;
   const unsigned long long go_timeout = p.go_timeout_ticks ? p.go_timeout_ticks : BANG_KERNEL_GO_TIMEOUT_TICKS;   // 100 MHz ticks
   // a wave's LDS region: [worklist of context 0]([worklist of context 1])[scratch 144]([parked context state 2 x 16]: nctx == 2 only)
   uint32_t* wbase = (uint32_t*)(lds + a.lds_piv_floats) + (size_t)wave * a.wave_words;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       if (!((started >> c) & 1u)) q = c * total_waves + gw;
       else {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(KARG(d_next_query), 1u);
+        if (lane == 0) t = __hip_atomic_fetch_add(KARGP(uint32_t, d_next_query), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q = nctx * total_waves + uni(t);
       }
       started |= 1u << c;
@@ -485,21 +507,18 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         w_n = 0; cc = 1; mark = 0x01010101u;           // cudaMemset(d_mark, 1, ...) :446 ; candidate log = [MEDOID] :452-464
         evals = 0; fetched = 0; iter = 1;
         if (SUMM) { summ.clear(); probes_skipped = 0; }
-        if (lane == 0) KARG(d_cand_ids)[(size_t)q * cand_stride] = medoid;
+        if (lane == 0) KARGP(uint32_t, d_cand_ids)[(size_t)q * cand_stride] = medoid;
         load_qc(q);
         // the seed list [MEDOID, adj(MEDOID)...] (bang_init :467-489): {count, id x 65}
-        { const uint32_t* seed = KARG(d_seed); cnt_in = seed[0]; x0 = seed[1 + lane]; x1 = seed[65]; }
+        { const uint32_t GAS* seed = KARGP(const uint32_t, d_seed); cnt_in = seed[0]; x0 = seed[1 + lane]; x1 = seed[65]; }
         have_row = true;
         self_row = false;
       } else exhausted = true;
     }
     if (!HOST && !active) break;
-    uint32_t* bloom = p.d_bloom + (size_t)q * BANG_BF_WORDS;
 
     // results of the front half, consumed by the back half below
     uint32_t n = 0, sid0 = 0, sid1 = 0, parent = 0;
-    HotHand hand;                                     // the hand-over's arguments
-    __builtin_memset(&hand, 0, sizeof(hand));
     // self-paced form: the summary's transposition passes (set) run at the END of the iteration, while the wave would otherwise idle waiting
     // for the next adjacency row (nothing reads the summary in between)
     constexpr bool SET_LATE = !HOST;
@@ -520,10 +539,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
       // a row that names a node the index does not have (rows overwritten behind the engine's back: the self-paced form has no host
       // thread that could notice) is not followed: the batch ends with BANG_ERR_HIP instead of a wild read of the code table
-      const uint32_t n_nodes = HOST ? 0u : KARG(n_nodes);
+      IA_FRESH();
+      uint32_t GAS* bloom = IAPTR(uint32_t, IA_BLOOM) + (size_t)q * BANG_BF_WORDS;
+      const uint32_t n_nodes = HOST ? 0u : IA32(IA_N_NODES);
       if (!HOST && n_nodes != 0u) {
         if (__ballot((uint32_t)lane < ci && x0 >= n_nodes) != 0ull) {
-          if (lane == 0 && KARG(d_abort)) *KARG(d_abort) = 2u;
+          if (lane == 0 && KARG(d_abort)) *KARGP(uint32_t, d_abort) = 2u;
           ci = 0;
         }
       }
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // CANON: every id is tested against the filter state at entry (all loads before any store); both words in one round trip.
       // A word the summary knows to be untouched is zero: no request (FilterSummary).
       bool la = v0, lb = v0;                                 // load word a / b?
-      const bool summ_on = SUMM && (HOST || iter <= p.summ_iters);     // (uniform; one-way per query: once off, the registers go stale.  bang_k_search resolves 0 = auto)
+      const bool summ_on = SUMM && (HOST || iter <= IA32(IA_SUMM_ITERS));     // (uniform; one-way per query: once off, the registers go stale.  bang_k_search resolves 0 = auto)
       if (SUMM && summ_on) {
         la = summ.test(h0a >> 5) && v0;
         lb = summ.test(h0b >> 5) && v0;
@@ -549,11 +570,15 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
       PqRow<NDW, ALIGNED> row;
       CoopFetch<NDW, ALIGNED> cf;
-      const uint8_t* d_codes = KARG(d_codes);                 // (read here, once per iteration)
+      const uint8_t GAS* d_codes = IAPTR(const uint8_t, IA_CODES);
       // SPEC: the code rows of every id of the row, behind the probes just issued (older loads are waited for first: the probes' answers
       // are used while the rows still travel)
       if (SPEC && COOP) cf.issue(d_codes, code_stride, x0, ci < 64u ? ci : 64u, lane);
       else if (SPEC && v0) pq_row_load(row, d_codes, code_stride, x0);
+      // The row loads stay HERE, in front of the wait for the probes: left to itself the scheduler -- this instance sits at its VGPR limit -- may sink them
+      // behind that wait to shorten the 24 piece registers' lives, and the early request is gone without a trace but the time (one more live register
+      // was enough: 1 250-query shard 1.51 -> 1.63 ms, ISA checked).  A compiler-level memory barrier: loads do not move across it.
+      if (SPEC) asm volatile("" ::: "memory");
       const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
@@ -696,31 +721,32 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
         ++cc;                                                  // (the candidate-log store :1451-1458 is issued behind the row request: it is not on the chain)
       }
     }
+    IA_FRESH();                                                 // (the hand-over's arguments: IterArgs)
+    const uint32_t cap_iter = IA32(IA_CAP_ITER);
     const bool want_row = active && found && iter < cap_iter;
     PH(5);     // parent selection
 
     // ---------------- hand the parent over
-    if (active && found) hand = KARG_BLOCK(HotHand, hand);      // (the hand-over's arguments: one block of the kernarg segment, HotHand)
     if (!HOST) {
       // graph resident in HBM: the next adjacency row is requested NOW, straight into the registers the next iteration reads (no copy at the
       // loop's end that would wait for it); it travels while the survivors are merged
       if (want_row) {
-        const uint8_t* gbase = hand.d_graph;
-        if (hand.row_layout) {                                // adjacency rows (pinned host memory, pull mode): 64 ids, padded
+        const uint8_t GAS* gbase = IAPTR(const uint8_t, IA_GRAPH);
+        if (IA32(IA_ROW_LAYOUT)) {                                // adjacency rows (pinned host memory, pull mode): 64 ids, padded
           // the rows of the first n_rows_hbm nodes also sit in HBM (whatever HBM the index left over): no PCIe read for those.  Peer rows
           // (n_slices > 1): slice parent / slice_rows of the node's HBM-resident rows -- this GPU's HBM or a peer's over xGMI; the table
           // holds biased base addresses (0: that slice is not there), read through the scalar cache
-          const uint32_t* hb = nullptr;
-          const uint32_t nsl = hand.n_slices;
+          const uint32_t GAS* hb = nullptr;
+          const uint32_t nsl = IA32(IA_N_SLICES);
           if (nsl > 1u) {
-            const uint32_t sl = parent / hand.slice_rows;                      // (uniform: scalar)
-            if (sl < nsl) hb = (const uint32_t*)(uintptr_t)((const uint64_t __attribute__((address_space(4)))*)hand.d_row_slices)[sl];     // (s_load: a vector load here is waited for with vmcnt(0) -- behind every filter store in flight)
-          } else if (parent < hand.n_rows_hbm) hb = hand.d_rows_hbm;
-          if (hb) x0 = hb[(uint64_t)parent * 64u + lane];
-          else x0 = __builtin_nontemporal_load((const uint32_t*)gbase + (uint64_t)parent * 64u + lane);
+            const uint32_t sl = parent / IA32(IA_SLICE_ROWS);                      // (uniform: scalar)
+            if (sl < nsl) hb = (const uint32_t GAS*)scalar_load_u64(IA64(IA_ROW_SLICES), sl);
+          } else if (parent < IA32(IA_N_ROWS_HBM)) hb = IAPTR(const uint32_t, IA_ROWS_HBM);
+          if (hb) x0 = hb[(uint64_t)parent * 64u + lane];        // (plain: with the non-temporal hint on the rows read from HBM the 10 K batch took 8.22 instead of 7.96 ms)
+          else x0 = __builtin_nontemporal_load((const uint32_t GAS*)gbase + (uint64_t)parent * 64u + lane);
           cnt_in = 64u;                                      // counted when the row is consumed
         } else {
-          const uint32_t* nrow = (const uint32_t*)(gbase + (uint64_t)parent * hand.entry_len + hand.vec_bytes);
+          const uint32_t GAS* nrow = (const uint32_t GAS*)(gbase + (uint64_t)parent * IA64(IA_ENTRY_LEN) + IA32(IA_VEC_BYTES));
           cnt_in = nrow[0];
           x0 = nrow[1 + lane];                               // in bounds: an entry holds R = 64 id slots (+ slack behind the graph)
         }
@@ -731,7 +757,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // asks for the row now -- it travels during the sort/merge, as in the self-paced form -- and publishes "nothing to fetch"
       self_row = false;
       if (nctx == 1u && want_row && !p.ship_vectors) {
-        if (parent < hand.n_rows_hbm) { self_row = true; x0 = hand.d_rows_hbm[(uint64_t)parent * 64u + lane]; cnt_in = 64u; }
+        if (parent < IA32(IA_N_ROWS_HBM)) { self_row = true; x0 = (IAPTR(const uint32_t, IA_ROWS_HBM))[(uint64_t)parent * 64u + lane]; cnt_in = 64u; }
       }
       if (lane == 0) {
         // parents travel to the host in one coalesced store per workgroup.  A parent whose vector the walker must ship (vectors
@@ -772,7 +798,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     }
 
     PH(8);     // hand-over: the next row is requested
-    if (active && found && lane == 0) hand.d_cand_ids[(size_t)q * cand_stride + cc - 1u] = parent;      // :1451-1458 (cc counts it already)
+    if (active && found && lane == 0) IAPTR(uint32_t, IA_CAND_IDS)[(size_t)q * cand_stride + cc - 1u] = parent;      // :1451-1458 (cc counts it already)
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
       LANE_FRESH();
@@ -789,21 +815,21 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       if ((!found && n == 0) || iter == cap_iter) {
         if (lane == 0) {
           // (the once-per-query arguments are read where they are used: KARG)
-          KARG(d_cand_cnt)[q] = cc;
-          uint32_t* qstats = KARG(d_qstats);
-          uint32_t* qiters = KARG(d_qiters);
-          uint32_t* qskip = KARG(d_qskip);
-          if (qstats) *(uint2*)(qstats + (size_t)q * 2) = make_uint2(evals, fetched);
+          KARGP(uint32_t, d_cand_cnt)[q] = cc;
+          uint32_t GAS* qstats = KARGP(uint32_t, d_qstats);
+          uint32_t GAS* qiters = KARGP(uint32_t, d_qiters);
+          uint32_t GAS* qskip = KARGP(uint32_t, d_qskip);
+          if (qstats) { qstats[(size_t)q * 2] = evals; qstats[(size_t)q * 2 + 1] = fetched; }
           if (qiters) qiters[q] = iter;
           if (qskip) qskip[q] = probes_skipped;
         }
         if (!HOST) {
           RerankArgs8 rr;                                                      // (read here, once per query: KARG)
-          rr.queries = KARG(rr_queries);
+          rr.queries = (const uint8_t GAS*)KARG(rr_queries);
           if (rr.queries) {                                                    // K6 + K7 on the spot (uniform)
-            rr.vec_base = KARG(rr_vec_base); rr.vec_stride = KARG(rr_vec_stride); rr.ids_out = KARG(rr_ids_out); rr.dists_out = KARG(rr_dists_out);
+            rr.vec_base = (const uint8_t GAS*)KARG(rr_vec_base); rr.vec_stride = KARG(rr_vec_stride); rr.ids_out = (uint64_t GAS*)KARG(rr_ids_out); rr.dists_out = (float GAS*)KARG(rr_dists_out);
             rr.D = KARG(rr_D); rr.k = KARG(rr_k); rr.q0 = KARG(rr_q0); rr.Q_total = KARG(rr_Q_total);
-            rr.cand = KARG(d_cand_ids) + (size_t)q * cand_stride;
+            rr.cand = KARGP(const uint32_t, d_cand_ids) + (size_t)q * cand_stride;
             const uint32_t nc = cc < cand_stride ? cc : cand_stride;
             const uint32_t rdt = KARG(rr_dtype);
             if (rdt == BANG_F32) wave_rerank_f32<4>(rr, q, nc, wbase, lane);
@@ -978,10 +1004,11 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   SearchArgs a;
   a.p = *p;
   a.lds_piv_floats = pivot_table_floats(p->psz, p->mp, p->pq_nhi);
-  __builtin_memset(&a.hand, 0, sizeof(a.hand));
-  a.hand.d_cand_ids = p->d_cand_ids; a.hand.d_graph = p->d_graph; a.hand.entry_len = p->entry_len; a.hand.vec_bytes = p->vec_bytes;
-  a.hand.row_layout = p->row_layout; a.hand.n_rows_hbm = p->n_rows_hbm; a.hand.n_slices = p->n_slices; a.hand.d_rows_hbm = p->d_rows_hbm;
-  a.hand.d_row_slices = p->d_row_slices; a.hand.slice_rows = p->slice_rows;
+  __builtin_memset(&a.iter, 0, sizeof(a.iter));
+  a.iter.d_codes = p->d_codes; a.iter.n_nodes = p->n_nodes; a.iter.d_cand_ids = p->d_cand_ids; a.iter.d_graph = p->d_graph; a.iter.entry_len = p->entry_len;
+  a.iter.vec_bytes = p->vec_bytes; a.iter.row_layout = p->row_layout; a.iter.n_rows_hbm = p->n_rows_hbm; a.iter.n_slices = p->n_slices;
+  a.iter.d_rows_hbm = p->d_rows_hbm; a.iter.d_row_slices = p->d_row_slices; a.iter.slice_rows = p->slice_rows;
+  a.iter.d_bloom = p->d_bloom; a.iter.cap_iter = p->cap_iter;      // (summ_iters: below, once the policy is resolved)
   uint32_t grid_n = 0, waves = 0, nctx = p->nctx, gs = p->group_waves;
   const int rc = bang_search_geometry(p->psz, p->mp, p->pq_nhi, p->L, p->Q, p->max_wgs, p->max_waves, p->d_graph ? 0 : 1, &grid_n, &waves, &nctx, &gs);
   if (rc != BANG_OK) return rc;
@@ -994,6 +1021,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // (with spec_rows on, re-measured: 1 250 queries 1.69 with / 1.63 without, 1 400: 1.73 / 1.72, 1 536 = 6 per CU: 1.74-1.78 / 1.73-1.74, 1 900: 1.94 / 1.99)
   const bool light = (p->Q + grid_n - 1) / grid_n <= 6u;
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
+  a.iter.summ_iters = a.p.summ_iters;
   // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,
   // ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9 random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
   // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.

@@ -73,6 +73,18 @@ def k2_alone(D, m, dtype, ctx, table_bytes=4 << 30, rows_per_launch=40_000_000, 
            "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "achieved": round(ach, 1), "unit": "GB/s",
            "peak": HBM_PEAK_GBPS, "frac": round(ach / HBM_PEAK_GBPS, 4), "rows_per_s": round(evals / (avg * 1e-6) / 1e9, 2),
            "timer": "HIP events on the launch stream"}
+    # the same launch under rocprofv3 --kernel-trace, from the committed record of tools/profile_k2.sh (the stage BASELINE.json quotes an HBM figure for)
+    try:
+        import json
+        import os
+        from .common import ROOT
+        tr = json.load(open(os.path.join(ROOT, "profiles", "k2_alone_trace.json")))
+        lay = tr["layouts"].get(f"m{m}_stride128" if rb == 128 and m != 128 else f"m{m}_packed")
+        if lay:
+            out["rocprof_kernel_trace_avg_us"] = lay["avg_us"]
+            out["rocprof_record"] = "profiles/r06_k2_alone.md"
+    except Exception:
+        pass
     del codes, nbrs, dist_o, cnt, qc, packed
     torch.cuda.empty_cache()
     return out

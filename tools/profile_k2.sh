@@ -38,13 +38,18 @@ if f:
     print("## rocprofv3 --kernel-trace: launches of pqdist_stream_kernel, in order (16 per layout: m = 32, 70, 70 at stride 128, 74, 74 at stride 128)\n")
     print("| layout | launches | avg us (last 10) | min us | max us | kernel |")
     print("|---|---|---|---|---|---|")
+    trace = {}
     for i, m in enumerate(LAYOUTS):
         grp = rows[i * NL:(i + 1) * NL][WARM:]
         if not grp:
             continue
         du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp]
         print(f"| m = {m} | {len(grp)} | {sum(du)/len(du):.1f} | {min(du):.1f} | {max(du):.1f} | {grp[0]['Kernel_Name'].split('(')[0][:60]} |")
+        key = ("m%s_stride128" % m.split()[0]) if "128" in m else ("m%s_packed" % m)
+        trace[key] = {"avg_us": round(sum(du) / len(du), 1), "min_us": round(min(du), 1), "launches": len(grp)}
     print()
+    # (what bench.py quotes beside its HIP-event time: copy to profiles/k2_alone_trace.json)
+    json.dump({"source": "rocprofv3 --kernel-trace of tools/k2_alone.py --big (tools/profile_k2.sh)", "layouts": trace}, open(os.path.join(os.path.dirname(out), "profiles_out", "k2_alone_trace.json"), "w"))
 for name, label in (("pmc_fetch", "FETCH_SIZE (KB; tallies every read request at 64 bytes although each is a 128-byte line: HBM bytes = 2 x FETCH_SIZE = TCC_EA0_RDREQ x 128, profiles/r04_traffic_calibration.md)"),
                     ("pmc_l2", "L2 / fabric counters"),
                     ("pmc_sq1", "where the wave cycles go (SQ, quad-cycles summed over waves)"),
