@@ -214,16 +214,16 @@ def main():
                "workload": prim["wl"]["name"], "L": L, "k": k, "recall_at_10": (round(recall, 3) if recall == recall else None),
                "graph": graph,
                "parity_vs_oracle_first_64" if prim["structured"] else "result_properties_ok": prim["ok"],
-               "reduced_n_hip_ids_equal_oracle": None, "k2_alone_frac": None, "k2_alone_GBps": None,
-               "requests_G_per_s": None, "request_ceiling_G_per_s": None, "request_frac": None,
+               "reduced_n_hip_ids_equal_oracle": None, "k2_alone_frac": None,
+               "request_frac": None, "requests_G_per_s": None,
                "traffic_over_algorithmic": (res["roofline"] or {}).get("traffic_over_algorithmic"),
                "qps_incl_init": res["qps_incl_init"], "rerank_fused": int(agg.get("rerank_fused", 0)),
                "shard_ms_5000": None, "shard_ms_2500": None, "shard_ms_1250": None, "gather_ms_world1": None,
                "projected_speedup_2": None, "projected_speedup_4": None, "projected_speedup_8": None,
-               "walker_qps": None, "walker_N": None, "rccl_world_seen": None,
-               "sift300m_qps": None, "sift300m_recall": None, "sift300m_L": None, "sift300m_parity_ok": None,
-               "sift300m_hops_p50": None, "sift1m_qps": None, "sift1m_recall": None, "sift1m_parity_ok": None,
-               "deep100m_shape_qps": None, "deep100m_shape_frac": None,
+               "walker_qps": None, "sift1m_qps": None, "deep100m_shape_qps": None, "deep100m_shape_frac": None, "rccl_world_seen": None,
+               "sift300m_qps": None, "sift1m_recall": None, "request_ceiling_G_per_s": None, "k2_alone_GBps": None, "walker_N": None,
+               "sift300m_recall": None, "sift300m_L": None, "sift300m_parity_ok": None,
+               "sift300m_hops_p50": None, "sift1m_parity_ok": None,
                "adjacency_rows_also_in_hbm": agg["rows_in_hbm"], "legs_skipped": None,
                "peer_rows": getattr(ctx, "peer_rows", None),
                "rows_from_peer_hbm_per_step": int(agg["rows_from_peer"] // args.steps), "rows_from_own_hbm_per_step": int(agg["rows_from_own_hbm"] // args.steps),
