@@ -897,13 +897,34 @@ static int launch_inst(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, h
   return BANG_OK;
 }
 
+// The instances live in TWO translation units of this one file (Makefile): part 0 (BANG_SEARCH_PART = 0: bang_search.o, built with
+// -mllvm -amdgpu-sched-strategy=iterative-ilp -- round 6: every BASELINE layout 1-5 % faster under it, a 1 250-query SIFT1B-shape shard 1.52 -> 1.45 ms) and part 1
+// (bang_search_b.o, the default scheduler): the instances the ILP strategy costs scratch -- rows of 96+ chunks, 74-chunk rows that are not dword-aligned
+// (0 -> 72-116 B per lane), and the host-paced instances of the long-row layouts (20-68 -> 116-168 B).  Both units compile the same dispatch; each instantiates only its own instances.
+#ifndef BANG_SEARCH_PART
+#define BANG_SEARCH_PART 0
+#endif
+constexpr bool search_in_part1(int ndw, bool aligned, bool host_paced) { return ndw >= 24 || (ndw == 19 && !aligned) || (host_paced && ndw >= 16); }
+extern "C" int bang_search_launch_part1(const SearchArgs* a, uint32_t grid, uint32_t block, size_t lds, void* stream);
+
+template <int PSZ, int NDW, bool ALIGNED, int NHI, bool HOST, bool SPEC>
+static int launch_part(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  if constexpr (search_in_part1(NDW, ALIGNED, HOST) == (BANG_SEARCH_PART == 1)) return launch_inst<PSZ, NDW, ALIGNED, NHI, HOST, SPEC>(a, grid, block, lds, st);
+#if BANG_SEARCH_PART == 0
+  return bang_search_launch_part1(&a, grid.x, block.x, lds, (void*)st);
+#else
+  bang_set_error("search-kernel instance psz=%u mp=%u is not part of this translation unit", a.p.psz, a.p.mp);
+  return BANG_ERR_UNSUPPORTED;
+#endif
+}
+
 template <int PSZ, int NDW, bool ALIGNED, int NHI>
 static int launch_hd(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   if constexpr (search_has_spec(NDW)) {
-    if (a.p.d_graph && a.p.spec_rows == 1u) return launch_inst<PSZ, NDW, ALIGNED, NHI, false, true>(a, grid, block, lds, st);
+    if (a.p.d_graph && a.p.spec_rows == 1u) return launch_part<PSZ, NDW, ALIGNED, NHI, false, true>(a, grid, block, lds, st);
   }
-  return a.p.d_graph ? launch_inst<PSZ, NDW, ALIGNED, NHI, false, false>(a, grid, block, lds, st)
-                     : launch_inst<PSZ, NDW, ALIGNED, NHI, true, false>(a, grid, block, lds, st);
+  return a.p.d_graph ? launch_part<PSZ, NDW, ALIGNED, NHI, false, false>(a, grid, block, lds, st)
+                     : launch_part<PSZ, NDW, ALIGNED, NHI, true, false>(a, grid, block, lds, st);
 }
 
 template <int PSZ, int NDW>
@@ -921,6 +942,36 @@ static int launch_al(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hip
   }
   return al ? launch_hd<PSZ, NDW, true, 0>(a, grid, block, lds, st) : launch_hd<PSZ, NDW, false, 0>(a, grid, block, lds, st);
 }
+
+static int search_dispatch(const SearchArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  const bang_search_params* p = &a.p;
+  const uint32_t key = p->psz * 100u + p->mp / 4u;
+  switch (key) {
+#ifndef BANG_DEV_ONLY_218          // development builds (ISA dumps, quick A/B libraries): the SIFT1B layout only
+    case 108: return launch_al<1, 8>(a, grid, block, lds, st);
+    case 116: return launch_al<1, 16>(a, grid, block, lds, st);
+    case 124: return launch_al<1, 24>(a, grid, block, lds, st);
+    case 132: return launch_al<1, 32>(a, grid, block, lds, st);
+    case 208: return launch_al<2, 8>(a, grid, block, lds, st);
+    case 216: return launch_al<2, 16>(a, grid, block, lds, st);
+    case 219: return launch_al<2, 19>(a, grid, block, lds, st);
+#endif
+    case 218: return launch_al<2, 18>(a, grid, block, lds, st);
+#ifndef BANG_DEV_ONLY_218
+    case 404: return launch_al<4, 4>(a, grid, block, lds, st);
+    case 408: return launch_al<4, 8>(a, grid, block, lds, st);
+    case 802: return launch_al<8, 2>(a, grid, block, lds, st);
+    case 804: return launch_al<8, 4>(a, grid, block, lds, st);
+#endif
+    default: bang_set_error("no search-kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
+  }
+}
+
+#if BANG_SEARCH_PART == 1
+extern "C" int bang_search_launch_part1(const SearchArgs* a, uint32_t grid, uint32_t block, size_t lds, void* stream) {
+  return search_dispatch(*a, dim3(grid), dim3(block), lds, (hipStream_t)stream);
+}
+#else
 
 #define SRCH_WG_SHARED_BYTES 2048u     // group-shared LDS behind the waves' regions (host-paced form): 128 words per pacing group, up to 4 groups
 #define SRCH_DEFAULT_GROUP_WAVES 8u
@@ -1033,24 +1084,6 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   const size_t lds = (size_t)a.lds_piv_floats * 4 + (size_t)waves * a.wave_words * 4 + (p->d_graph ? 0u : SRCH_WG_SHARED_BYTES);
   const dim3 grid(grid_n), block(waves * WAVE);
   hipStream_t st = (hipStream_t)stream;
-  const uint32_t key = p->psz * 100u + p->mp / 4u;
-  switch (key) {
-#ifndef BANG_DEV_ONLY_218          // development builds (ISA dumps, quick A/B libraries): the SIFT1B layout only
-    case 108: return launch_al<1, 8>(a, grid, block, lds, st);
-    case 116: return launch_al<1, 16>(a, grid, block, lds, st);
-    case 124: return launch_al<1, 24>(a, grid, block, lds, st);
-    case 132: return launch_al<1, 32>(a, grid, block, lds, st);
-    case 208: return launch_al<2, 8>(a, grid, block, lds, st);
-    case 216: return launch_al<2, 16>(a, grid, block, lds, st);
-    case 219: return launch_al<2, 19>(a, grid, block, lds, st);
-#endif
-    case 218: return launch_al<2, 18>(a, grid, block, lds, st);
-#ifndef BANG_DEV_ONLY_218
-    case 404: return launch_al<4, 4>(a, grid, block, lds, st);
-    case 408: return launch_al<4, 8>(a, grid, block, lds, st);
-    case 802: return launch_al<8, 2>(a, grid, block, lds, st);
-    case 804: return launch_al<8, 4>(a, grid, block, lds, st);
-#endif
-    default: bang_set_error("no search-kernel instance for psz=%u mp=%u", p->psz, p->mp); return BANG_ERR_UNSUPPORTED;
-  }
+  return search_dispatch(a, grid, block, lds, st);
 }
+#endif   // BANG_SEARCH_PART == 0

@@ -50,7 +50,12 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--md", default=None, help="also write a markdown table here")
     a, extra = ap.parse_known_args()
-    rs = rows(usage_of(a.file, extra), a.filter)
+    if os.path.basename(a.file) == "bang_search.hip" and not any(x.startswith("-DBANG_SEARCH_PART") for x in extra):
+        # the search kernel's instances live in two translation units of the one file (Makefile: part 0 under the ILP scheduling strategy, part 1 under the default)
+        sched = [] if any("sched-strategy" in x for x in extra) or os.environ.get("BANG_USAGE_NO_SCHED") else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+        rs = rows(usage_of(a.file, extra + sched), a.filter) + rows(usage_of(a.file, extra + ["-DBANG_SEARCH_PART=1"]), a.filter)
+    else:
+        rs = rows(usage_of(a.file, extra), a.filter)
     for r in rs:
         print(f"{r['kernel'][:70]:70s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} sgpr {r['sgpr']:3d} scratch {r['scratch']:4d} occ {r['occ']}")
     if a.md:
@@ -59,7 +64,8 @@ def main():
             f.write("`python tools/dev/kernel_usage.py --md <this file>` (hipcc `-Rpass-analysis=kernel-resource-usage`, gfx950).  Template arguments of "
                     "`search_kernel`: `<PSZ, NDW, ALIGNED, NHI, HOST, SPEC>` -- `<2, 18, true, 58, false, *>` is the SIFT1B layout (m = 70, rows 128 B apart), self-paced "
                     "(SPEC = code rows requested with the filter probes); `<2, 19, *, 22, false, *>` DEEP100M (m = 74); `<4, 8, true, 0, false, false>` SIFT1M (m = 32).  Budget: 168 VGPRs for the 12-wave (768-thread) "
-                    "instances, 128 for the 16-wave ones; 106 SGPRs (the compiler always reports the cap).  Dynamic LDS is sized at launch.\n\n")
+                    "instances, 128 for the 16-wave ones; 106 SGPRs (the compiler always reports the cap).  Dynamic LDS is sized at launch.  The instances are compiled in two translation units "
+                    "(Makefile: `bang_search.o` under `-amdgpu-sched-strategy=iterative-ilp`, `bang_search_b.o` -- 96+ chunks, unaligned 74-chunk rows -- under the default scheduler).\n\n")
             f.write("| kernel instance | VGPRs | AGPRs | SGPRs | scratch B/lane | waves/SIMD |\n|---|---|---|---|---|---|\n")
             for r in rs:
                 f.write(f"| `{r['kernel']}` | {r['vgpr']} | {r['agpr']} | {r['sgpr']} | {r['scratch']} | {r['occ']} |\n")
