@@ -56,20 +56,28 @@ def test_baseline_search_instances_run_without_scratch(libbang, tmp_path):
     scratch traffic inside the row reduce.  Read from the code object that was just built (kernel descriptors in the ELF notes)."""
     llvm = "/opt/rocm/lib/llvm/bin"
     tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
-    obj = os.path.join(ROOT, "bang-billion-scale-ann_amd", "lib", "bang_search.o")
-    if not all(os.path.exists(t) for t in tools) or not os.path.exists(obj):
-        pytest.skip("llvm binutils / the kernel object are not here")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
-    subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", obj, str(tmp_path / "unused.o")], check=True)
-    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
-    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
-    usage = {}
-    for blk in notes.split(".name:")[1:]:
-        name = blk.split()[0]
-        m = re.match(r"_Z13search_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])EEv10SearchArgs$", name)
-        if m:
-            key = tuple(int(x) for x in m.groups())                      # (PSZ, NDW, ALIGNED, NHI, HOST, SPEC)
-            usage[key] = (int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1)), int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)))
+    objs = [os.path.join(ROOT, "bang-billion-scale-ann_amd", "lib", n) for n in ("bang_search.o", "bang_search_b.o")]
+    if not all(os.path.exists(t) for t in tools) or not all(os.path.exists(o) for o in objs):
+        pytest.skip("llvm binutils / the kernel objects are not here")
+
+    def usage_of(obj, tag):
+        fat, co = str(tmp_path / f"fat{tag}.bin"), str(tmp_path / f"dev{tag}.co")
+        subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", obj, str(tmp_path / "unused.o")], check=True)
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+        out = {}
+        for blk in notes.split(".name:")[1:]:
+            name = blk.split()[0]
+            m = re.match(r"_Z13search_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])EEv10SearchArgs$", name)
+            if m:
+                key = tuple(int(x) for x in m.groups())                      # (PSZ, NDW, ALIGNED, NHI, HOST, SPEC)
+                out[key] = (int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1)), int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)))
+        return out
+    # the instances live in two translation units of the one source file (Makefile: part 0 under the ILP scheduling strategy -- the BASELINE
+    # layouts --, part 1 under the default scheduler): every instance exactly once, the BASELINE self-paced ones in part 0
+    usage, part1 = usage_of(objs[0], 0), usage_of(objs[1], 1)
+    assert not (set(usage) & set(part1)) and len(usage) + len(part1) == 64, (len(usage), len(part1))
+    assert all(k[1] >= 24 or (k[1] == 19 and not k[2]) or (k[4] and k[1] >= 16) for k in part1), sorted(part1)
     want = [(2, 18, 1, 58, 0, 0), (2, 18, 1, 58, 0, 1), (2, 19, 1, 22, 0, 0), (2, 19, 1, 22, 0, 1), (4, 8, 1, 0, 0, 0)]
     for key in want:
         assert key in usage, (key, sorted(usage)[:4])
