@@ -24,7 +24,7 @@
 //    sort/merge.  In host-graph mode the parents of a workgroup's waves go to the host walker in one coalesced store per round,
 //    and the sort/merge overlaps the walker's round trip.
 //
-//  * A launch of at most 6 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of every iteration and
+//  * A launch of at most 5 queries per CU leaves the FilterSummary off (its LDS-crossbar work sits on the chain of every iteration and
 //    a lightly loaded chip is not short of requests); an adjacency id >= N is never followed (n_nodes: the batch ends with an error
 //    instead of a wild read).  Experiments that measured no faster live in git history and docs/HISTORY.md, not here.
 //  * Round 5: K6 + K7 by the wave that finishes a query (wave_rerank8, bang_device.h: 8-bit vectors); the query replicated per 16-lane row
@@ -1068,9 +1068,10 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // The filter summary trades LDS-crossbar work on the chain of every iteration (12 ds_bpermute + two transposition passes) for
   // memory requests.  A full chip is short of requests-in-flight: with it the 10 K SIFT1B-shape batch takes 8.36 instead of 9.09 ms, 5 000 /
   // 2 500 queries 4.68 / 2.37 instead of 4.99 / 2.71.  A lightly loaded one is short of nothing but the chain: 1 250 queries (5 waves per CU)
-  // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto: off up to 6 queries per CU.
+  // 1.70 ms without it against 1.77, 625 queries 1.43 against 1.53 (profiles/r04_summary_cutoff.md).  auto then: off up to 6 queries per CU.
   // (with spec_rows on, re-measured: 1 250 queries 1.69 with / 1.63 without, 1 400: 1.73 / 1.72, 1 536 = 6 per CU: 1.74-1.78 / 1.73-1.74, 1 900: 1.94 / 1.99)
-  const bool light = (p->Q + grid_n - 1) / grid_n <= 6u;
+  // (round 6, final kernel: 1 536 queries = 6 per CU 1.555 with / 1.585 without, 1 250 = 5 per CU 1.493 / 1.453: the cut-off is 5)
+  const bool light = (p->Q + grid_n - 1) / grid_n <= 5u;
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
   a.iter.summ_iters = a.p.summ_iters;
   // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,

@@ -388,7 +388,7 @@ typedef struct {
   uint32_t n_nodes;                    /* nodes of the index, or 0: an adjacency id >= n_nodes (and not the pad value) is never expanded nor evaluated -- the row
                                           counts as empty and *d_abort is set to 2 (a corrupt row must not become a wild read of the code table) */
   uint32_t summ_iters;                 /* self-paced form: the on-chip filter summary is consulted and maintained for a query's first summ_iters iterations only
-                                          (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 6 queries per CU, where its
+                                          (0xFFFFFFFF = always; 0 = auto: always, except 1 -- i.e. off -- for launches of at most 5 queries per CU, where its
                                           LDS-crossbar work on the chain of every iteration costs more than the requests it saves) */
   uint32_t spec_rows;                  /* self-paced form, 70- and 74-chunk layouts (the other instances ignore it): the PQ code rows of ALL ids of an adjacency row are
                                           requested together with their filter probes (1) -- one memory latency less per iteration, the rows of the ids the
