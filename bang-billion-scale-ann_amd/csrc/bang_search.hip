@@ -30,6 +30,10 @@
 //  * Round 5: K6 + K7 by the wave that finishes a query (wave_rerank8, bang_device.h: 8-bit vectors); the query replicated per 16-lane row
 //    for the BASELINE long-row layouts (QcRow16: "pivot - query" is one DPP instruction); peer rows (a table of HBM slices of the adjacency
 //    rows, this GPU's or a peer's over xGMI); arguments a query needs once read from the kernarg segment where they are used (KARG).
+//  * Round 6: what an iteration needs of the arguments travels in the lanes of one vector register (IterArgs) instead of being re-read from the kernarg
+//    segment on the chain; every pointer the kernel rebuilds is typed global (GAS: no flat_ instruction is left -- a flat_ load counts in lgkmcnt and
+//    makes every LDS wait a wait for the loads in flight); code rows with the non-temporal hint; K6 + K7 for float vectors too (wave_rerank_f32);
+//    the instances compiled in two translation units (BANG_SEARCH_PART: the BASELINE layouts under LLVM's iterative-ILP scheduling strategy).
 //
 // Results are bit-identical to the per-iteration kernels and to the oracle: the per-query algorithm (Appendix B of SURVEY.md,
 // canonical semantics of DESIGN.md section 2) is unchanged, only where its state lives and who schedules it.
