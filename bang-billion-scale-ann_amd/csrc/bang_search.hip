@@ -87,14 +87,14 @@ __device__ __forceinline__ uint64_t scalar_load_u64(uint64_t tab, uint32_t idx) 
 // of each use site so that the reads stay THERE (a v_readlane of a loop-invariant register is loop-invariant too and would be hoisted back into scalar
 // registers).  Pointers rebuilt from these dwords are typed GAS (bang_device.h): generic, every access through them is a flat_ instruction.
 struct IterArgs {
-  const uint8_t* d_codes; uint32_t n_nodes, pad0;                                               // dwords 0-1, 2, 3
+  const uint8_t* d_codes; uint32_t n_nodes, prio;                                               // dwords 0-1, 2, 3
   uint32_t* d_cand_ids; const uint8_t* d_graph; uint64_t entry_len;                             // 4-5, 6-7, 8-9
   uint32_t vec_bytes, row_layout, n_rows_hbm, n_slices;                                         // 10, 11, 12, 13
   const uint32_t* d_rows_hbm; const uint64_t* d_row_slices;                                     // 14-15, 16-17
   uint32_t slice_rows, summ_iters;                                                              // 18, 19
   uint32_t* d_bloom; uint32_t cap_iter, pad1;                                                   // 20-21, 22, 23
 };
-enum { IA_CODES = 0, IA_N_NODES = 2, IA_CAND_IDS = 4, IA_GRAPH = 6, IA_ENTRY_LEN = 8, IA_VEC_BYTES = 10, IA_ROW_LAYOUT = 11, IA_N_ROWS_HBM = 12,
+enum { IA_CODES = 0, IA_N_NODES = 2, IA_PRIO = 3, IA_CAND_IDS = 4, IA_GRAPH = 6, IA_ENTRY_LEN = 8, IA_VEC_BYTES = 10, IA_ROW_LAYOUT = 11, IA_N_ROWS_HBM = 12,
        IA_N_SLICES = 13, IA_ROWS_HBM = 14, IA_ROW_SLICES = 16, IA_SLICE_ROWS = 18, IA_SUMM_ITERS = 19, IA_BLOOM = 20, IA_CAP_ITER = 22, IA_DWORDS = 24 };
 static_assert(sizeof(IterArgs) == 4 * IA_DWORDS && offsetof(IterArgs, d_cand_ids) == 4 * IA_CAND_IDS && offsetof(IterArgs, vec_bytes) == 4 * IA_VEC_BYTES &&
               offsetof(IterArgs, d_rows_hbm) == 4 * IA_ROWS_HBM && offsetof(IterArgs, slice_rows) == 4 * IA_SLICE_ROWS && offsetof(IterArgs, d_bloom) == 4 * IA_BLOOM && offsetof(IterArgs, cap_iter) == 4 * IA_CAP_ITER,
@@ -544,6 +544,12 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // a row that names a node the index does not have (rows overwritten behind the engine's back: the self-paced form has no host
       // thread that could notice) is not followed: the batch ends with BANG_ERR_HIP instead of a wild read of the code table
       IA_FRESH();
+      // Wave priority (launch policy `prio`, bang_k_search): the two stretches of an iteration that END in memory requests -- hashes -> probes -> code-row
+      // requests here, parent selection -> row request below -- run at raised priority, the reduce and the merge at the default: a wave that is about to
+      // put requests in flight is not held up by its neighbours' arithmetic.  Pays where wave slots are free (2 500-query shard 2.24 -> 2.20 ms, 1 250:
+      // 1.46 -> 1.44), costs a full chip 2 % (10 K batch 7.92 -> 8.12): on for launches of at most 10 queries per CU.
+      const bool prio = !HOST && IA32(IA_PRIO) != 0u;
+      if (prio) __builtin_amdgcn_s_setprio(3);
       uint32_t GAS* bloom = IAPTR(uint32_t, IA_BLOOM) + (size_t)q * BANG_BF_WORDS;
       const uint32_t n_nodes = HOST ? 0u : IA32(IA_N_NODES);
       if (!HOST && n_nodes != 0u) {
@@ -583,6 +589,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // behind that wait to shorten the 24 piece registers' lives, and the early request is gone without a trace but the time (one more live register
       // was enough: 1 250-query shard 1.51 -> 1.63 ms, ISA checked).  A compiler-level memory barrier: loads do not move across it.
       if (SPEC) asm volatile("" ::: "memory");
+      if (prio) __builtin_amdgcn_s_setprio(0);
       const bool pass0 = v0 && !(((w0a >> (h0a & 31)) & 1u) && ((w0b >> (h0b & 31)) & 1u));
       const bool pass1 = v1 && (lane == 0) && !(((w1a >> (h1a & 31)) & 1u) && ((w1b >> (h1b & 31)) & 1u));
       const uint64_t m0 = __ballot(pass0);
@@ -689,6 +696,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
 
       // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ----------------
+      if (prio) __builtin_amdgcn_s_setprio(3);                // parent selection -> row request
       LANE_FRESH();
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
       const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
@@ -802,6 +810,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     }
 
     PH(8);     // hand-over: the next row is requested
+    if (!HOST && IA32(IA_PRIO) != 0u) __builtin_amdgcn_s_setprio(0);
     if (active && found && lane == 0) IAPTR(uint32_t, IA_CAND_IDS)[(size_t)q * cand_stride + cc - 1u] = parent;      // :1451-1458 (cc counts it already)
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
@@ -1078,6 +1087,8 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   const bool light = (p->Q + grid_n - 1) / grid_n <= 5u;
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
   a.iter.summ_iters = a.p.summ_iters;
+  // wave priority around the request-issuing stretches of an iteration: on where wave slots are free (<= 10 queries per CU); BANG_SEARCH_PRIO = 0 / 1 forces it
+  { const char* e = getenv("BANG_SEARCH_PRIO"); a.iter.prio = (e && (e[0] == '0' || e[0] == '1')) ? (uint32_t)(e[0] - '0') : (((p->Q + grid_n - 1) / grid_n <= 10u) ? 1u : 0u); }
   // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,
   // ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9 random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
   // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.

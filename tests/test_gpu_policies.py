@@ -35,15 +35,17 @@ def _big_batch(request, fixture, Q):
     return _big[fixture]
 
 
-@pytest.mark.parametrize("summ_iters,max_wgs,spec_rows", [("-1", "0", "1"), ("3", "0", "2"), ("3", "96", "1"), ("-1", "96", "2"), ("0", "0", "0")])
+@pytest.mark.parametrize("summ_iters,max_wgs,spec_rows,prio", [("-1", "0", "1", "1"), ("3", "0", "2", "0"), ("3", "96", "1", "1"), ("-1", "96", "2", "0"), ("0", "0", "0", "")])
 @pytest.mark.parametrize("graph", [0, 1])
 @pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
-def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, summ_iters, max_wgs, spec_rows):
+def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, summ_iters, max_wgs, spec_rows, prio):
     import bang_amd
     ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: full for every instance
     monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
     monkeypatch.setenv("BANG_SEARCH_MAX_WGS", max_wgs)
     monkeypatch.setenv("BANG_SPEC_ROWS", spec_rows)          # (code rows requested with the filter probes: the 70-chunk fixture has the instance)
+    if prio:
+        monkeypatch.setenv("BANG_SEARCH_PRIO", prio)         # (raised wave priority around the request-issuing stretches: forced on / off; "" = the launch policy)
     with bang_amd.Engine(ix.dtype, graph=graph, search=1) as e:
         e.load_index(ix)
         e.set_searchparams(10, 64)

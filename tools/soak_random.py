@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: random index shapes / search parameters on the GPU against the oracle, all three loop forms (device graph, pull, walker), with
-the launch policies of the search kernel (BANG_SUMM_ITERS, BANG_SEARCH_MAX_WGS, BANG_SPEC_ROWS: instruction order and query hand-out,
+the launch policies of the search kernel (BANG_SUMM_ITERS, BANG_SEARCH_MAX_WGS, BANG_SPEC_ROWS, BANG_SEARCH_PRIO: instruction order and query hand-out,
 never results) drawn at random per case.
     python tools/soak_random.py [n_cases] [seed] [budget_seconds]
 Prints one line per failure and a summary; exit code 1 on any mismatch.  tests/test_gpu_policies.py runs a 60-second slice of it."""
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bang-billion-scale-ann_amd"))
 
-POLICY_KEYS = ("BANG_SUMM_ITERS", "BANG_SEARCH_MAX_WGS", "BANG_SPEC_ROWS")
+POLICY_KEYS = ("BANG_SUMM_ITERS", "BANG_SEARCH_MAX_WGS", "BANG_SPEC_ROWS", "BANG_SEARCH_PRIO")
 
 
 def run(n_cases=40, seed=7, budget_s=None, log=print):
@@ -43,7 +43,8 @@ def run(n_cases=40, seed=7, budget_s=None, log=print):
             k = int(rng.integers(1, min(L, 20) + 1))
             mips = bool(rng.integers(0, 5) == 0) and dtype == "float"
             policy = {"BANG_SUMM_ITERS": str(int(rng.choice([-1, 0, 1, 3, 40]))),
-                      "BANG_SEARCH_MAX_WGS": str(int(rng.choice([0, 0, 1, 3]))), "BANG_SPEC_ROWS": str(int(rng.integers(0, 3)))}
+                      "BANG_SEARCH_MAX_WGS": str(int(rng.choice([0, 0, 1, 3]))), "BANG_SPEC_ROWS": str(int(rng.integers(0, 3))),
+                      "BANG_SEARCH_PRIO": str(rng.choice(["0", "1", "auto"]))}
             try:
                 ix, q, _, _ = synth.make_index(N, D, dtype, R, m, Q, K=min(10, k), n_clusters=8, seed=int(rng.integers(1, 1 << 30)), pq_iters=2)
             except Exception as e:
