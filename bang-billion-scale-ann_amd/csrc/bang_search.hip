@@ -548,7 +548,8 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       // requests here, parent selection -> row request below -- run at raised priority, the reduce and the merge at the default: a wave that is about to
       // put requests in flight is not held up by its neighbours' arithmetic.  Pays where wave slots are free (2 500-query shard 2.24 -> 2.20 ms, 1 250:
       // 1.46 -> 1.44), costs a full chip 2 % (10 K batch 7.92 -> 8.12): on for launches of at most 10 queries per CU.
-      const bool prio = !HOST && IA32(IA_PRIO) != 0u;
+      const uint32_t prio_m = HOST ? 0u : IA32(IA_PRIO);     // bit 0: this stretch, bit 1: the hand-over's
+      const bool prio = (prio_m & 1u) != 0u;
       if (prio) __builtin_amdgcn_s_setprio(3);
       uint32_t GAS* bloom = IAPTR(uint32_t, IA_BLOOM) + (size_t)q * BANG_BF_WORDS;
       const uint32_t n_nodes = HOST ? 0u : IA32(IA_N_NODES);
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
       }
 
       // ---------------- K4: parent (compute_parent1 :1464-1521 / compute_parent2 :1384-1459) ----------------
-      if (prio) __builtin_amdgcn_s_setprio(3);                // parent selection -> row request
+      if (prio_m & 2u) __builtin_amdgcn_s_setprio(3);         // parent selection -> row request
       LANE_FRESH();
       // closest new neighbour: strict '<', first minimum wins, MEDOID skipped (:1413-1418)
       const bool elig = (uint32_t)lane < n && sid0 != medoid && d0 < BIG_DIST;
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(search_maxt(NDW, HOST)) void search_kernel(const Se
     }
 
     PH(8);     // hand-over: the next row is requested
-    if (!HOST && IA32(IA_PRIO) != 0u) __builtin_amdgcn_s_setprio(0);
+    if (!HOST && (IA32(IA_PRIO) & 2u) != 0u) __builtin_amdgcn_s_setprio(0);
     if (active && found && lane == 0) IAPTR(uint32_t, IA_CAND_IDS)[(size_t)q * cand_stride + cc - 1u] = parent;      // :1451-1458 (cc counts it already)
     if (active) {
       // ---------------- K3a + K3b: sort the survivors, merge them into the worklist ----------------
@@ -1088,7 +1089,7 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   if (a.p.summ_iters == 0u) a.p.summ_iters = light ? 1u : 0xFFFFFFFFu;
   a.iter.summ_iters = a.p.summ_iters;
   // wave priority around the request-issuing stretches of an iteration: on where wave slots are free (<= 10 queries per CU); BANG_SEARCH_PRIO = 0 / 1 forces it
-  { const char* e = getenv("BANG_SEARCH_PRIO"); a.iter.prio = (e && (e[0] == '0' || e[0] == '1')) ? (uint32_t)(e[0] - '0') : (((p->Q + grid_n - 1) / grid_n <= 10u) ? 1u : 0u); }
+  { const char* e = getenv("BANG_SEARCH_PRIO"); a.iter.prio = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] == '1' ? 3u : e[0] == '3' ? 1u : (uint32_t)(e[0] - '0')) : (((p->Q + grid_n - 1) / grid_n <= 10u) ? 3u : 0u); }   // (1 = both stretches, 2 = the hand-over's only, 3 = the top's only)
   // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,
   // ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9 random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
   // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.
