@@ -85,7 +85,7 @@ static const SwitchDef kSwitches[] = {
     {"BANG_FILTER_MEM", "visited filters in 1 = uncached / 2 = fine-grained device memory instead of ordinary device memory (experiment, read at bang_alloc)"},
     {"BANG_SUMM_ITERS", "search kernel, self-paced form: the filter summary serves a query's first N iterations only (0 = auto: all, off for launches of <= 5 queries per CU; -1 = all)"},
     {"BANG_SEARCH_PRIO", "search kernel, self-paced form: raised wave priority (s_setprio) for the stretches of an iteration that end in memory requests -- 1 = both (row arrival -> probes + code-row requests; parent selection -> row request), 2 = the second only, 3 = the first only, 0 = off; unset = auto: both for launches of <= 10 queries per CU"},
-    {"BANG_SPEC_ROWS", "search kernel, self-paced form, 70 / 74-chunk layouts: 1 = code rows of all ids of an adjacency row requested with their filter probes, 2 = behind the filter (survivors only), 0 = auto (1 where the rows are pulled, and for launches of <= 10 queries per CU where the graph is in HBM)"},
+    {"BANG_SPEC_ROWS", "search kernel, self-paced form, 70 / 74-chunk layouts: 1 = code rows of all ids of an adjacency row requested with their filter probes, 2 = behind the filter (survivors only), 0 = auto (1 where the rows are pulled, and for launches of <= 8 queries per CU where the graph is in HBM)"},
     {"BANG_WALKER_SELF_ROWS", "host-paced search kernel, walker-from-rows form: 0 = every row comes from the walker threads, also those this GPU holds in its HBM copy (A/B)"},
     {"BANG_SEARCH_GS", "host-paced search kernel: waves per pacing group (default 8)"},
     {"BANG_SEARCH_CTX", "host-paced search kernel: query contexts per wave (default 1; 2 measured slower)"},

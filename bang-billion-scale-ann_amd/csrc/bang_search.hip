@@ -1093,8 +1093,10 @@ extern "C" int bang_k_search(const bang_search_params* p, void* stream) {
   // spec_rows: one memory latency less on the chain of every iteration, the rows of the ids the filter drops fetched in vain.  Without / with,
   // ms per batch (profiles/r05_spec_rows.md) -- rows pulled, N = 1e9 random graph: 10 000 queries 8.75 / 8.38, 5 000 4.72 / 4.61, 2 500 2.33 / 2.29, 1 250 1.74 / 1.63; N = 1e8 Vamana-style graph, pulled:
   // 6.48 / 6.38, 1.77 / 1.77, 1.29 / 1.23; the same graph in HBM: 4.68 / 4.79, 1.44 / 1.41, 1.13 / 1.07.
-  // auto: on where the rows are pulled, and up to 10 queries per CU where the graph is in HBM
-  const bool spec_auto = p->row_layout != 0u || (p->Q + grid_n - 1) / grid_n <= 10u;
+  // auto: on where the rows are pulled, and up to 8 queries per CU where the graph is in HBM
+  // (round 6, final kernel, structured 1e8-point graph in HBM, without / with: 10 000 queries 4.40 / 4.62 ms, 2 500: 1.32 / 1.345, 2 000: 1.18 / 1.13, 1 250: 1.05 / 1.02, 625: 0.94 / 0.91;
+  //  the shape-only DEEP100M index -- its filter drops next to nothing -- 7.16 / 7.05 at 10 000: the policy follows the structured graph, up to 8 queries per CU)
+  const bool spec_auto = p->row_layout != 0u || (p->Q + grid_n - 1) / grid_n <= 8u;
   a.p.spec_rows = (search_has_spec((int)(p->mp / 4u)) && p->d_graph && (p->spec_rows == 1u || (p->spec_rows == 0u && spec_auto))) ? 1u : 2u;
   a.wl_words = search_wl_words(p->L);
   a.wave_words = search_wave_words(p->L, nctx, (int)(p->mp / 4u), p->d_graph == nullptr);

@@ -393,7 +393,7 @@ typedef struct {
   uint32_t spec_rows;                  /* self-paced form, 70- and 74-chunk layouts (the other instances ignore it): the PQ code rows of ALL ids of an adjacency row are
                                           requested together with their filter probes (1) -- one memory latency less per iteration, the rows of the ids the
                                           filter drops fetched in vain -- or behind the filter, survivors only (2); 0 = auto: 1 where the rows are pulled (row_layout), and
-                                          for launches of <= 10 queries per CU where the graph is in HBM. */
+                                          for launches of <= 8 queries per CU where the graph is in HBM. */
   /* K6 + K7 FUSED into the launch (self-paced form, 8-bit vectors; compute_L2Dist :1254-1299, compute_NearestNeighbours :1312-1368): the wave
    * that finishes a query re-ranks its candidate log on the spot -- exact distances to the full-precision vectors at rr_vec_base + id *
    * rr_vec_stride, stable rank by (distance, expansion order) -- and writes the query's k results; no second launch behind the search, and
