@@ -145,6 +145,27 @@ def test_search_kernel_lds_budget_arithmetic(libbang):
     assert g(2, 72, 58, 70) == 1 and g(2, 76, 22, 74) == 1 and g(2, 32, 20, 30) == 0 and g(4, 32, 0, 32) == 0
 
 
+def test_search_geometry_spreads_and_balances_a_batch(libbang):
+    """bang_search_geometry (host-side arithmetic of the bang_k_search launch; 256 CUs on an MI355X, and where no device answers): a batch
+    smaller than one wave-full per CU is spread over all CUs; one of one to two wave-fulls runs as two EQUAL rounds (self-paced form only);
+    larger batches use every wave that fits."""
+    f = libbang.bang_search_geometry
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint32] * 7 + [C.c_int] + [C.POINTER(C.c_uint32)] * 4
+
+    def geo(Q, host_paced=0, max_waves=0, layout=(2, 72, 58, 152)):
+        wg, w, nctx, gs = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        assert f(*layout, Q, 0, max_waves, host_paced, C.byref(wg), C.byref(w), C.byref(nctx), C.byref(gs)) == 0
+        return wg.value, w.value
+
+    assert geo(100) == (100, 1) and geo(1250) == (256, 5) and geo(2500) == (256, 10) and geo(3072) == (256, 12)
+    assert geo(3073) == (256, 7) and geo(3400) == (256, 7) and geo(4000) == (256, 8) and geo(5000) == (256, 10) and geo(6144) == (256, 12)
+    assert geo(6145) == (256, 12) and geo(10000) == (256, 12)                          # three rounds and more: every wave that fits
+    assert geo(5000, max_waves=8) == (256, 8) and geo(4000, max_waves=10) == (256, 8)  # (the cap first, then the balance under it)
+    assert geo(5000, host_paced=1)[1] == geo(10000, host_paced=1)[1]                   # host-paced groups are not re-balanced
+    assert geo(6000, layout=(4, 32, 0, 70)) == (256, 12) and geo(10000, layout=(4, 32, 0, 70)) == (256, 16)   # SIFT1M layout: 16 waves fit
+
+
 def test_no_gpu_means_error_not_fallback(libbang):
     """On a box without a HIP device every engine entry point must fail with BANG_ERR_NOGPU (-6)."""
     import bang_amd

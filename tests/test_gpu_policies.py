@@ -40,7 +40,8 @@ def _big_batch(request, fixture, Q):
 @pytest.mark.parametrize("fixture", ["small_u8", "small_deep", "small_f32"])
 def test_full_launch_policies_match_oracle(request, libbang, monkeypatch, fixture, graph, summ_iters, max_wgs, spec_rows, prio):
     import bang_amd
-    ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: full for every instance
+    ix, qq, ids_o, dists_o, st_o = _big_batch(request, fixture, 4300)        # > 256 CUs x 16 waves: queries handed out from the queue in every instance -- as two equal
+    # rounds of 9 waves per CU (bang_search_geometry) on the whole chip, as four to five rounds of every wave that fits on 96 workgroups
     monkeypatch.setenv("BANG_SUMM_ITERS", summ_iters)
     monkeypatch.setenv("BANG_SEARCH_MAX_WGS", max_wgs)
     monkeypatch.setenv("BANG_SPEC_ROWS", spec_rows)          # (code rows requested with the filter probes: the 70-chunk fixture has the instance)
