@@ -412,8 +412,9 @@ int bang_search_can_rerank(int dtype, uint32_t D, uint64_t vec_stride, uint32_t 
 int bang_k_search(const bang_search_params* p, void* stream);
 /* waves per workgroup that fit the 160 KB of LDS beside the pivot table at worklist length L (0: the kernel cannot run) */
 int bang_search_supported(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L);
-/* grid of a bang_k_search launch over Q queries: workgroups (<= CUs, <= max_wgs if nonzero), waves per workgroup and query
- * contexts per wave (*nctx in: 0 = auto, out: 1 or 2) and, host-paced form, waves per pacing group (*group_waves in: 0 = auto = 8) */
+/* grid of a bang_k_search launch over Q queries: workgroups (<= CUs, <= max_wgs if nonzero), waves per workgroup (every wave that fits,
+ * <= max_waves if nonzero; no more than a workgroup's share of Q needs; a self-paced batch of one to two wave-fulls per CU: half its share,
+ * two equal rounds) and query contexts per wave (*nctx in: 0 = auto, out: 1 or 2) and, host-paced form, waves per pacing group (*group_waves in: 0 = auto = 8) */
 int bang_search_geometry(uint32_t psz, uint32_t mp, uint32_t nhi, uint32_t L, uint32_t Q, uint32_t max_wgs, uint32_t max_waves,
                          int host_paced, uint32_t* workgroups, uint32_t* waves, uint32_t* nctx, uint32_t* group_waves);
 
